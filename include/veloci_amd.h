@@ -1,0 +1,206 @@
+/*
+ * veloci_amd.h — C ABI of the MI355X-native veloci query-execution path.
+ *
+ * This is the drop-in boundary.  The reference exposes the path as
+ *
+ *     pub fn search(request: Request, persistence: &Persistence)
+ *         -> Result<SearchResult, VelociError>              (src/search.rs:143)
+ *
+ * and has no FFI of its own; every entry point below states which reference
+ * interface it replaces.  Plain pointers and sizes only: a Rust `extern "C"`
+ * block, cgo or ctypes can bind it (INTEGRATION.md shows the Rust stub).
+ *
+ * Threading: a `vq_index` is immutable after `vq_index_build`; `vq_search*`
+ * may be called from many host threads on one index (reference: `Persistence:
+ * Sync`, src/persistence.rs:80-84).  Errors: every call returns `VQ_OK` or an
+ * error code and leaves a message for `vq_last_error()` (thread local) that
+ * reproduces the reference's `VelociError` rendering (src/error.rs:5-43).
+ */
+#ifndef VELOCI_AMD_H
+#define VELOCI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- errors */
+
+enum {
+    VQ_OK = 0,
+    /* VelociError::InvalidRequest (src/error.rs:11) and the reference's panics on
+       malformed plans (execution_plan.rs:220,408,437; plan_steps.rs:287) */
+    VQ_ERR_INVALID_REQUEST = 1,
+    /* VelociError::FstNotFound: "field does not exist {path} (fst not found)" (src/error.rs:35) */
+    VQ_ERR_FST_NOT_FOUND = 2,
+    /* VelociError::StringError("Did not found path in indices ...") (src/persistence.rs:454-458) */
+    VQ_ERR_INDEX_NOT_FOUND = 3,
+    /* request uses a feature outside the GPU hot path (select, why_found, snippet, regex, suggest,
+       token_value, explain): never silently ignored */
+    VQ_ERR_UNSUPPORTED = 4,
+    /* HIP runtime failure / no device / extension missing */
+    VQ_ERR_DEVICE = 5,
+    VQ_ERR_INVALID_ARGUMENT = 6,
+    /* serde_json parse failure of the request text (VelociError::JsonError) */
+    VQ_ERR_JSON = 7
+};
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* vq_last_error(void);
+
+/* ------------------------------------------------------- index (load side)
+ *
+ * Replaces `Persistence::load` + `PersistenceIndices` (src/persistence.rs:52-60,
+ * 206-291, 393-410) at the *decoded array* level: the caller (a Rust shim walking
+ * `persistence.indices`, or the synthetic generator) hands over every index as
+ * plain CSR arrays under the reference's own index names
+ * ("<field>.textindex.to_anchor_id_score", "...tokens_to_text_id", ...,
+ * suffix constants src/persistence.rs:23-50).  Arrays are copied; the caller may
+ * free them after the call returns.
+ *
+ * Sharding: an index holds the anchors (documents) in
+ * [doc_lo, doc_hi).  Anchor-valued lists may be passed whole or pre-sliced —
+ * the loader drops anchors outside the range.  Anchor-keyed stores take
+ * `key_base`: the id of the first key in the arrays handed over.
+ */
+typedef struct vq_index_builder vq_index_builder;
+typedef struct vq_index vq_index;
+
+vq_index_builder* vq_index_builder_new(uint32_t num_anchors, uint32_t doc_lo, uint32_t doc_hi);
+void vq_index_builder_free(vq_index_builder*);
+
+/* Term dictionary of "<field>.textindex" — replaces `indices.fst[path]`
+ * (src/persistence.rs:59; built at src/create/create_fulltext.rs:53-80).
+ * Terms are UTF-8, bytewise sorted, ordinal == term id. */
+int vq_index_add_fst(vq_index_builder*, const char* path, uint32_t num_terms,
+                     const uint8_t* term_bytes, const uint64_t* term_offsets /* [num_terms+1] */);
+
+/* Posting lists "<field>.textindex.to_anchor_id_score" — replaces
+ * `TokenToAnchorScore::get_score_iter` (src/persistence.rs:80-82,
+ * src/indices/persistence_score/token_to_anchor_score_vint.rs:150-204).
+ * Per token: anchors ascending & unique, integer scores as stored
+ * (converted to f16 with RNE at load, as `f16::from_f32(score as f32)` :155).
+ * `global_lens` (may be NULL) gives each list's length in the *unsharded* index;
+ * needed only when the arrays are pre-sliced to a shard. */
+int vq_index_add_token_to_anchor_score(vq_index_builder*, const char* path, uint32_t num_tokens,
+                                       const uint64_t* offsets /* [num_tokens+1] */,
+                                       const uint32_t* anchors, const uint32_t* scores,
+                                       const uint64_t* global_lens);
+
+/* Any `IndexIdToParent<Output=u32>` store (src/persistence.rs:142-181):
+ * ".tokens_to_text_id", ".text_id_to_anchor", ".parent_to_value_id",
+ * ".anchor_to_text_id", ".value_id_to_anchor", ".value_id_to_parent",
+ * ".text_id_to_token_ids".  Key k (k = key_base + row) maps to
+ * values[offsets[row] .. offsets[row+1]]. */
+int vq_index_add_key_value_store(vq_index_builder*, const char* path, uint32_t key_base,
+                                 uint32_t num_keys, const uint64_t* offsets, const uint32_t* values);
+
+/* "<field>.textindex.phrase_pair_to_anchor" — replaces
+ * `PhrasePairToAnchor::get_values((u32,u32))` (src/persistence.rs:84-87,
+ * src/indices/persistence_data_binary_search.rs:167-202).  Keys sorted by (t1,t2). */
+int vq_index_add_phrase_pair_to_anchor(vq_index_builder*, const char* path, uint64_t num_pairs,
+                                       const uint32_t* t1, const uint32_t* t2,
+                                       const uint64_t* offsets /* [num_pairs+1] */,
+                                       const uint32_t* anchors);
+
+/* "<field>.boost_valid_to_value" — replaces `persistence.get_boost(path)`
+ * (src/persistence.rs boost_valueid_to_value; read at src/search/boost.rs:490-494).
+ * `present[row]` != 0 when key (key_base+row) has a value; value_bits = f32 bits. */
+int vq_index_add_boost(vq_index_builder*, const char* path, uint32_t key_base, uint32_t num_keys,
+                       const uint8_t* present /* may be NULL = all present */,
+                       const uint32_t* value_bits);
+
+/* Column metadata consulted on the query path: `is_anchor_identity_column`
+ * (src/search/search_field.rs:474-480, src/search/boost.rs:60-66). */
+int vq_index_set_column_meta(vq_index_builder*, const char* field, int is_anchor_identity_column);
+
+/* Stage everything into HBM on `device` (padded segmented arrays) and return the
+ * immutable index.  The builder stays valid and must still be freed. */
+int vq_index_build(vq_index_builder*, int device, vq_index** out);
+void vq_index_free(vq_index*);
+
+/* Run this index's launches on an existing HIP stream (hipStream_t as void*);
+ * NULL restores the index's own stream. */
+int vq_index_set_stream(vq_index*, void* hip_stream);
+/* Bytes of HBM held by the staged image. */
+uint64_t vq_index_device_bytes(const vq_index*);
+
+/* --------------------------------------------------------------- requests
+ *
+ * `vq_request` == `search::Request` (src/search/request/mod.rs:15-87), parsed
+ * from its serde-JSON rendering.  Unknown keys are ignored (as serde does). */
+typedef struct vq_request vq_request;
+
+int vq_request_parse(const char* json, size_t len, vq_request** out);
+void vq_request_free(vq_request*);
+
+/* ---------------------------------------------------------------- results
+ *
+ * `vq_result` == `search::SearchResult` (src/search/result/search_result.rs:9-26). */
+typedef struct vq_result vq_result;
+
+uint64_t vq_result_num_hits(const vq_result*);
+uint64_t vq_result_execution_time_ns(const vq_result*);
+size_t vq_result_len(const vq_result*);            /* data.len() */
+const uint32_t* vq_result_ids(const vq_result*);   /* data[i].id    */
+const float* vq_result_scores(const vq_result*);   /* data[i].score */
+size_t vq_result_num_facets(const vq_result*);
+const char* vq_result_facet_field(const vq_result*, size_t facet);
+size_t vq_result_facet_len(const vq_result*, size_t facet);
+const char* vq_result_facet_value(const vq_result*, size_t facet, size_t i);
+uint64_t vq_result_facet_count(const vq_result*, size_t facet, size_t i);
+/* serde_json rendering of the SearchResult (ids/scores/facets), for diffing. */
+const char* vq_result_to_json(const vq_result*);
+void vq_result_free(vq_result*);
+
+/* ----------------------------------------------------------------- search */
+
+/* == search::search(request, &persistence) (src/search.rs:143-228). */
+int vq_search(const vq_index*, const vq_request*, vq_result** out);
+/* Same, from the request's JSON text. */
+int vq_search_json(const vq_index*, const char* json, size_t len, vq_result** out);
+/* Throughput path: n independent searches executed as one device batch
+ * (the reference's equivalent is n concurrent `search()` calls from server
+ * threads, server/rocket_server.rs:139-145).  out[i] receives request i's
+ * result, or NULL with status[i] != VQ_OK.  Returns VQ_OK when the batch ran. */
+int vq_search_batch(const vq_index*, const vq_request* const* requests, size_t n,
+                    vq_result** out, int* status);
+
+/* ------------------------------------------------- shard-partial interface
+ *
+ * New surface (the reference has no sharding): a shard returns
+ * its exact local top-(top+skip) with global doc ids, its local hit count and
+ * its facet histograms over value ids; `vq_merge_partials` turns the gathered
+ * partials of all shards into the final results.  The gather itself is done by
+ * the caller (RCCL all-gather of the packed buffers). */
+typedef struct vq_partial_batch vq_partial_batch;
+
+int vq_search_batch_partial(const vq_index*, const vq_request* const* requests, size_t n,
+                            vq_partial_batch** out);
+/* Packed, fixed-size representation of the partials (same size on every shard
+ * for the same requests).  Resident in HBM: `device_ptr` can be handed to RCCL. */
+size_t vq_partial_bytes(const vq_partial_batch*);
+void* vq_partial_device_ptr(vq_partial_batch*);
+/* Merge `num_shards` gathered packed buffers (device memory, shard-major,
+ * each `vq_partial_bytes` long) into final results. */
+int vq_merge_partials(const vq_index*, vq_partial_batch* local, const void* gathered_device,
+                      uint32_t num_shards, vq_result** out, int* status);
+void vq_partial_free(vq_partial_batch*);
+
+/* ------------------------------------------------------------ measurement */
+
+/* Device time (ms, HIP events on the index's stream) and launch count of the
+ * dominant scan kernel accumulated since the last call with reset != 0. */
+int vq_profile_read(const vq_index*, int reset, double* scan_kernel_ms, uint64_t* scan_launches,
+                    uint64_t* algorithmic_bytes);
+/* Enable (1) / disable (0) the HIP-event bracketing used by vq_profile_read. */
+int vq_profile_enable(vq_index*, int on);
+
+const char* vq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELOCI_AMD_H */
