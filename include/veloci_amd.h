@@ -113,8 +113,9 @@ int vq_index_add_boost(vq_index_builder*, const char* path, uint32_t key_base, u
                        const uint32_t* value_bits);
 
 /* Column metadata consulted on the query path: `is_anchor_identity_column`
- * (src/search/search_field.rs:474-480, src/search/boost.rs:60-66). */
-int vq_index_set_column_meta(vq_index_builder*, const char* field, int is_anchor_identity_column);
+ * (src/search/search_field.rs:474-480, src/search/boost.rs:60-66) and
+ * `textindex_metadata.options.tokenize` (src/search/search_field.rs:650-658). */
+int vq_index_set_column_meta(vq_index_builder*, const char* field, int is_anchor_identity_column, int tokenize);
 
 /* Stage everything into HBM on `device` (padded segmented arrays) and return the
  * immutable index.  The builder stays valid and must still be freed. */

@@ -32,16 +32,12 @@
 #include <vector>
 
 #include "../veloci_amd/csrc/json.hpp"
+#include "../veloci_amd/csrc/request.hpp"
 #include "../veloci_amd/csrc/text.hpp"
 
 namespace vo {
 
-// ------------------------------------------------------------------ errors (src/error.rs:5-43)
-struct VelociError : std::runtime_error {
-    int code;  // same numbering as include/veloci_amd.h
-    VelociError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-enum { OK = 0, ERR_INVALID_REQUEST = 1, ERR_FST_NOT_FOUND = 2, ERR_INDEX_NOT_FOUND = 3, ERR_UNSUPPORTED = 4, ERR_JSON = 7 };
+using namespace vqreq;  // Request structs, VelociError and error codes (wire-format plumbing shared with the product)
 
 // ------------------------------------------------------------------ half (half 2.3.1: f16::from_f32 / to_f32)
 inline uint16_t f32_to_f16_bits(float f) {
@@ -95,85 +91,6 @@ struct Hit {  // src/search.rs:53-57
     uint32_t id;
     float score;
 };
-
-enum class BoostFunction { Log2, Log10, Multiply, Add, Replace };  // src/search/request/boost_request.rs:22-33
-
-struct RequestBoostPart {  // src/search/request/boost_request.rs:3-20
-    std::string path;
-    std::optional<BoostFunction> boost_fun;
-    std::optional<float> param;
-    std::optional<std::vector<float>> skip_when_score;
-    std::optional<std::string> expression;
-    std::string key() const;
-};
-
-struct SearchRequestOptions {  // src/search/request/search_request.rs:103-119
-    bool explain = false;
-    std::optional<size_t> top, skip;
-    std::optional<std::vector<RequestBoostPart>> boost;
-    std::string key() const;
-};
-
-struct RequestSearchPart {  // src/search/request/search_request.rs:127-179
-    std::string path;
-    std::vector<std::string> terms;
-    std::optional<uint32_t> levenshtein_distance;
-    bool starts_with = false;
-    bool is_regex = false;
-    std::optional<RequestBoostPart> token_value;
-    std::optional<float> boost;
-    std::optional<bool> ignore_case;
-    std::optional<bool> snippet;
-    bool has_snippet_info = false;
-    std::optional<size_t> top, skip;
-    std::optional<SearchRequestOptions> options;
-    std::string key() const;  // stands in for derive(PartialEq, Hash): equal keys <=> equal requests
-};
-
-struct SearchRequest;
-struct SearchTree {  // src/search/request/search_request.rs:15-23
-    std::vector<SearchRequest> queries;
-    std::optional<SearchRequestOptions> options;
-};
-struct SearchRequest {  // src/search/request/search_request.rs:6-13
-    enum Kind { Or, And, Search } kind = Search;
-    SearchTree tree;
-    RequestSearchPart part;
-    const std::optional<SearchRequestOptions>& get_options() const { return kind == Search ? part.options : tree.options; }
-};
-
-struct FacetRequest {  // src/search/request/facet_request.rs:2-11
-    std::string field;
-    std::optional<size_t> top = 10;
-};
-struct RequestPhraseBoost {  // src/search/request/mod.rs:89-93
-    RequestSearchPart search1, search2;
-};
-
-struct Request {  // src/search/request/mod.rs:15-87
-    std::optional<SearchRequest> search_req;
-    bool has_suggest = false;
-    std::optional<std::vector<RequestBoostPart>> boost;
-    std::optional<std::vector<RequestSearchPart>> boost_term;
-    std::optional<std::vector<FacetRequest>> facets;
-    std::optional<std::vector<RequestPhraseBoost>> phrase_boosts;
-    bool has_select = false;
-    std::optional<SearchRequest> filter;
-    std::optional<size_t> top = 10;  // default_top, src/search.rs:46-48
-    std::optional<size_t> skip;
-    bool why_found = false;
-    bool text_locality = false;
-    bool explain = false;
-};
-
-Request request_from_json(const vqjson::Value& v);
-inline Request request_from_json_text(const char* s, size_t n) {
-    try {
-        return request_from_json(vqjson::parse(s, n));
-    } catch (const vqjson::ParseError& e) {
-        throw VelociError(ERR_JSON, std::string("JsonError: ") + e.what());
-    }
-}
 
 using TermIdHits = std::map<std::string, std::map<std::string, std::vector<uint32_t>>>;  // path -> term -> term ids
 

@@ -1,0 +1,242 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded synthetic corpora.
+Doc-id lists bit-exact; f32 scores bit-exact wherever only + * / are involved, 1e-5 relative for log boosts."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def corpus():
+    import veloci_amd
+    from veloci_amd import synth
+    from oracle import binding as O
+    spec = synth.SynthSpec(num_docs=300_000, num_terms=5000, triples=2, extra_probe_dfs=(1000, 30_000, 300_000), background_terms=40)
+    data, meta = synth.generate(spec)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    return data, meta, idx, ora
+
+
+def check(corpus, req, exact_scores=True):
+    import veloci_amd
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    got = veloci_amd.search(req, idx)
+    want = ora.search_json(json.dumps(req))
+    assert_same(req, got, want, exact_scores)
+    return got
+
+
+def test_native_library_is_loaded():
+    import veloci_amd
+    assert veloci_amd.lib_path().endswith("libveloci_amd.so")
+    assert b"gfx950" in veloci_amd.lib().vq_version()
+
+
+def test_single_term(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    for t in meta.extra_probes + list(meta.triples[0]):
+        for top in (1, 10, 100):
+            r = check(corpus, synth.req_single(t, top=top))
+            assert r.num_hits > 0
+
+
+def test_single_term_skip(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    t = meta.extra_probes[1]
+    check(corpus, synth.req_single(t, top=10, skip=5))
+    r = check(corpus, synth.req_single(meta.extra_probes[0], top=10, skip=1000))
+    check(corpus, synth.req_single(t, top=0))
+    assert len(r.ids) == min(10, max(0, r.num_hits - 1000))
+
+
+def test_unknown_term_and_background(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    r = check(corpus, synth.req_single("zzzzzzzzzzzzzzzzzzzz"))
+    assert r.num_hits == 0 and len(r.ids) == 0
+    for t in meta.background[:10]:
+        check(corpus, synth.req_single(t))
+
+
+def test_case_insensitive_default(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    t = meta.extra_probes[0]
+    check(corpus, synth.req_single(t.upper()))
+    check(corpus, {"search_req": {"search": {"path": "body", "terms": [t.upper()], "ignore_case": False}}})
+
+
+def test_and(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    for tri in meta.triples:
+        a, b, c = tri
+        for terms in ([a, b], [b, c], [a, b, c], [c, b, a], [b, a, c]):
+            r = check(corpus, synth.req_and(terms))
+            assert r.num_hits > 0
+    check(corpus, synth.req_and([meta.triples[0][0], meta.triples[1][2], meta.extra_probes[2]], top=50))
+    check(corpus, synth.req_and([meta.triples[0][0], "zzzzzzzzzzzzzzz"]))
+
+
+def test_or(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    check(corpus, synth.req_or([a, b]))
+    check(corpus, synth.req_or([a, b, c], top=25))
+    check(corpus, synth.req_or([c, meta.extra_probes[0], meta.background[3]]))
+    check(corpus, synth.req_or([a, a]))  # same term twice: one slot (set_op.rs:143,176)
+
+
+def test_nested(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    d, e, f = meta.triples[1]
+    leaf = lambda t: {"search": {"path": "body", "terms": [t]}}
+    check(corpus, {"search_req": {"and": {"queries": [{"or": {"queries": [leaf(a), leaf(d)]}}, {"or": {"queries": [leaf(b), leaf(e)]}}]}}})
+    check(corpus, {"search_req": {"or": {"queries": [{"or": {"queries": [leaf(a), leaf(d)]}}, leaf(c)]}}})
+    check(corpus, {"search_req": {"and": {"queries": [leaf(a)]}}})
+    check(corpus, {"search_req": {"or": {"queries": [{"and": {"queries": [leaf(a), leaf(b), leaf(c)]}}, leaf(f)]}}})
+
+
+def test_leaf_boost(corpus):
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    check(corpus, {"search_req": {"or": {"queries": [{"search": {"path": "body", "terms": [a], "boost": 2.5}}, {"search": {"path": "body", "terms": [b], "boost": 0.3}}]}}})
+
+
+def test_phrase_and_locality(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    for tri in meta.triples:
+        check(corpus, synth.req_and_phrase_locality(list(tri)))
+    a, b, c = meta.triples[0]
+    r = synth.req_or([a, b, c])
+    r["text_locality"] = True
+    check(corpus, r)
+    r2 = synth.req_and([a, b])
+    r2["phrase_boosts"] = [{"search1": {"path": "body", "terms": [a]}, "search2": {"path": "body", "terms": [b]}}]
+    check(corpus, r2)
+
+
+def test_column_boosts(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    for fun, exact in (("Multiply", True), ("Add", True), ("Replace", True), ("Log10", False), ("Log2", False)):
+        r = synth.req_and([a, b])
+        r["boost"] = [{"path": "pop", "boost_fun": fun, "param": 1.0}]
+        check(corpus, r, exact_scores=exact)
+    r = synth.req_and([a, b])
+    r["boost"] = [{"path": "pop", "boost_fun": "Add", "expression": "$SCORE * 2.0"}, {"path": "pop", "boost_fun": "Multiply", "skip_when_score": [20.6]}]
+    check(corpus, r)
+
+
+def test_and_of_ors_full(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    d, e, f = meta.triples[1]
+    check(corpus, synth.req_and_of_ors([a, b], [c, d]), exact_scores=False)
+
+
+def test_facets(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    r = synth.req_and([a, b])
+    r["facets"] = [{"field": "cat"}, {"field": "tags[]", "top": 5}]
+    got = check(corpus, r)
+    assert got.facets and len(got.facets["cat"]) == 10 and len(got.facets["tags[]"]) == 5
+    r = synth.req_single(meta.extra_probes[2])
+    r["facets"] = [{"field": "tags[]", "top": 50}]
+    check(corpus, r)
+
+
+def test_filter(corpus):
+    from veloci_amd import synth
+    data, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    # identity column: filter ids are the matched TERM ids taken as anchors (search_field.rs:474-481)
+    leaf = lambda t: {"search": {"path": "body", "terms": [t]}}
+    r = synth.req_or([a, b, c], top=20)
+    r["filter"] = {"or": {"queries": [leaf(t) for t in meta.background[:20]]}}
+    check(corpus, r)
+
+
+def test_boost_term(corpus):
+    from veloci_amd import synth
+    _, meta, _, _ = corpus
+    a, b, c = meta.triples[0]
+    r = synth.req_or([a, b, c], top=20)
+    r["boost_term"] = [{"path": "body", "terms": [t], "boost": 3.0} for t in meta.background[:5]] + [{"path": "body", "terms": [meta.background[6]]}]
+    check(corpus, r)
+
+
+def test_errors(corpus):
+    import veloci_amd
+    _, meta, idx, ora = corpus
+    req = {"search_req": {"search": {"path": "nofield", "terms": ["x"]}}}
+    with pytest.raises(veloci_amd.VelociError) as ei:
+        veloci_amd.search(req, idx)
+    # pinned text: tests/all/tests.rs:422-436 of the reference
+    assert ei.value.code == 2 and str(ei.value) == "field does not exist nofield.textindex (fst not found)"
+    from oracle.binding import OracleError
+    with pytest.raises(OracleError) as eo:
+        ora.search_json(json.dumps(req))
+    assert str(eo.value) == str(ei.value)
+    with pytest.raises(veloci_amd.VelociError) as e2:
+        veloci_amd.search({"top": 3}, idx)
+    assert e2.value.code == 1
+    with pytest.raises(veloci_amd.VelociError) as e3:
+        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"]}}, "why_found": True}, idx)
+    assert e3.value.code == 4
+
+
+def test_batch_equals_single(corpus):
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    _, meta, idx, ora = corpus
+    reqs = []
+    for tri in meta.triples:
+        reqs += [synth.req_and(list(tri)), synth.req_or(list(tri)), synth.req_and_phrase_locality(list(tri)), synth.req_single(tri[0], top=3)]
+    reqs += [synth.req_single(t) for t in meta.extra_probes + meta.background[:8]]
+    reqs = reqs * 4
+    got = veloci_amd.search_batch(reqs, idx)
+    for r, g in zip(reqs, got):
+        assert_same(r, g, ora.search_json(json.dumps(r)))
+
+
+def test_two_shards_merge_equals_unsharded(corpus):
+    """doc-range shards + packed partials + merge == the unsharded result, bit for bit."""
+    import torch
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    N = data.num_anchors
+    cut = N // 3
+    s0 = veloci_amd.Index(data, device=0, doc_lo=0, doc_hi=cut)
+    s1 = veloci_amd.Index(data, device=0, doc_lo=cut, doc_hi=N)
+    a, b, c = meta.triples[0]
+    reqs = [synth.req_and([a, b, c]), synth.req_or([a, b, c], top=30), synth.req_and_phrase_locality([a, b, c]), synth.req_single(meta.extra_probes[0])]
+    reqs[1]["facets"] = [{"field": "cat"}, {"field": "tags[]", "top": 7}]
+    p0 = veloci_amd.PartialBatch(s0, reqs)
+    p1 = veloci_amd.PartialBatch(s1, reqs)
+    assert p0.nbytes == p1.nbytes
+    from veloci_amd.dist import device_view
+    g = torch.cat([device_view(p0.device_ptr, p0.nbytes).clone(), device_view(p1.device_ptr, p1.nbytes).clone()])
+    torch.cuda.synchronize()
+    res = p0.merge(g.data_ptr(), 2)
+    p1.merge(None, 1)  # releases the shard's workspace
+    for r, got in zip(reqs, res):
+        assert_same(r, got, ora.search_json(json.dumps(r)))

@@ -1,0 +1,346 @@
+// extern "C" boundary (include/veloci_amd.h).  No torch types, no exceptions across the ABI.
+#include <cstring>
+
+#include "../../include/veloci_amd.h"
+#include "engine.hpp"
+
+using namespace vq;
+using vqreq::Request;
+using vqreq::VelociError;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+template <class F>
+int guard(F f) {
+    try {
+        f();
+        g_err.clear();
+        return VQ_OK;
+    } catch (const VelociError& e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(VQ_ERR_DEVICE, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(VQ_ERR_INVALID_ARGUMENT, e.what());
+    }
+}
+
+void json_f32(std::string& out, float f) {
+    char buf[40];
+    std::snprintf(buf, sizeof buf, "%.9g", double(f));
+    out += buf;
+    if (!std::strpbrk(buf, ".eEni")) out += ".0";
+}
+}  // namespace
+
+struct vq_index_builder {
+    IndexBuilder b;
+};
+struct vq_index {
+    std::unique_ptr<Index> idx;
+};
+struct vq_request {
+    Request req;
+};
+struct vq_result {
+    Result r;
+};
+struct vq_partial_batch {
+    std::unique_ptr<PartialBatch> pb;
+};
+
+extern "C" {
+
+const char* vq_last_error(void) { return g_err.c_str(); }
+const char* vq_version(void) { return "veloci_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ index
+vq_index_builder* vq_index_builder_new(uint32_t num_anchors, uint32_t doc_lo, uint32_t doc_hi) {
+    auto* b = new vq_index_builder();
+    b->b.num_anchors = num_anchors;
+    b->b.doc_lo = doc_lo;
+    b->b.doc_hi = doc_hi;
+    return b;
+}
+void vq_index_builder_free(vq_index_builder* b) { delete b; }
+
+int vq_index_add_fst(vq_index_builder* b, const char* path, uint32_t num_terms, const uint8_t* term_bytes, const uint64_t* term_offsets) {
+    return guard([&] {
+        if (!b || !path || (num_terms && (!term_bytes || !term_offsets))) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_fst: null argument");
+        HostFst f;
+        f.terms.reserve(num_terms);
+        for (uint32_t i = 0; i < num_terms; ++i) {
+            f.terms.emplace_back(reinterpret_cast<const char*>(term_bytes) + term_offsets[i], size_t(term_offsets[i + 1] - term_offsets[i]));
+            if (i && !(f.terms[i - 1] < f.terms[i])) throw VelociError(VQ_ERR_INVALID_ARGUMENT, std::string("terms must be bytewise sorted and unique: ") + path);
+        }
+        b->b.fst[path] = std::move(f);
+    });
+}
+
+int vq_index_add_token_to_anchor_score(vq_index_builder* b, const char* path, uint32_t num_tokens, const uint64_t* offsets, const uint32_t* anchors,
+                                       const uint32_t* scores, const uint64_t* global_lens) {
+    return guard([&] {
+        if (!b || !path || !offsets) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_token_to_anchor_score: null argument");
+        HostPostings p;
+        p.offsets.assign(offsets, offsets + num_tokens + 1);
+        const uint64_t n = offsets[num_tokens];
+        if (n && (!anchors || !scores)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_token_to_anchor_score: null arrays");
+        p.anchors.assign(anchors, anchors + n);
+        p.scores.assign(scores, scores + n);
+        for (uint32_t t = 0; t < num_tokens; ++t)
+            for (uint64_t i = offsets[t] + 1; i < offsets[t + 1]; ++i)
+                if (!(anchors[i - 1] < anchors[i])) throw VelociError(VQ_ERR_INVALID_ARGUMENT, std::string("posting lists must be ascending and unique: ") + path);
+        if (global_lens) p.global_lens.assign(global_lens, global_lens + num_tokens);
+        b->b.postings[path] = std::move(p);
+    });
+}
+
+int vq_index_add_key_value_store(vq_index_builder* b, const char* path, uint32_t key_base, uint32_t num_keys, const uint64_t* offsets,
+                                 const uint32_t* values) {
+    return guard([&] {
+        if (!b || !path || !offsets) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_key_value_store: null argument");
+        HostKV k;
+        k.key_base = key_base;
+        k.offsets.assign(offsets, offsets + num_keys + 1);
+        const uint64_t n = offsets[num_keys];
+        if (n && !values) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_key_value_store: null values");
+        k.values.assign(values, values + n);
+        b->b.kv[path] = std::move(k);
+    });
+}
+
+int vq_index_add_phrase_pair_to_anchor(vq_index_builder* b, const char* path, uint64_t num_pairs, const uint32_t* t1, const uint32_t* t2,
+                                       const uint64_t* offsets, const uint32_t* anchors) {
+    return guard([&] {
+        if (!b || !path || !offsets) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_phrase_pair_to_anchor: null argument");
+        HostPhrase p;
+        p.t1.assign(t1, t1 + num_pairs);
+        p.t2.assign(t2, t2 + num_pairs);
+        p.offsets.assign(offsets, offsets + num_pairs + 1);
+        p.anchors.assign(anchors, anchors + offsets[num_pairs]);
+        b->b.phrase[path] = std::move(p);
+    });
+}
+
+int vq_index_add_boost(vq_index_builder* b, const char* path, uint32_t key_base, uint32_t num_keys, const uint8_t* present, const uint32_t* value_bits) {
+    return guard([&] {
+        if (!b || !path || (num_keys && !value_bits)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_add_boost: null argument");
+        HostBoost h;
+        h.key_base = key_base;
+        if (present) h.present.assign(present, present + num_keys);
+        h.bits.assign(value_bits, value_bits + num_keys);
+        b->b.boost[path] = std::move(h);
+    });
+}
+
+int vq_index_set_column_meta(vq_index_builder* b, const char* field, int is_anchor_identity_column, int tokenize) {
+    return guard([&] {
+        if (!b || !field) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_column_meta: null argument");
+        ColumnMeta m;
+        m.is_anchor_identity_column = is_anchor_identity_column != 0;
+        m.tokenize = tokenize != 0;
+        b->b.columns[field] = m;
+    });
+}
+
+int vq_index_build(vq_index_builder* b, int device, vq_index** out) {
+    return guard([&] {
+        if (!b || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_build: null argument");
+        *out = nullptr;
+        auto idx = build_index(b->b, device);
+        auto* h = new vq_index();
+        h->idx = std::move(idx);
+        *out = h;
+    });
+}
+void vq_index_free(vq_index* i) { delete i; }
+
+int vq_index_set_stream(vq_index* i, void* hip_stream) {
+    return guard([&] {
+        if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_stream: null index");
+        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        i->idx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_stream;
+    });
+}
+uint64_t vq_index_device_bytes(const vq_index* i) { return i ? i->idx->device_bytes : 0; }
+
+// ------------------------------------------------------------------ requests
+int vq_request_parse(const char* json, size_t len, vq_request** out) {
+    return guard([&] {
+        if (!json || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_request_parse: null argument");
+        *out = nullptr;
+        auto* r = new vq_request();
+        try {
+            r->req = vqreq::request_from_json_text(json, len);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+    });
+}
+void vq_request_free(vq_request* r) { delete r; }
+
+// ------------------------------------------------------------------ results
+uint64_t vq_result_num_hits(const vq_result* r) { return r->r.num_hits; }
+uint64_t vq_result_execution_time_ns(const vq_result* r) { return r->r.execution_time_ns; }
+size_t vq_result_len(const vq_result* r) { return r->r.ids.size(); }
+const uint32_t* vq_result_ids(const vq_result* r) { return r->r.ids.data(); }
+const float* vq_result_scores(const vq_result* r) { return r->r.scores.data(); }
+size_t vq_result_num_facets(const vq_result* r) { return r->r.facets.size(); }
+const char* vq_result_facet_field(const vq_result* r, size_t f) { return r->r.facets[f].field.c_str(); }
+size_t vq_result_facet_len(const vq_result* r, size_t f) { return r->r.facets[f].entries.size(); }
+const char* vq_result_facet_value(const vq_result* r, size_t f, size_t i) { return r->r.facets[f].entries[i].first.c_str(); }
+uint64_t vq_result_facet_count(const vq_result* r, size_t f, size_t i) { return r->r.facets[f].entries[i].second; }
+const char* vq_result_to_json(const vq_result* r) {
+    std::string& s = r->r.json;
+    s.clear();
+    s += "{\"execution_time_ns\":" + std::to_string(r->r.execution_time_ns) + ",\"num_hits\":" + std::to_string(r->r.num_hits) + ",\"data\":[";
+    for (size_t i = 0; i < r->r.ids.size(); ++i) {
+        if (i) s += ',';
+        s += "{\"id\":" + std::to_string(r->r.ids[i]) + ",\"score\":";
+        json_f32(s, r->r.scores[i]);
+        s += '}';
+    }
+    s += "],\"ids\":[]";
+    if (r->r.has_facets) {
+        s += ",\"facets\":{";
+        for (size_t f = 0; f < r->r.facets.size(); ++f) {
+            if (f) s += ',';
+            vqjson::escape_to(s, r->r.facets[f].field);
+            s += ":[";
+            for (size_t i = 0; i < r->r.facets[f].entries.size(); ++i) {
+                if (i) s += ',';
+                s += '[';
+                vqjson::escape_to(s, r->r.facets[f].entries[i].first);
+                s += ',' + std::to_string(r->r.facets[f].entries[i].second) + ']';
+            }
+            s += ']';
+        }
+        s += '}';
+    }
+    s += '}';
+    return s.c_str();
+}
+void vq_result_free(vq_result* r) { delete r; }
+
+// ------------------------------------------------------------------ search
+static int run_batch(const vq_index* index, const vq_request* const* requests, size_t n, vq_result** out, int* status, std::string* first_error) {
+    std::vector<const Request*> reqs(n);
+    for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
+    auto pb = run_partial(*index->idx, reqs.data(), n);
+    std::vector<std::unique_ptr<Result>> results;
+    std::vector<int> st;
+    std::vector<std::string> errs;
+    finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = nullptr;
+        if (status) status[i] = st[i];
+        if (st[i] == 0) {
+            auto* r = new vq_result();
+            r->r = std::move(*results[i]);
+            out[i] = r;
+        } else if (first_error && first_error->empty()) *first_error = errs[i];
+    }
+    return 0;
+}
+
+int vq_search(const vq_index* index, const vq_request* request, vq_result** out) {
+    int st = 0;
+    std::string err;
+    int rc = guard([&] {
+        if (!index || !request || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search: null argument");
+        *out = nullptr;
+        const vq_request* arr[1] = {request};
+        run_batch(index, arr, 1, out, &st, &err);
+    });
+    if (rc != VQ_OK) return rc;
+    if (st != 0) return fail(st, err);
+    return VQ_OK;
+}
+
+int vq_search_json(const vq_index* index, const char* json, size_t len, vq_result** out) {
+    vq_request* req = nullptr;
+    int rc = vq_request_parse(json, len, &req);
+    if (rc != VQ_OK) return rc;
+    rc = vq_search(index, req, out);
+    vq_request_free(req);
+    return rc;
+}
+
+int vq_search_batch(const vq_index* index, const vq_request* const* requests, size_t n, vq_result** out, int* status) {
+    return guard([&] {
+        if (!index || (n && (!requests || !out))) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch: null argument");
+        std::string err;
+        run_batch(index, requests, n, out, status, &err);
+        if (!err.empty()) g_err = err;
+    });
+}
+
+// ------------------------------------------------------------------ shard partials
+int vq_search_batch_partial(const vq_index* index, const vq_request* const* requests, size_t n, vq_partial_batch** out) {
+    return guard([&] {
+        if (!index || !out || (n && !requests)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_partial: null argument");
+        *out = nullptr;
+        std::vector<const Request*> reqs(n);
+        for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
+        auto pb = run_partial(*index->idx, reqs.data(), n);
+        VQ_HIP(hipStreamSynchronize(index->idx->stream));  // the packed buffer is handed to another library (RCCL)
+        auto* h = new vq_partial_batch();
+        h->pb = std::move(pb);
+        *out = h;
+    });
+}
+size_t vq_partial_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.bytes) : 0; }
+void* vq_partial_device_ptr(vq_partial_batch* p) { return p ? p->pb->d_partial : nullptr; }
+
+int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, vq_result** out, int* status) {
+    return guard([&] {
+        if (!index || !local || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_merge_partials: null argument");
+        std::vector<std::unique_ptr<Result>> results;
+        std::vector<int> st;
+        std::vector<std::string> errs;
+        finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
+        for (size_t i = 0; i < results.size(); ++i) {
+            out[i] = nullptr;
+            if (status) status[i] = st[i];
+            if (st[i] == 0) {
+                auto* r = new vq_result();
+                r->r = std::move(*results[i]);
+                out[i] = r;
+            } else if (g_err.empty()) g_err = errs[i];
+        }
+    });
+}
+void vq_partial_free(vq_partial_batch* p) { delete p; }
+
+// ------------------------------------------------------------------ measurement
+int vq_profile_enable(vq_index* i, int on) {
+    return guard([&] {
+        if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_profile_enable: null index");
+        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        i->idx->profile.enabled = on != 0;
+    });
+}
+int vq_profile_read(const vq_index* i, int reset, double* scan_kernel_ms, uint64_t* scan_launches, uint64_t* algorithmic_bytes) {
+    return guard([&] {
+        if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_profile_read: null index");
+        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        Profile& p = i->idx->profile;
+        if (scan_kernel_ms) *scan_kernel_ms = p.scan_ms;
+        if (scan_launches) *scan_launches = p.scan_launches;
+        if (algorithmic_bytes) *algorithmic_bytes = p.algorithmic_bytes;
+        if (reset) {
+            p.scan_ms = 0;
+            p.scan_launches = 0;
+            p.algorithmic_bytes = 0;
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,668 @@
+// Query compiler: search::Request -> device program (lists + postfix ops + sink stages).
+//
+// Mirrors what the reference does while it creates and wires its plan
+// (src/plan_creator/execution_plan.rs:91-534, plan_steps.rs:137-345) and the host-only bookkeeping of
+// search() (src/search.rs:143-228): leaf de-duplication, filter / boost / phrase wiring, term-id
+// bookkeeping for text locality, path algebra.  Everything that touches postings, scores or hit
+// lists is NOT done here — it is encoded for k_tile_scan.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <set>
+
+#include "engine.hpp"
+#include "text.hpp"
+
+namespace vq {
+
+using namespace vqreq;
+
+namespace {
+
+bool ends_with(const std::string& s, const char* suf) {
+    size_t n = std::strlen(suf);
+    return s.size() >= n && std::memcmp(s.data() + s.size() - n, suf, n) == 0;
+}
+
+[[noreturn]] void unsupported(const std::string& what) {
+    throw VelociError(ERR_UNSUPPORTED, "unsupported on the MI355X query path: " + what);
+}
+
+// reference src/util.rs:147-162
+std::vector<std::string> get_steps_to_anchor(const std::string& path) {
+    std::vector<std::string> paths;
+    std::string current;
+    size_t start = 0;
+    while (true) {
+        size_t dot = path.find('.', start);
+        std::string part = path.substr(start, dot == std::string::npos ? std::string::npos : dot - start);
+        if (!current.empty()) current += ".";
+        current += part;
+        if (ends_with(part, "[]")) paths.push_back(current);
+        if (dot == std::string::npos) break;
+        start = dot + 1;
+    }
+    paths.push_back(path + TEXTINDEX);
+    return paths;
+}
+
+// search_field.rs:27-33
+float default_score_for_distance(uint8_t distance, bool prefix_matches) {
+    if (prefix_matches) return 2.0f / (std::log2(float(distance) + 1.0f) + 0.2f);
+    return 2.0f / (float(distance) + 0.2f);
+}
+
+bool cp_eq(uint32_t a, uint32_t b, bool ci) { return a == b || (ci && vqtext::lower_cp(a) == vqtext::lower_cp(b)); }
+
+// expression.rs:48-95 — "x op y", x/y = $SCORE or a float
+void parse_expression(const std::string& expression, DColBoost& cb) {
+    struct Tok {
+        int kind;  // 0 score, 1 float, 2.. operators (2 div, 3 mul, 4 add, 5 sub)
+        float val;
+    };
+    std::vector<Tok> ops;
+    std::string current;
+    auto try_float = [](const std::string& s, float& out) {
+        if (s.empty()) return false;
+        char* end = nullptr;
+        out = std::strtof(s.c_str(), &end);
+        return end && *end == 0 && end != s.c_str();
+    };
+    for (char ch : expression) {
+        if (ch == ' ') {
+            float v;
+            if (try_float(current, v)) ops.push_back({1, v});
+            current.clear();
+        } else current.push_back(ch);
+        if (current == "+") ops.push_back({4, 0}), current.clear();
+        else if (current == "-") ops.push_back({5, 0}), current.clear();
+        else if (current == "/") ops.push_back({2, 0}), current.clear();
+        else if (current == "*") ops.push_back({3, 0}), current.clear();
+        else if (current == "$SCORE") ops.push_back({0, 0}), current.clear();
+    }
+    float v;
+    if (try_float(current, v)) ops.push_back({1, v});
+    if (ops.size() < 3 || ops[0].kind > 1 || ops[2].kind > 1 || ops[1].kind < 2)
+        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"bad score expression " + expression + "\" ");
+    cb.expr_lkind = ops[0].kind;
+    cb.expr_lval = ops[0].val;
+    cb.expr_rkind = ops[2].kind;
+    cb.expr_rval = ops[2].val;
+    cb.expr_op = ops[1].kind == 2 ? EX_DIV : ops[1].kind == 3 ? EX_MUL : ops[1].kind == 4 ? EX_ADD : EX_SUB;
+}
+
+struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:16-44, plan_steps.rs:137-148)
+    RequestSearchPart part;
+    std::string path;  // with ".textindex"
+    bool get_scores = false, get_ids = false, store_term_id_hits = false;
+    bool computed = false;
+    std::vector<std::pair<uint32_t, float>> hits_scores;  // (term id, term score), ascending term id
+    std::vector<uint32_t> hits_ids;                        // term ids
+};
+
+struct NodeInfo {
+    std::string label;           // request.terms[0] carried by the node's result (set_op.rs:122,215,439)
+    bool label_known = true;
+    bool len_known = false;      // result length known without executing (needed for set_op.rs:388-393)
+    uint64_t glen = 0;           // that length (unsharded)
+    std::vector<uint32_t> cover; // lists that cover the node's result docs
+    uint64_t cover_len = 0;      // shard-local entries of the cover
+    bool emitted = false;        // false: node produced no op of its own (single child / passthrough)
+};
+
+struct Compiler {
+    const Index& idx;
+    const Request& req;
+    CompiledQuery cq;
+    std::map<std::string, Leaf> cache;  // FieldRequestCache
+    std::map<std::string, std::map<std::string, std::vector<uint32_t>>> term_id_hits;  // path -> term -> term ids
+    uint32_t max_depth = 0;
+
+    Compiler(const Index& i, const Request& r) : idx(i), req(r) {}
+
+    // ------------------------------------------------------------ leaves
+    void add_to_cache(const RequestSearchPart& part, bool ids_only) {  // execution_plan.rs:108-130
+        auto it = cache.find(part.key());
+        if (it != cache.end()) {
+            it->second.get_ids |= ids_only;
+            it->second.get_scores |= !ids_only;
+            return;
+        }
+        Leaf l;
+        l.part = part;
+        l.get_scores = !ids_only;
+        l.get_ids = ids_only;
+        cache.emplace(part.key(), std::move(l));
+    }
+    void collect(const SearchRequest& r, bool ids_only) {
+        if (r.kind == SearchRequest::Search) add_to_cache(r.part, ids_only);
+        else
+            for (auto& q : r.tree.queries) collect(q, ids_only);
+    }
+    Leaf& leaf(const RequestSearchPart& part) {
+        auto it = cache.find(part.key());
+        if (it == cache.end()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"PlanCreator: Could not find request in field_search_cache\" ");
+        return it->second;
+    }
+    void flag_tree(const SearchRequest& r) {  // execution_plan.rs:401-418
+        if (r.kind == SearchRequest::Search) leaf(r.part).store_term_id_hits |= (req.why_found || req.text_locality);
+        else
+            for (auto& q : r.tree.queries) flag_tree(q);
+    }
+
+    // get_term_ids_in_field (search_field.rs:277-398) — dictionary side only
+    static void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
+        const RequestSearchPart& p = l.part;
+        if (p.is_regex) unsupported("is_regex");
+        if (p.token_value) unsupported("token_value");
+        if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
+        if (p.options && p.options->explain) unsupported("explain");
+        if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
+        l.path = p.path;
+        if (!ends_with(l.path, TEXTINDEX)) l.path += TEXTINDEX;
+        const std::string lower_term = vqtext::to_lower_utf8(p.terms[0]);
+        const auto lower_cps = vqtext::decode_utf8(lower_term);
+        uint32_t lev = 0;
+        if (p.levenshtein_distance) {  // :285-287
+            if (lower_cps.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"empty term with levenshtein_distance\" ");
+            lev = std::min<uint32_t>(*p.levenshtein_distance, uint32_t(lower_cps.size()) - 1);
+        }
+        auto dit = idx.dict.find(l.path);
+        if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "field does not exist " + l.path + " (fst not found)");
+        const Dictionary& dict = dit->second;
+        if (lev != 0 || p.starts_with) unsupported("levenshtein_distance > 0 / starts_with (dictionary scan kernel not in this build)");
+        if (p.top) unsupported("top/skip on a search part");
+
+        const bool ci = p.ignore_case.value_or(true);  // search_field.rs:88
+        const auto query_cps = vqtext::decode_utf8(p.terms[0]);
+        std::vector<uint32_t> cand;
+        if (ci) {
+            auto it = dict.lower_map.find(lower_term);
+            if (it != dict.lower_map.end()) cand = it->second;
+        } else {
+            auto it = std::lower_bound(dict.terms.begin(), dict.terms.end(), p.terms[0]);
+            if (it != dict.terms.end() && *it == p.terms[0]) cand.push_back(uint32_t(it - dict.terms.begin()));
+        }
+        for (uint32_t id : cand) {  // ascending ids == FST stream order
+            const auto cps = vqtext::decode_utf8(dict.terms[id]);
+            if (cps.size() != query_cps.size()) continue;
+            bool eq = true;
+            for (size_t i = 0; i < cps.size() && eq; ++i) eq = cp_eq(cps[i], query_cps[i], ci);
+            if (!eq) continue;
+            if (get_ids) l.hits_ids.push_back(id);
+            if (get_scores) {
+                // distance 0 under the scoring automaton (lowercased hit == lowercased term), no prefix bonus (:302,315-317)
+                const bool same_lower = vqtext::to_lower_utf8(dict.terms[id]) == lower_term;
+                float score = default_score_for_distance(same_lower ? 0 : 1, false);
+                if (p.boost) score *= *p.boost;  // :359-364
+                l.hits_scores.push_back({id, score});
+            }
+        }
+    }
+    Leaf& field_result(const RequestSearchPart& part) {
+        Leaf& l = leaf(part);
+        if (!l.computed) {
+            lookup_terms(idx, l, l.get_scores, l.get_ids);
+            if (l.store_term_id_hits && !l.hits_scores.empty()) {  // search_field.rs:379-383
+                std::vector<uint32_t> ids;
+                for (auto& h : l.hits_scores) ids.push_back(h.first);
+                term_id_hits[l.path][part.terms[0]] = ids;
+            }
+            l.computed = true;
+        }
+        return l;
+    }
+
+    // ------------------------------------------------------------ lists
+    uint32_t add_list(const HList& h) {
+        if (cq.lists.size() >= size_t(kMaxLists)) unsupported("more than " + std::to_string(kMaxLists) + " posting/id lists in one query");
+        cq.lists.push_back(h);
+        cq.total_len += h.len;
+        return uint32_t(cq.lists.size() - 1);
+    }
+    uint32_t add_inline_list(std::vector<uint32_t> docs) {  // sorted unique doc ids, restricted to the shard
+        std::vector<uint32_t> d;
+        for (uint32_t x : docs)
+            if (x >= idx.doc_lo && x < idx.doc_hi) d.push_back(x);
+        HList h;
+        h.len = uint32_t(d.size());
+        h.global_len = docs.size();
+        h.inline_idx = int(cq.inline_lists.size());
+        cq.inline_lists.push_back(std::move(d));
+        return add_list(h);
+    }
+    const PostingStore& posting_store(const std::string& textindex_path) {
+        auto it = idx.postings.find(textindex_path + TO_ANCHOR_ID_SCORE);
+        if (it == idx.postings.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + textindex_path + TO_ANCHOR_ID_SCORE);
+        return it->second;
+    }
+    const KVStore& kv_store(const std::string& path) {
+        auto it = idx.kv.find(path);
+        if (it == idx.kv.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + path);
+        return it->second;
+    }
+
+    // hits_ids of resolve_token_to_anchor (search_field.rs:468-498): text ids -> anchors, as id-only lists.
+    // Returns the list indices; `with_multiplicity` keeps duplicates as extra lists (boost_term).
+    std::vector<uint32_t> ids_to_anchor_lists(const Leaf& l, bool with_multiplicity) {
+        std::vector<uint32_t> out;
+        if (l.hits_ids.empty()) return out;
+        if (idx.is_anchor_identity(l.path)) {  // text ids ARE anchor ids
+            std::vector<uint32_t> ids = l.hits_ids;
+            std::sort(ids.begin(), ids.end());
+            if (!with_multiplicity) ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            out = layered_inline(ids);
+            return out;
+        }
+        const KVStore& t2a = kv_store(l.path + TEXT_ID_TO_ANCHOR);
+        if (!with_multiplicity || (l.hits_ids.size() == 1 && t2a.rows_sorted_unique)) {
+            for (uint32_t id : l.hits_ids) {
+                if (id < t2a.key_base || id - t2a.key_base >= t2a.num_keys) continue;
+                const uint32_t r = id - t2a.key_base;
+                if (t2a.host_off[r] == t2a.host_off[r + 1]) continue;
+                HList h;
+                h.d_docs = t2a.values.as<uint32_t>() + t2a.start[r];
+                h.len = t2a.len[r];
+                h.global_len = t2a.host_off[r + 1] - t2a.host_off[r];
+                out.push_back(add_list(h));
+            }
+            return out;
+        }
+        std::vector<uint32_t> all;
+        for (uint32_t id : l.hits_ids) {
+            const uint32_t *b, *e;
+            if (t2a.host_row(id, &b, &e)) all.insert(all.end(), b, e);
+        }
+        std::sort(all.begin(), all.end());
+        return layered_inline(all);
+    }
+    // sorted ids with duplicates -> layers of unique lists (layer j holds the ids occurring more than j times)
+    std::vector<uint32_t> layered_inline(const std::vector<uint32_t>& sorted_ids) {
+        std::vector<std::vector<uint32_t>> layers;
+        for (size_t i = 0; i < sorted_ids.size();) {
+            size_t j = i;
+            while (j < sorted_ids.size() && sorted_ids[j] == sorted_ids[i]) ++j;
+            const size_t mult = j - i;
+            if (layers.size() < mult) layers.resize(mult);
+            for (size_t m = 0; m < mult; ++m) layers[m].push_back(sorted_ids[i]);
+            i = j;
+        }
+        std::vector<uint32_t> out;
+        for (auto& l : layers) out.push_back(add_inline_list(std::move(l)));
+        return out;
+    }
+
+    // ------------------------------------------------------------ trees
+    void push_op(std::vector<DOp>& ops, const DOp& op, uint32_t& sp) {
+        if (ops.size() >= size_t(kMaxOps)) unsupported("query tree with more than " + std::to_string(kMaxOps) + " nodes");
+        ops.push_back(op);
+        if (op.kind != OP_LEAF) sp -= op.nchild;
+        ++sp;
+        max_depth = std::max(max_depth, sp);
+        if (sp > uint32_t(kStackDepth)) unsupported("query tree deeper than the evaluation stack");
+    }
+
+    NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
+        NodeInfo info;
+        if (r.kind == SearchRequest::Search) {
+            Leaf& l = field_result(r.part);
+            if (!is_filter) {  // 1:n boosts joined through a shared [] prefix (execution_plan.rs:422-509)
+                size_t pos = r.part.path.rfind("[]");
+                if (pos != std::string::npos) {
+                    std::string end_obj = r.part.path.substr(0, pos);
+                    for (auto& el : boost) {
+                        size_t p = el.path.rfind("[]");
+                        if (p != std::string::npos && el.path.substr(0, p) == end_obj) unsupported("1:n field boost (" + el.path + ")");
+                    }
+                }
+            }
+            DOp op{};
+            op.kind = OP_LEAF;
+            op.list_begin = uint16_t(cq.lists.size());
+            info.label = r.part.terms[0];
+            if (is_filter) {
+                auto lists = ids_to_anchor_lists(l, false);
+                op.list_count = uint16_t(lists.size());
+                for (uint32_t li : lists) {
+                    info.cover.push_back(li);
+                    info.cover_len += cq.lists[li].len;
+                    info.glen += cq.lists[li].global_len;
+                    cq.algorithmic_bytes += 4ull * cq.lists[li].len;
+                }
+                info.len_known = lists.size() <= 1;
+            } else {
+                const PostingStore& ps = posting_store(l.path);
+                uint32_t count = 0;
+                uint32_t with_entries = 0;
+                for (auto& [tid, score] : l.hits_scores) {
+                    if (tid >= ps.num_tokens) continue;
+                    if (ps.global_len[tid]) ++with_entries;
+                    if (ps.len[tid] == 0) continue;
+                    HList h;
+                    h.d_docs = ps.docs.as<uint32_t>() + ps.start[tid];
+                    h.d_scores = ps.scores.as<uint16_t>() + ps.start[tid];
+                    h.len = ps.len[tid];
+                    h.global_len = ps.global_len[tid];
+                    h.flags = LIST_HAS_SCORES;
+                    h.term_score = score;
+                    uint32_t li = add_list(h);
+                    info.cover.push_back(li);
+                    info.cover_len += h.len;
+                    cq.algorithmic_bytes += 6ull * h.len;
+                    ++count;
+                }
+                op.list_count = uint16_t(count);
+                // a single posting list and no Set filter in front of it: the result length is the list length
+                info.len_known = with_entries <= 1 && !req.filter;
+                info.glen = 0;
+                for (auto& [tid, score] : l.hits_scores)
+                    if (tid < ps.num_tokens) info.glen += ps.global_len[tid];
+            }
+            push_op(ops, op, sp);
+            info.emitted = true;
+            return info;
+        }
+        const auto& queries = r.tree.queries;
+        if (queries.empty()) {  // set_op.rs:90-92 / :369-371: empty result
+            DOp op{};
+            op.kind = OP_LEAF;
+            op.list_begin = uint16_t(cq.lists.size());
+            op.list_count = 0;
+            push_op(ops, op, sp);
+            info.len_known = true;
+            info.label_known = false;
+            info.emitted = true;
+            return info;
+        }
+        std::vector<NodeInfo> ch;
+        for (auto& q : queries) {
+            std::vector<RequestBoostPart> child_boost = boost;  // merge_vec execution_plan.rs:263-270
+            if (q.get_options() && q.get_options()->boost) child_boost.insert(child_boost.end(), q.get_options()->boost->begin(), q.get_options()->boost->end());
+            ch.push_back(compile_node(q, is_filter, ops, sp, child_boost));
+        }
+        if (ch.size() == 1) return ch[0];  // set_op.rs:93-96 / :372-375: the single operand is passed through
+        if (ch.size() > size_t(kMaxChildren)) unsupported("more than " + std::to_string(kMaxChildren) + " operands in one and/or");
+        DOp op{};
+        op.nchild = uint8_t(ch.size());
+        const size_t n = ch.size();
+        if (r.kind == SearchRequest::And) {
+            op.kind = OP_AND;
+            bool all_known = true;
+            for (auto& c : ch) all_known = all_known && c.len_known;
+            size_t shortest = 0;
+            if (all_known) {  // get_shortest_result set_op.rs:9-17: first minimal length
+                for (size_t i = 1; i < n; ++i)
+                    if (ch[i].glen < ch[shortest].glen) shortest = i;
+            } else if (n > 2 && !is_filter) {
+                unsupported("AND of 3+ operands whose result sizes are only known at run time (summation order, set_op.rs:388-416)");
+            }
+            // swap_remove(shortest): the last operand takes its slot; the shortest is added last (:393,:415-416)
+            std::vector<uint8_t> order;
+            for (size_t i = 0; i < n; ++i) order.push_back(uint8_t(i));
+            order[shortest] = order[n - 1];
+            order.pop_back();
+            order.push_back(uint8_t(shortest));
+            for (size_t i = 0; i < n; ++i) op.and_order[i] = order[i];
+            // result.request = and_results[0].request after the swap_remove (:439)
+            const size_t label_src = order[0];
+            info.label = ch[label_src].label;
+            info.label_known = (all_known || n == 1) && ch[label_src].label_known;
+            if (!all_known && n == 2) info.label_known = false;
+            info.len_known = false;
+            // cover: the operand with the fewest shard-local entries
+            size_t best = 0;
+            for (size_t i = 1; i < n; ++i)
+                if (ch[i].cover_len < ch[best].cover_len) best = i;
+            info.cover = ch[best].cover;
+            info.cover_len = ch[best].cover_len;
+        } else {
+            op.kind = OP_OR;
+            if (!is_filter) {
+                std::vector<std::string> terms;  // set_op.rs:122-124
+                for (auto& c : ch) {
+                    if (!c.label_known) unsupported("OR over an operand whose term label is only known at run time (set_op.rs:143,439)");
+                    terms.push_back(c.label);
+                }
+                std::sort(terms.begin(), terms.end());
+                terms.erase(std::unique(terms.begin(), terms.end()), terms.end());
+                op.nslots = uint8_t(terms.size());
+                for (size_t i = 0; i < n; ++i) op.child_slot[i] = uint8_t(std::find(terms.begin(), terms.end(), ch[i].label) - terms.begin());
+            }
+            info.label = ch[0].label;  // set_op.rs:215
+            info.label_known = ch[0].label_known;
+            info.len_known = false;
+            for (auto& c : ch) {
+                info.cover.insert(info.cover.end(), c.cover.begin(), c.cover.end());
+                info.cover_len += c.cover_len;
+            }
+        }
+        push_op(ops, op, sp);
+        info.emitted = true;
+        return info;
+    }
+
+    // ------------------------------------------------------------ the whole request (search.rs:143-228)
+    void run() {
+        if (req.has_select) unsupported("select");
+        if (req.why_found) unsupported("why_found");
+        if (req.explain) unsupported("explain");
+        if (req.has_suggest) unsupported("suggest");
+        if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
+        cq.top = uint32_t(req.top.value_or(10));  // :146
+        cq.skip = uint32_t(req.skip.value_or(0));
+        const uint64_t want = uint64_t(cq.top) + cq.skip;
+        if (want > uint64_t(kMaxTopK)) unsupported("top + skip > " + std::to_string(kMaxTopK));
+        cq.top_k = uint32_t(std::max<uint64_t>(want, 1));
+
+        // collect_all_field_request_into_cache (execution_plan.rs:91-106), then the flags set during plan creation
+        if (req.phrase_boosts)
+            for (auto& el : *req.phrase_boosts) {
+                add_to_cache(el.search1, false);
+                add_to_cache(el.search2, false);
+            }
+        collect(*req.search_req, false);
+        if (req.filter) collect(*req.filter, true);
+        if (req.filter) flag_tree(*req.filter);
+        flag_tree(*req.search_req);
+        if (req.phrase_boosts)
+            for (auto& el : *req.phrase_boosts) {
+                leaf(el.search1).get_ids = true;
+                leaf(el.search2).get_ids = true;
+            }
+
+        // filter tree (ids only), then the score tree
+        uint32_t sp = 0;
+        if (req.filter) {
+            compile_node(*req.filter, true, cq.fops, sp, {});
+            if (cq.fops.empty()) unsupported("filter that reduces to nothing");
+        }
+        sp = 0;
+        NodeInfo root = compile_node(*req.search_req, false, cq.ops, sp, req.boost.value_or(std::vector<RequestBoostPart>{}));
+        for (uint32_t li : root.cover) cq.lists[li].flags |= LIST_COVER;
+
+        // anchor-level column boosts (execution_plan.rs:175-189, boost.rs:470-504)
+        if (req.boost)
+            for (auto& b : *req.boost) {
+                if (b.path.find("[]") != std::string::npos) continue;  // only used through a matching 1:n search path
+                auto it = idx.boost.find(b.path + BOOST_VALID_TO_VALUE);
+                if (it == idx.boost.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + b.path + BOOST_VALID_TO_VALUE);
+                DColBoost cb{};
+                cb.values = it->second.values.as<float>();
+                cb.present = it->second.has_present ? it->second.present.as<uint32_t>() : nullptr;
+                cb.key_base = it->second.key_base;
+                cb.num_keys = it->second.num_keys;
+                cb.fun = b.boost_fun ? int32_t(*b.boost_fun) : BF_NONE;  // enum order matches BoostFun
+                cb.param = b.param.value_or(0.0f);
+                if (b.skip_when_score) {
+                    if (b.skip_when_score->size() > size_t(kMaxSkipWhen)) unsupported("more than 4 skip_when_score values");
+                    cb.nskip = uint32_t(b.skip_when_score->size());
+                    for (size_t i = 0; i < b.skip_when_score->size(); ++i) cb.skip[i] = (*b.skip_when_score)[i];
+                }
+                cb.expr_op = EX_NONE;
+                if (b.expression) parse_expression(*b.expression, cb);
+                cq.cols.push_back(cb);
+                cq.algorithmic_bytes += 0;  // 4 B gather per hit, unknown until run time
+            }
+
+        // phrase boosts (execution_plan.rs:202-262, plan_steps.rs:235-293, search_field.rs:247-275)
+        if (req.phrase_boosts) {
+            std::map<std::pair<std::string, std::string>, std::vector<uint32_t>> grouped;  // (term1, term2) -> lists
+            for (auto& pb : *req.phrase_boosts) {
+                Leaf& l1 = field_result(pb.search1);
+                Leaf& l2 = field_result(pb.search2);
+                if (pb.search1.path != pb.search2.path) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"phrase boost over two different paths\" ");
+                std::string path = pb.search1.path;
+                if (!ends_with(path, TEXTINDEX)) path += TEXTINDEX;
+                path += PHRASE_PAIR_TO_ANCHOR;
+                auto it = idx.phrase.find(path);
+                if (it == idx.phrase.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + path);
+                const PhraseStore& store = it->second;
+                auto& lists = grouped[{pb.search1.terms[0], pb.search2.terms[0]}];
+                for (uint32_t t1 : l1.hits_ids)
+                    for (uint32_t t2 : l2.hits_ids) {
+                        auto key = std::make_pair(t1, t2);
+                        auto kit = std::lower_bound(store.keys.begin(), store.keys.end(), key);
+                        if (kit == store.keys.end() || *kit != key) continue;
+                        const size_t k = size_t(kit - store.keys.begin());
+                        HList h;
+                        h.d_docs = store.anchors.as<uint32_t>() + store.start[k];
+                        h.len = store.len[k];
+                        h.global_len = store.len[k];
+                        lists.push_back(add_list(h));
+                        cq.algorithmic_bytes += 4ull * h.len;
+                    }
+            }
+            // lists of one group must be contiguous for DGroup: re-emit them in group order
+            for (auto& [terms, lists] : grouped) {
+                if (lists.empty()) continue;
+                bool contiguous = true;
+                for (size_t i = 1; i < lists.size(); ++i) contiguous = contiguous && lists[i] == lists[i - 1] + 1;
+                uint32_t begin = lists[0];
+                if (!contiguous) {
+                    begin = uint32_t(cq.lists.size());
+                    for (uint32_t li : lists) {
+                        HList copy = cq.lists[li];
+                        cq.total_len -= copy.len;  // counted twice otherwise
+                        add_list(copy);
+                    }
+                    for (uint32_t li : lists) cq.lists[li].len = 0, cq.lists[li].d_docs = nullptr;
+                }
+                DGroup g{};
+                g.list_begin = uint16_t(begin);
+                g.list_count = uint16_t(lists.size());
+                g.mult = 5.0f;  // plan_steps.rs:270-272
+                cq.groups.push_back(g);
+            }
+        }
+
+        // boost_term (search.rs:176-178, boost.rs:89-195, 380-402)
+        if (req.boost_term)
+            for (auto& part : *req.boost_term) {
+                Leaf l;
+                l.part = part;
+                lookup_terms(idx, l, false, true);
+                const float mult = part.boost.value_or(2.0f);  // boost.rs:393
+                for (uint32_t li : ids_to_anchor_lists(l, true)) {
+                    DTermBoost tb{};
+                    tb.list = uint16_t(li);
+                    tb.mult = mult;
+                    cq.tboosts.push_back(tb);
+                    cq.algorithmic_bytes += 4ull * cq.lists[li].len;
+                }
+            }
+
+        // text locality (search.rs:180-184, boost.rs:11-87)
+        if (req.text_locality)
+            for (auto& [path, terms] : term_id_hits) {
+                if (terms.size() <= 1) continue;  // boost.rs:36-39
+                const KVStore& t2t = kv_store(path + TOKENS_TO_TEXT_ID);
+                if (!idx.is_anchor_identity(path)) unsupported("text_locality on a field that is not an anchor identity column");
+                DLocField lf{};
+                lf.list_begin = uint16_t(cq.lists.size());
+                uint32_t count = 0;
+                for (auto& [term, ids] : terms)
+                    for (uint32_t id : ids) {
+                        if (id < t2t.key_base || id - t2t.key_base >= t2t.num_keys) continue;
+                        const uint32_t r = id - t2t.key_base;
+                        if (t2t.host_off[r] == t2t.host_off[r + 1]) continue;
+                        HList h;
+                        h.d_docs = t2t.values.as<uint32_t>() + t2t.start[r];
+                        h.len = t2t.len[r];
+                        h.global_len = t2t.host_off[r + 1] - t2t.host_off[r];
+                        add_list(h);
+                        cq.algorithmic_bytes += 4ull * h.len;
+                        ++count;
+                    }
+                lf.list_count = uint16_t(count);
+                cq.locf.push_back(lf);
+            }
+
+        // facets (search.rs:188-206, facet.rs:31-73)
+        if (req.facets)
+            for (auto& fr : *req.facets) {
+                std::vector<std::string> steps = get_steps_to_anchor(fr.field);
+                std::string store_path;
+                if (steps.size() == 1) store_path = steps.front() + PARENT_TO_VALUE_ID;
+                else if (idx.kv.count(steps.back() + ANCHOR_TO_TEXT_ID)) store_path = steps.back() + ANCHOR_TO_TEXT_ID;
+                else unsupported("facet on " + fr.field + " without an anchor_to_text_id index (n-step join)");
+                const KVStore& kv = kv_store(store_path);
+                if (!kv.facet_csr) unsupported("facet source " + store_path + " is not staged as an anchor-keyed CSR");
+                auto dit = idx.dict.find(steps.back());
+                if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "fst not found loaded in indices " + steps.back() + " ");
+                if (!fr.top) unsupported("facet with top: null (unbounded)");
+                if (*fr.top > size_t(kMaxTopK)) unsupported("facet top > " + std::to_string(kMaxTopK));
+                DFacet f{};
+                f.offsets = kv.csr_off.as<uint64_t>();
+                f.values = kv.csr_values.as<uint32_t>();
+                f.key_base = kv.csr_key_base;
+                f.num_keys = kv.csr_num_keys;
+                f.num_values = uint32_t(dit->second.terms.size());
+                f.top = uint32_t(*fr.top);
+                cq.facets.push_back(f);
+                FacetOut fo;
+                fo.field = fr.field;
+                fo.dict_path = steps.back();
+                fo.top = f.top;
+                fo.num_values = f.num_values;
+                cq.facet_out.push_back(fo);
+                cq.algorithmic_bytes += 4ull * f.num_values;
+            }
+        cq.algorithmic_bytes += 8ull * cq.top_k;
+
+        // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
+        const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);
+        const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
+        uint32_t ww = 1024;  // W = 32768 docs
+        const size_t var_budget = 40 * 1024;
+        while (ww > 32 && (size_t(ww) + size_t(L) * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
+        if ((size_t(ww) + size_t(L) * ww + size_t(L) * ww / 2) * 4 > 96 * 1024) unsupported("too many lists for the LDS tile");
+        const uint64_t cover_len = std::max<uint64_t>(root.cover_len, 1);
+        // a sparse cover visits about one tile per cover doc: shrink the tile until it holds ~1 cover entry,
+        // so that the per-tile clear / prefix work stays proportional to what is actually read
+        if (cover_len * (uint64_t(ww) << 5) / std::max<uint64_t>(range, 1) < 64) {
+            const uint64_t want = std::max<uint64_t>(range / cover_len, 1024);
+            while (ww > 32 && (uint64_t(ww) << 5) / 2 >= want) ww >>= 1;
+        }
+        cq.tile_words = ww;
+        uint64_t spans = (cq.total_len + 65535) / 65536;
+        const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
+        spans = std::min<uint64_t>(spans, tiles);
+        spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);
+        cq.n_spans = uint32_t(spans);
+    }
+};
+
+}  // namespace
+
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req) {
+    Compiler c(idx, req);
+    try {
+        c.run();
+    } catch (const VelociError& e) {
+        c.cq.status = e.code;
+        c.cq.error = e.what();
+    }
+    return std::move(c.cq);
+}
+
+}  // namespace vq

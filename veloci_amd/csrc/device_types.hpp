@@ -1,0 +1,121 @@
+// Device-visible descriptors of one compiled query ("query blob") — shared by the host compiler
+// (compile.cpp) and the kernels (kernels.hip).  All offsets are bytes from the blob start; every
+// section is 8-byte aligned.
+//
+// A query is evaluated tile by tile over the shard's doc-id space:
+//   lists   — sorted, unique doc-id lists living in HBM: posting lists (doc u32 + f16 score),
+//             id-only lists (phrase-pair anchors, text_id_to_anchor rows, tokens_to_text_id rows,
+//             small host-built lists carried inside the blob)
+//   ops     — postfix program of the score tree (reference Request.search_req)
+//   fops    — postfix program of the filter tree (presence only)
+//   groups / tboosts / cols / locf / facets — the per-hit sink stages, in the order the reference
+//             applies them (plan_creator/execution_plan.rs:163-193, search.rs:176-206)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vq {
+
+constexpr int kBlock = 256;         // threads per workgroup (4 waves of 64)
+constexpr int kCandCap = 2048;      // LDS candidate buffer (u64 keys) per workgroup
+constexpr int kMaxTopK = 1024;      // top + skip supported in-kernel
+constexpr int kStackDepth = 8;      // postfix evaluation stack
+constexpr int kMaxChildren = 8;     // children per AND/OR node
+constexpr int kMaxLists = 64;       // lists per query in one launch
+constexpr int kMaxOps = 32;
+constexpr int kMaxSkipWhen = 4;
+
+enum ListFlags : uint32_t {
+    LIST_HAS_SCORES = 1u,  // posting list: f16 anchor scores, value = term_score * (f16 / 100)
+    LIST_COVER = 2u,       // part of the cover set that decides which tiles are visited
+};
+
+struct DList {  // 32 B
+    const uint32_t* docs;    // 16-byte aligned, padded to a multiple of 4 with 0xFFFFFFFF
+    const uint16_t* scores;  // f16 bits, same indexing as docs (null for id-only lists)
+    uint32_t len;
+    uint32_t flags;
+    float term_score;        // s_t (search_field.rs:426), request.boost folded in (:359-364)
+    uint32_t pad;
+};
+
+enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2 };
+
+struct DOp {  // 24 B
+    uint8_t kind;
+    uint8_t nchild;
+    uint8_t nslots;  // OR: number of distinct term slots (set_op.rs:122-124)
+    uint8_t pad;
+    uint16_t list_begin;  // LEAF: lists [list_begin, list_begin + list_count) — union, max score (search_field.rs:453-464)
+    uint16_t list_count;
+    uint8_t child_slot[kMaxChildren];  // OR: term slot of each child, children in stack (request) order
+    uint8_t and_order[kMaxChildren];   // AND: child indices in summation order: others first, shortest last (set_op.rs:393,415-416)
+};
+
+struct DGroup {  // phrase group: present in ANY list -> multiply once (plan_steps.rs:235-277)
+    uint16_t list_begin, list_count;
+    float mult;
+};
+
+struct DTermBoost {  // one multiplication per list containing the doc (boost.rs:380-402)
+    uint16_t list;
+    uint16_t pad;
+    float mult;
+};
+
+enum BoostFun : int32_t { BF_NONE = -1, BF_LOG2 = 0, BF_LOG10 = 1, BF_MULTIPLY = 2, BF_ADD = 3, BF_REPLACE = 4 };
+enum ExprOp : int32_t { EX_NONE = -1, EX_DIV = 0, EX_MUL = 1, EX_ADD = 2, EX_SUB = 3 };
+
+struct DColBoost {  // boost.rs:283-377, 470-504
+    const float* values;      // dense column over [key_base, key_base + num_keys)
+    const uint32_t* present;  // bitmap over the same keys (null = all present)
+    uint32_t key_base, num_keys;
+    int32_t fun;
+    float param;
+    uint32_t nskip;
+    float skip[kMaxSkipWhen];
+    int32_t expr_op;      // expression "x op y" (expression.rs:26-46); operand kind 0 = $SCORE (the boost value), 1 = constant
+    int32_t expr_lkind, expr_rkind;
+    float expr_lval, expr_rval;
+    uint32_t pad;
+};
+
+struct DLocField {  // one text field with >= 2 query terms (boost.rs:34-87), identity column
+    uint16_t list_begin, list_count;
+};
+
+struct DFacet {  // facet.rs:31-73 fast path: anchor -> value ids, counted into a histogram
+    const uint64_t* offsets;  // CSR over [key_base, key_base + num_keys]
+    const uint32_t* values;
+    uint32_t key_base, num_keys;
+    uint32_t hist_off;    // u32 index into the batch's histogram area
+    uint32_t num_values;  // histogram length == dictionary size of the facet field
+    uint32_t top;         // entries to report
+    uint32_t out_off;     // index into the facet output arrays
+};
+
+struct QHeader {
+    uint32_t n_lists, n_ops, n_fops, n_groups, n_tboost, n_col, n_locf, n_facets;
+    uint32_t off_lists, off_ops, off_fops, off_groups, off_tboost, off_col, off_locf, off_facets;
+    uint32_t top_k;       // top + skip (search.rs:211)
+    uint32_t tile_words;  // W / 32, power of two
+    uint32_t n_spans;
+    uint32_t keys_base;   // span s writes its top_k keys at span_keys[keys_base + s * top_k]
+    uint32_t doc_lo, doc_hi;
+    uint32_t part_keys_off;  // u64 index of this query's top_k keys inside the partial buffer's key area
+    uint32_t blob_bytes;
+};
+
+// Layout of the packed partial buffer (one per shard and batch; identical size on every shard):
+//   [u64 num_hits[nq]] [u64 keys[total_keys]] [u32 hist[total_hist]]
+struct PartialLayout {
+    uint64_t nq, total_keys, total_hist;
+    uint64_t off_hits, off_keys, off_hist, bytes;
+};
+
+// 64-bit ranking key: (order-preserving f32 bits << 32) | doc  — larger == better under
+// (score desc, id desc) (search.rs:122-130).
+__host__ __device__ inline uint32_t order_f32(uint32_t bits) { return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u); }
+__host__ __device__ inline uint32_t unorder_f32(uint32_t o) { return (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; }
+
+}  // namespace vq

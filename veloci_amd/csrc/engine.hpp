@@ -1,0 +1,293 @@
+// Host side of the MI355X query path: staged index image, query compiler, batch executor.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "device_types.hpp"
+#include "kernels.hpp"
+#include "request.hpp"
+
+namespace vq {
+
+using vqreq::VelociError;
+
+#define VQ_HIP(expr)                                                                                                          \
+    do {                                                                                                                      \
+        hipError_t _e = (expr);                                                                                               \
+        if (_e != hipSuccess) throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); \
+    } while (0)
+
+// suffix constants, reference src/persistence.rs:23-50
+extern const char* const TOKENS_TO_TEXT_ID;
+extern const char* const TO_ANCHOR_ID_SCORE;
+extern const char* const PHRASE_PAIR_TO_ANCHOR;
+extern const char* const VALUE_ID_TO_PARENT;
+extern const char* const PARENT_TO_VALUE_ID;
+extern const char* const TEXT_ID_TO_ANCHOR;
+extern const char* const ANCHOR_TO_TEXT_ID;
+extern const char* const BOOST_VALID_TO_VALUE;
+extern const char* const VALUE_ID_TO_ANCHOR;
+extern const char* const TEXTINDEX;
+
+// ------------------------------------------------------------------ builder-side (host copies of what the caller hands over)
+struct HostFst {
+    std::vector<std::string> terms;  // bytewise sorted, ordinal == term id
+};
+struct HostPostings {
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> anchors;
+    std::vector<uint32_t> scores;
+    std::vector<uint64_t> global_lens;  // empty: lengths of the arrays handed over are the global ones
+};
+struct HostKV {
+    uint32_t key_base = 0;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> values;
+};
+struct HostPhrase {
+    std::vector<uint32_t> t1, t2;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> anchors;
+};
+struct HostBoost {
+    uint32_t key_base = 0;
+    std::vector<uint8_t> present;
+    std::vector<uint32_t> bits;
+};
+struct ColumnMeta {
+    bool is_anchor_identity_column = false;
+    bool tokenize = true;
+};
+
+struct IndexBuilder {
+    uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;
+    std::map<std::string, HostFst> fst;
+    std::map<std::string, HostPostings> postings;
+    std::map<std::string, HostKV> kv;
+    std::map<std::string, HostPhrase> phrase;
+    std::map<std::string, HostBoost> boost;
+    std::map<std::string, ColumnMeta> columns;
+};
+
+// ------------------------------------------------------------------ staged image
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n);
+    void ensure(size_t n);  // grow (never shrink); contents are not preserved
+    void release();
+    void upload(const void* src, size_t n, hipStream_t st = nullptr);
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Dictionary {  // term dictionary of one text field (host side: exact lookups; device side: fuzzy scan, later)
+    std::vector<std::string> terms;
+    std::unordered_map<std::string, std::vector<uint32_t>> lower_map;  // lowercase(term) -> ascending term ids
+};
+
+struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segmented arrays in HBM
+    uint32_t num_tokens = 0;
+    std::vector<uint64_t> start;        // start[t]: first entry of list t inside docs/scores (multiple of 4)
+    std::vector<uint32_t> len;          // entries of list t inside this shard
+    std::vector<uint64_t> global_len;   // entries of list t in the unsharded index
+    DevBuf docs;                        // u32, lists padded to a multiple of 4 with 0xFFFFFFFF
+    DevBuf scores;                      // f16 bits (u16), same indexing
+    uint64_t total_padded = 0;
+};
+
+struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device images
+    uint32_t key_base = 0, num_keys = 0;  // host addressing, as handed over
+    std::vector<uint64_t> host_off;
+    std::vector<uint32_t> host_values;
+    // list use: values are anchors -> every row is a padded, sorted, unique doc-id list in HBM
+    bool list_rows = false;
+    bool rows_sorted_unique = true;
+    std::vector<uint64_t> start;  // first entry of row r inside `values` (multiple of 4)
+    std::vector<uint32_t> len;    // entries of row r inside this shard
+    DevBuf values;
+    // facet use: keys are anchors -> CSR restricted to the shard's anchors
+    bool facet_csr = false;
+    uint32_t csr_key_base = 0, csr_num_keys = 0;
+    DevBuf csr_off;     // u64 [csr_num_keys + 1]
+    DevBuf csr_values;  // u32
+
+    bool host_row(uint64_t key, const uint32_t** b, const uint32_t** e) const {  // IndexIdToParent::get_values
+        if (key < key_base) return false;
+        uint64_t r = key - key_base;
+        if (r >= num_keys || host_off[r] == host_off[r + 1]) return false;
+        *b = host_values.data() + host_off[r];
+        *e = host_values.data() + host_off[r + 1];
+        return true;
+    }
+};
+
+struct PhraseStore {
+    std::vector<std::pair<uint32_t, uint32_t>> keys;  // sorted
+    std::vector<uint64_t> start;
+    std::vector<uint32_t> len;
+    DevBuf anchors;  // padded rows
+};
+
+struct BoostColumn {
+    uint32_t key_base = 0, num_keys = 0;
+    bool has_present = false;
+    DevBuf values;   // f32
+    DevBuf present;  // bitmap u32
+};
+
+struct PinnedBuf {  // page-locked host staging
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf();
+    void ensure(size_t n);
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Workspace {  // per-index scratch reused by every batch (guarded by Index::exec_mutex)
+    PinnedBuf h_up, h_down;
+    DevBuf d_up;        // blobs + blob_off + span_base + facet jobs
+    DevBuf d_span_keys;
+    DevBuf d_partial;
+    DevBuf d_hist_sum;
+    DevBuf d_down;      // results
+};
+
+struct Profile {
+    bool enabled = false;
+    double scan_ms = 0;
+    uint64_t scan_launches = 0;
+    uint64_t algorithmic_bytes = 0;
+};
+
+struct Index {
+    int device = 0;
+    uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;
+    std::map<std::string, Dictionary> dict;
+    std::map<std::string, PostingStore> postings;
+    std::map<std::string, KVStore> kv;
+    std::map<std::string, PhraseStore> phrase;
+    std::map<std::string, BoostColumn> boost;
+    std::map<std::string, ColumnMeta> columns;
+    uint64_t device_bytes = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    mutable std::mutex exec_mutex;  // one batch at a time per index (workspace is shared)
+    mutable Profile profile;
+    mutable Workspace ws;
+    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~Index();
+    bool is_anchor_identity(const std::string& textindex_path) const;
+};
+
+std::unique_ptr<Index> build_index(const IndexBuilder& b, int device);
+
+// ------------------------------------------------------------------ compiled query
+struct HList {
+    const uint32_t* d_docs = nullptr;
+    const uint16_t* d_scores = nullptr;
+    uint32_t len = 0;
+    uint32_t flags = 0;
+    float term_score = 0.f;
+    uint64_t global_len = 0;
+    int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
+};
+
+struct FacetOut {
+    std::string field;
+    std::string dict_path;  // fst used to turn value ids into strings
+    uint32_t top = 10;
+    uint32_t num_values = 0;
+};
+
+struct CompiledQuery {
+    int status = 0;
+    std::string error;
+    std::vector<HList> lists;
+    std::vector<std::vector<uint32_t>> inline_lists;
+    std::vector<DOp> ops, fops;
+    std::vector<DGroup> groups;
+    std::vector<DTermBoost> tboosts;
+    std::vector<DColBoost> cols;
+    std::vector<DLocField> locf;
+    std::vector<DFacet> facets;
+    std::vector<FacetOut> facet_out;
+    uint32_t top = 10, skip = 0, top_k = 10;
+    uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
+    uint64_t algorithmic_bytes = 0;
+    uint32_t tile_words = 0, n_spans = 1;
+};
+
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req);
+
+// ------------------------------------------------------------------ results
+struct ResultFacet {
+    std::string field;
+    std::vector<std::pair<std::string, uint64_t>> entries;
+};
+struct Result {
+    uint64_t num_hits = 0;
+    uint64_t execution_time_ns = 0;
+    std::vector<uint32_t> ids;
+    std::vector<float> scores;
+    std::vector<ResultFacet> facets;
+    bool has_facets = false;
+    mutable std::string json;
+};
+
+struct PartialBatch {
+    const Index* index = nullptr;
+    std::unique_lock<std::mutex> lock;    // holds the index workspace until the batch is finished
+    std::vector<CompiledQuery> queries;   // status != 0: failed at compile time
+    std::vector<uint32_t> slot;           // slot[i]: position of request i among the device queries, or UINT32_MAX
+    uint32_t nq_dev = 0;
+    PartialLayout layout{};
+    // device addresses inside the workspace
+    const uint8_t* d_blobs = nullptr;
+    const uint32_t* d_blob_off = nullptr;
+    const uint32_t* d_span_base = nullptr;
+    const FacetJob* d_facet_jobs = nullptr;
+    uint8_t* d_partial = nullptr;
+    uint32_t total_spans = 0;
+    uint32_t n_facet_jobs = 0;
+    uint32_t total_facet_out = 0;
+    bool profiled = false;
+    std::chrono::steady_clock::time_point t0;
+};
+
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n);
+void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
+                  std::vector<int>& status, std::vector<std::string>& errors);
+
+}  // namespace vq

@@ -1,0 +1,332 @@
+// Batch executor: compile n requests, pack their device programs, launch the kernels, assemble results.
+// One batch == one k_tile_scan launch over all (query, span) pairs (SURVEY.md §7 "design for batches").
+#include <algorithm>
+#include <cstring>
+
+#include "engine.hpp"
+
+namespace vq {
+
+using namespace vqreq;
+
+void DevBuf::ensure(size_t n) {
+    if (n <= bytes) return;
+    size_t want = std::max(n, bytes + bytes / 2);
+    alloc(want);
+}
+PinnedBuf::~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+}
+void PinnedBuf::ensure(size_t n) {
+    if (n <= bytes) return;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    size_t want = std::max(n, bytes + bytes / 2);
+    VQ_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    bytes = want;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// serialise one compiled query into `dst` (host), whose device address will be `dev`
+static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst, const uint8_t* dev, uint32_t keys_base, uint32_t part_keys_off,
+                        const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off) {
+    size_t off = align_up(sizeof(QHeader), 16);
+    QHeader h{};
+    auto section = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 16);
+        return o;
+    };
+    h.n_lists = uint32_t(cq.lists.size());
+    h.n_ops = uint32_t(cq.ops.size());
+    h.n_fops = uint32_t(cq.fops.size());
+    h.n_groups = uint32_t(cq.groups.size());
+    h.n_tboost = uint32_t(cq.tboosts.size());
+    h.n_col = uint32_t(cq.cols.size());
+    h.n_locf = uint32_t(cq.locf.size());
+    h.n_facets = uint32_t(cq.facets.size());
+    h.off_lists = uint32_t(section(cq.lists.size() * sizeof(DList)));
+    h.off_ops = uint32_t(section(cq.ops.size() * sizeof(DOp)));
+    h.off_fops = uint32_t(section(cq.fops.size() * sizeof(DOp)));
+    h.off_groups = uint32_t(section(cq.groups.size() * sizeof(DGroup)));
+    h.off_tboost = uint32_t(section(cq.tboosts.size() * sizeof(DTermBoost)));
+    h.off_col = uint32_t(section(cq.cols.size() * sizeof(DColBoost)));
+    h.off_locf = uint32_t(section(cq.locf.size() * sizeof(DLocField)));
+    h.off_facets = uint32_t(section(cq.facets.size() * sizeof(DFacet)));
+    std::vector<size_t> inline_off(cq.inline_lists.size());
+    for (size_t i = 0; i < cq.inline_lists.size(); ++i) inline_off[i] = section(align_up(cq.inline_lists[i].size(), 4) * 4);
+    h.top_k = cq.top_k;
+    h.tile_words = cq.tile_words;
+    h.n_spans = cq.n_spans;
+    h.keys_base = keys_base;
+    h.doc_lo = idx.doc_lo;
+    h.doc_hi = idx.doc_hi;
+    h.part_keys_off = part_keys_off;
+    h.blob_bytes = uint32_t(off);
+    if (!dst) return off;
+
+    std::memcpy(dst, &h, sizeof h);
+    DList* dl = reinterpret_cast<DList*>(dst + h.off_lists);
+    for (size_t i = 0; i < cq.lists.size(); ++i) {
+        const HList& l = cq.lists[i];
+        DList d{};
+        d.docs = l.inline_idx >= 0 ? reinterpret_cast<const uint32_t*>(dev + inline_off[l.inline_idx]) : l.d_docs;
+        d.scores = l.d_scores;
+        d.len = l.len;
+        d.flags = l.flags;
+        d.term_score = l.term_score;
+        dl[i] = d;
+    }
+    if (!cq.ops.empty()) std::memcpy(dst + h.off_ops, cq.ops.data(), cq.ops.size() * sizeof(DOp));
+    if (!cq.fops.empty()) std::memcpy(dst + h.off_fops, cq.fops.data(), cq.fops.size() * sizeof(DOp));
+    if (!cq.groups.empty()) std::memcpy(dst + h.off_groups, cq.groups.data(), cq.groups.size() * sizeof(DGroup));
+    if (!cq.tboosts.empty()) std::memcpy(dst + h.off_tboost, cq.tboosts.data(), cq.tboosts.size() * sizeof(DTermBoost));
+    if (!cq.cols.empty()) std::memcpy(dst + h.off_col, cq.cols.data(), cq.cols.size() * sizeof(DColBoost));
+    if (!cq.locf.empty()) std::memcpy(dst + h.off_locf, cq.locf.data(), cq.locf.size() * sizeof(DLocField));
+    DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);
+    for (size_t i = 0; i < cq.facets.size(); ++i) {
+        DFacet f = cq.facets[i];
+        f.hist_off = hist_off[i];
+        f.out_off = fac_out_off[i];
+        df[i] = f;
+    }
+    for (size_t i = 0; i < cq.inline_lists.size(); ++i) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(dst + inline_off[i]);
+        const auto& v = cq.inline_lists[i];
+        std::memcpy(p, v.data(), v.size() * 4);
+        for (size_t k = v.size(); k < align_up(v.size(), 4); ++k) p[k] = 0xFFFFFFFFu;
+    }
+    return off;
+}
+
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n) {
+    auto pb = std::make_unique<PartialBatch>();
+    pb->index = &idx;
+    pb->t0 = std::chrono::steady_clock::now();
+    pb->lock = std::unique_lock<std::mutex>(idx.exec_mutex);
+    VQ_HIP(hipSetDevice(idx.device));
+    Workspace& ws = idx.ws;
+    hipStream_t st = idx.stream;
+
+    // ---- compile
+    pb->queries.reserve(n);
+    pb->slot.assign(n, UINT32_MAX);
+    for (size_t i = 0; i < n; ++i) {
+        if (!reqs[i]) {
+            CompiledQuery cq;
+            cq.status = ERR_INVALID_ARGUMENT;
+            cq.error = "null request";
+            pb->queries.push_back(std::move(cq));
+            continue;
+        }
+        pb->queries.push_back(compile_query(idx, *reqs[i]));
+    }
+    // ---- layout
+    uint32_t nq = 0;
+    uint64_t total_keys = 0, total_hist = 0, total_span_keys = 0, total_spans = 0, blob_bytes = 0;
+    uint32_t max_lists = 1, max_ww = 32;
+    size_t lds_bytes = 0;
+    std::vector<uint32_t> keys_base, part_keys_off, span_base;
+    std::vector<std::vector<uint32_t>> hist_offs, fac_out_offs;
+    std::vector<FacetJob> jobs;
+    uint32_t fac_out_total = 0;
+    uint64_t algo_bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        CompiledQuery& cq = pb->queries[i];
+        if (cq.status != 0) continue;
+        pb->slot[i] = nq++;
+        keys_base.push_back(uint32_t(total_span_keys));
+        part_keys_off.push_back(uint32_t(total_keys));
+        span_base.push_back(uint32_t(total_spans));
+        total_span_keys += uint64_t(cq.n_spans) * cq.top_k;
+        total_keys += cq.top_k;
+        total_spans += cq.n_spans;
+        std::vector<uint32_t> ho, fo;
+        for (auto& f : cq.facets) {
+            ho.push_back(uint32_t(total_hist));
+            fo.push_back(fac_out_total);
+            jobs.push_back(FacetJob{uint32_t(total_hist), f.num_values, f.top, fac_out_total});
+            total_hist += f.num_values;
+            fac_out_total += f.top;
+        }
+        hist_offs.push_back(std::move(ho));
+        fac_out_offs.push_back(std::move(fo));
+        blob_bytes += pack_blob(cq, idx, nullptr, nullptr, 0, 0, {}, {});
+        max_lists = std::max<uint32_t>(max_lists, uint32_t(cq.lists.size()));
+        max_ww = std::max(max_ww, cq.tile_words);
+        lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(cq.lists.size()), cq.tile_words));
+        algo_bytes += cq.algorithmic_bytes;
+    }
+    if (total_span_keys > 0xFFFFFFFFull || total_hist > 0xFFFFFFFFull || total_spans > 0x7FFFFFFFull)
+        throw VelociError(ERR_UNSUPPORTED, "batch too large for 32-bit workspace offsets: split the batch");
+    span_base.push_back(uint32_t(total_spans));
+    pb->nq_dev = nq;
+    pb->total_spans = uint32_t(total_spans);
+    pb->n_facet_jobs = uint32_t(jobs.size());
+    pb->total_facet_out = fac_out_total;
+
+    PartialLayout& lay = pb->layout;
+    lay.nq = nq;
+    lay.total_keys = total_keys;
+    lay.total_hist = total_hist;
+    lay.off_hits = 0;
+    lay.off_keys = align_up(size_t(nq) * 8, 16);
+    lay.off_hist = lay.off_keys + align_up(size_t(total_keys) * 8, 16);
+    lay.bytes = align_up(lay.off_hist + size_t(total_hist) * 4, 256);
+
+    // ---- upload area: [blobs][blob_off][span_base][facet jobs]
+    const size_t up_blob_off = align_up(blob_bytes, 256);
+    const size_t up_span_base = up_blob_off + align_up(size_t(nq + 1) * 4, 256);
+    const size_t up_jobs = up_span_base + align_up(size_t(nq + 1) * 4, 256);
+    const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
+    ws.h_up.ensure(up_bytes);
+    ws.d_up.ensure(up_bytes);
+    uint8_t* hup = ws.h_up.as<uint8_t>();
+    uint8_t* dup = ws.d_up.as<uint8_t>();
+    {
+        size_t off = 0;
+        uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
+        uint32_t qi = 0;
+        for (size_t i = 0; i < n; ++i) {
+            CompiledQuery& cq = pb->queries[i];
+            if (cq.status != 0) continue;
+            hbo[qi] = uint32_t(off);
+            off += pack_blob(cq, idx, hup + off, dup + off, keys_base[qi], part_keys_off[qi], hist_offs[qi], fac_out_offs[qi]);
+            ++qi;
+        }
+        hbo[nq] = uint32_t(off);
+        std::memcpy(hup + up_span_base, span_base.data(), span_base.size() * 4);
+        if (!jobs.empty()) std::memcpy(hup + up_jobs, jobs.data(), jobs.size() * sizeof(FacetJob));
+    }
+    pb->d_blobs = dup;
+    pb->d_blob_off = reinterpret_cast<const uint32_t*>(dup + up_blob_off);
+    pb->d_span_base = reinterpret_cast<const uint32_t*>(dup + up_span_base);
+    pb->d_facet_jobs = reinterpret_cast<const FacetJob*>(dup + up_jobs);
+    if (nq == 0) return pb;
+
+    VQ_HIP(hipMemcpyAsync(dup, hup, up_bytes, hipMemcpyHostToDevice, st));
+    ws.d_span_keys.ensure(size_t(total_span_keys) * 8 + 16);
+    ws.d_partial.ensure(lay.bytes);
+    pb->d_partial = ws.d_partial.as<uint8_t>();
+    VQ_HIP(hipMemsetAsync(pb->d_partial, 0, lay.bytes, st));
+
+    // ---- the scan
+    if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
+    pb->profiled = idx.profile.enabled;
+    if (pb->profiled) VQ_HIP(hipEventRecord(idx.ev0, st));
+    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, ws.d_span_keys.as<unsigned long long>(),
+                     reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
+    if (pb->profiled) {
+        VQ_HIP(hipEventRecord(idx.ev1, st));
+        idx.profile.scan_launches += 1;
+        idx.profile.algorithmic_bytes += algo_bytes;
+    }
+    VQ_HIP(hipGetLastError());
+    launch_merge_spans(st, nq, pb->d_blobs, pb->d_blob_off, ws.d_span_keys.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_keys));
+    VQ_HIP(hipGetLastError());
+    return pb;
+}
+
+void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
+                  std::vector<int>& status, std::vector<std::string>& errors) {
+    const size_t n = pb.queries.size();
+    out.clear();
+    out.resize(n);
+    status.assign(n, 0);
+    errors.assign(n, std::string());
+    Workspace& ws = idx.ws;
+    hipStream_t st = idx.stream;
+    const PartialLayout& lay = pb.layout;
+    const uint32_t nq = pb.nq_dev;
+    VQ_HIP(hipSetDevice(idx.device));
+
+    // download area: [hits u64 nq][n u32 nq][ids u32 K][scores f32 K][facet_n u32 J][facet_vals u32 F][facet_counts u32 F]
+    const size_t K = size_t(lay.total_keys), J = pb.n_facet_jobs, F = pb.total_facet_out;
+    const size_t o_hits = 0;
+    const size_t o_n = align_up(o_hits + size_t(nq) * 8, 16);
+    const size_t o_ids = align_up(o_n + size_t(nq) * 4, 16);
+    const size_t o_scores = align_up(o_ids + K * 4, 16);
+    const size_t o_fn = align_up(o_scores + K * 4, 16);
+    const size_t o_fv = align_up(o_fn + J * 4, 16);
+    const size_t o_fc = align_up(o_fv + F * 4, 16);
+    const size_t down_bytes = align_up(o_fc + F * 4, 256);
+
+    if (nq) {
+        const uint8_t* gathered = gathered_device ? static_cast<const uint8_t*>(gathered_device) : pb.d_partial;
+        if (!gathered_device) num_shards = 1;
+        ws.d_down.ensure(down_bytes);
+        ws.h_down.ensure(down_bytes);
+        uint8_t* dd = ws.d_down.as<uint8_t>();
+        launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, lay, reinterpret_cast<uint32_t*>(dd + o_ids),
+                        reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
+        VQ_HIP(hipGetLastError());
+        if (J) {
+            const uint32_t* hist;
+            if (num_shards > 1) {
+                ws.d_hist_sum.ensure(size_t(lay.total_hist) * 4 + 16);
+                launch_hist_reduce(st, gathered, num_shards, lay, ws.d_hist_sum.as<uint32_t>());
+                hist = ws.d_hist_sum.as<uint32_t>();
+            } else hist = reinterpret_cast<const uint32_t*>(gathered + lay.off_hist);
+            launch_facet_select(st, uint32_t(J), pb.d_facet_jobs, hist, reinterpret_cast<uint32_t*>(dd + o_fv), reinterpret_cast<uint32_t*>(dd + o_fc),
+                                reinterpret_cast<uint32_t*>(dd + o_fn));
+            VQ_HIP(hipGetLastError());
+        }
+        VQ_HIP(hipMemcpyAsync(ws.h_down.p, dd, down_bytes, hipMemcpyDeviceToHost, st));
+        VQ_HIP(hipStreamSynchronize(st));
+        if (pb.profiled) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, idx.ev0, idx.ev1) == hipSuccess) idx.profile.scan_ms += ms;
+        }
+    }
+    const uint64_t ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pb.t0).count());
+
+    const uint8_t* hd = ws.h_down.as<uint8_t>();
+    size_t key_off = 0, job = 0, fac_off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const CompiledQuery& cq = pb.queries[i];
+        if (cq.status != 0) {
+            status[i] = cq.status;
+            errors[i] = cq.error;
+            continue;
+        }
+        const uint32_t q = pb.slot[i];
+        auto r = std::make_unique<Result>();
+        r->num_hits = reinterpret_cast<const uint64_t*>(hd + o_hits)[q];
+        r->execution_time_ns = ns;
+        const uint32_t have = reinterpret_cast<const uint32_t*>(hd + o_n)[q];
+        const uint32_t* ids = reinterpret_cast<const uint32_t*>(hd + o_ids) + key_off;
+        const float* scores = reinterpret_cast<const float*>(hd + o_scores) + key_off;
+        // apply_top_skip (search.rs:230-239) on the top+skip window
+        const uint32_t want = cq.top + cq.skip;
+        const uint32_t avail = std::min(have, want);
+        const uint32_t from = std::min(cq.skip, avail);
+        const uint32_t to = std::min(avail, from + cq.top);
+        r->ids.assign(ids + from, ids + to);
+        r->scores.assign(scores + from, scores + to);
+        key_off += cq.top_k;
+        if (!cq.facet_out.empty()) r->has_facets = true;
+        for (size_t f = 0; f < cq.facet_out.size(); ++f, ++job) {
+            const FacetOut& fo = cq.facet_out[f];
+            ResultFacet rf;
+            rf.field = fo.field;
+            const uint32_t fn = reinterpret_cast<const uint32_t*>(hd + o_fn)[job];
+            // jobs were appended in query order: this job's output offset is the running sum of the tops
+            const auto dit = idx.dict.find(fo.dict_path);
+            const size_t out_off = fac_off;
+            fac_off += fo.top;
+            const uint32_t* fv = reinterpret_cast<const uint32_t*>(hd + o_fv) + out_off;
+            const uint32_t* fc = reinterpret_cast<const uint32_t*>(hd + o_fc) + out_off;
+            for (uint32_t k = 0; k < fn && k < fo.top; ++k) {
+                std::string text = (dit != idx.dict.end() && fv[k] < dit->second.terms.size()) ? dit->second.terms[fv[k]] : std::string();
+                rf.entries.push_back({std::move(text), uint64_t(fc[k])});
+            }
+            r->facets.push_back(std::move(rf));
+        }
+        out[i] = std::move(r);
+    }
+    pb.lock.unlock();
+}
+
+}  // namespace vq

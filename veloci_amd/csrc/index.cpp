@@ -1,0 +1,262 @@
+// Index staging: decoded arrays handed over through the C ABI -> padded segmented arrays in HBM.
+// Replaces Persistence::load / load_indices (reference src/persistence.rs:206-291, 393-410) at the
+// decoded-array level; the on-disk formats are not read here.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "engine.hpp"
+#include "text.hpp"
+
+namespace vq {
+
+const char* const TOKENS_TO_TEXT_ID = ".tokens_to_text_id";
+const char* const TO_ANCHOR_ID_SCORE = ".to_anchor_id_score";
+const char* const PHRASE_PAIR_TO_ANCHOR = ".phrase_pair_to_anchor";
+const char* const VALUE_ID_TO_PARENT = ".value_id_to_parent";
+const char* const PARENT_TO_VALUE_ID = ".parent_to_value_id";
+const char* const TEXT_ID_TO_ANCHOR = ".text_id_to_anchor";
+const char* const ANCHOR_TO_TEXT_ID = ".anchor_to_text_id";
+const char* const BOOST_VALID_TO_VALUE = ".boost_valid_to_value";
+const char* const VALUE_ID_TO_ANCHOR = ".value_id_to_anchor";
+const char* const TEXTINDEX = ".textindex";
+
+static bool ends_with(const std::string& s, const char* suf) {
+    size_t n = std::strlen(suf);
+    return s.size() >= n && std::memcmp(s.data() + s.size() - n, suf, n) == 0;
+}
+
+void DevBuf::alloc(size_t n) {
+    release();
+    bytes = n;
+    if (n == 0) return;
+    VQ_HIP(hipMalloc(&p, n));
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+void DevBuf::upload(const void* src, size_t n, hipStream_t st) {
+    if (n == 0) return;
+    if (st) VQ_HIP(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, st));
+    else VQ_HIP(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+}
+
+Index::~Index() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+bool Index::is_anchor_identity(const std::string& textindex_path) const {
+    // reference util.rs:131-137 extract_field_name: drop the trailing ".textindex"
+    std::string field = textindex_path;
+    if (ends_with(field, TEXTINDEX)) field.resize(field.size() - std::strlen(TEXTINDEX));
+    auto it = columns.find(field);
+    return it != columns.end() && it->second.is_anchor_identity_column;
+}
+
+// IEEE binary16 round-to-nearest-even of an f32 (== half::f16::from_f32, reference
+// src/indices/persistence_score/token_to_anchor_score_vint.rs:155)
+static uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t exp = (x >> 23) & 0xFFu;
+    uint32_t man = x & 0x7FFFFFu;
+    if (exp == 0xFF) return uint16_t(sign | 0x7C00u | (man ? (0x200u | (man >> 13)) : 0));
+    const int32_t e = int32_t(exp) - 112;
+    if (e >= 0x1F) return uint16_t(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return uint16_t(sign);
+        man |= 0x800000u;
+        const uint32_t shift = uint32_t(14 - e);
+        uint32_t hm = man >> shift;
+        const uint32_t rb = 1u << (shift - 1);
+        if ((man & rb) && ((man & (rb - 1)) || (hm & 1))) hm++;
+        return uint16_t(sign | hm);
+    }
+    uint32_t h = sign | (uint32_t(e) << 10) | (man >> 13);
+    if ((man & 0x1000u) && ((man & 0xFFFu) || (h & 1))) h++;
+    return uint16_t(h);
+}
+
+// pad a row to a multiple of 4 entries with the 0xFFFFFFFF sentinel
+static void append_padded(std::vector<uint32_t>& dst, const uint32_t* b, const uint32_t* e) {
+    dst.insert(dst.end(), b, e);
+    while (dst.size() & 3u) dst.push_back(0xFFFFFFFFu);
+}
+
+static void shard_subrange(const uint32_t* b, const uint32_t* e, uint32_t lo, uint32_t hi, const uint32_t** ob, const uint32_t** oe) {
+    *ob = std::lower_bound(b, e, lo);
+    *oe = std::lower_bound(*ob, e, hi);
+}
+
+std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw VelociError(vqreq::ERR_DEVICE, "no HIP device available: the veloci_amd query path needs an MI355X (no CPU fallback)");
+    if (device < 0 || device >= ndev) throw VelociError(vqreq::ERR_INVALID_ARGUMENT, "device index out of range");
+    VQ_HIP(hipSetDevice(device));
+
+    auto idx = std::make_unique<Index>();
+    idx->device = device;
+    idx->num_anchors = b.num_anchors;
+    idx->doc_lo = b.doc_lo;
+    idx->doc_hi = b.doc_hi;
+    idx->columns = b.columns;
+    VQ_HIP(hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking));
+    idx->stream = idx->own_stream;
+    VQ_HIP(hipEventCreate(&idx->ev0));
+    VQ_HIP(hipEventCreate(&idx->ev1));
+    const uint32_t lo = b.doc_lo, hi = b.doc_hi;
+
+    for (auto& [path, f] : b.fst) {
+        Dictionary d;
+        d.terms = f.terms;
+        d.lower_map.reserve(d.terms.size());
+        for (uint32_t i = 0; i < d.terms.size(); ++i) d.lower_map[vqtext::to_lower_utf8(d.terms[i])].push_back(i);
+        idx->dict.emplace(path, std::move(d));
+    }
+
+    for (auto& [path, p] : b.postings) {
+        PostingStore ps;
+        ps.num_tokens = uint32_t(p.offsets.size() - 1);
+        ps.start.resize(ps.num_tokens);
+        ps.len.resize(ps.num_tokens);
+        ps.global_len.resize(ps.num_tokens);
+        std::vector<uint32_t> docs;
+        std::vector<uint16_t> scores;
+        docs.reserve(p.anchors.size() + 4 * size_t(std::min<uint32_t>(ps.num_tokens, 1u << 20)));
+        for (uint32_t t = 0; t < ps.num_tokens; ++t) {
+            const uint32_t* rb = p.anchors.data() + p.offsets[t];
+            const uint32_t* re = p.anchors.data() + p.offsets[t + 1];
+            const uint32_t *sb, *se;
+            shard_subrange(rb, re, lo, hi, &sb, &se);
+            ps.start[t] = docs.size();
+            ps.len[t] = uint32_t(se - sb);
+            ps.global_len[t] = p.global_lens.empty() ? uint64_t(re - rb) : p.global_lens[t];
+            append_padded(docs, sb, se);
+            const uint32_t* sc = p.scores.data() + (sb - p.anchors.data());
+            for (uint32_t i = 0; i < ps.len[t]; ++i) scores.push_back(f32_to_f16_rne(float(sc[i])));
+            while (scores.size() < docs.size()) scores.push_back(0);
+        }
+        ps.total_padded = docs.size();
+        ps.docs.alloc(docs.size() * 4 + 16);
+        ps.docs.upload(docs.data(), docs.size() * 4);
+        ps.scores.alloc(scores.size() * 2 + 16);
+        ps.scores.upload(scores.data(), scores.size() * 2);
+        idx->device_bytes += ps.docs.bytes + ps.scores.bytes;
+        idx->postings.emplace(path, std::move(ps));
+    }
+
+    for (auto& [path, k] : b.kv) {
+        KVStore s;
+        s.key_base = k.key_base;
+        s.num_keys = uint32_t(k.offsets.size() - 1);
+        s.host_off = k.offsets;
+        s.host_values = k.values;
+        // which stores hold anchors as VALUES (rows usable as doc-id lists on the device)?
+        bool identity_t2t = false;
+        if (ends_with(path, TOKENS_TO_TEXT_ID)) {
+            std::string ti = path.substr(0, path.size() - std::strlen(TOKENS_TO_TEXT_ID));
+            identity_t2t = idx->is_anchor_identity(ti);
+        }
+        s.list_rows = ends_with(path, TEXT_ID_TO_ANCHOR) || identity_t2t;
+        if (s.list_rows) {
+            s.start.resize(s.num_keys);
+            s.len.resize(s.num_keys);
+            std::vector<uint32_t> vals;
+            vals.reserve(k.values.size() + 4);
+            std::vector<uint32_t> tmp;
+            for (uint32_t r = 0; r < s.num_keys; ++r) {
+                const uint32_t* rb = k.values.data() + k.offsets[r];
+                const uint32_t* re = k.values.data() + k.offsets[r + 1];
+                if (!std::is_sorted(rb, re) || std::adjacent_find(rb, re) != re) {
+                    // the device row is a sorted set; multiplicities, where they matter, come from the host copy
+                    tmp.assign(rb, re);
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    rb = tmp.data();
+                    re = tmp.data() + tmp.size();
+                    s.rows_sorted_unique = false;
+                }
+                const uint32_t *sb, *se;
+                shard_subrange(rb, re, lo, hi, &sb, &se);
+                s.start[r] = vals.size();
+                s.len[r] = uint32_t(se - sb);
+                append_padded(vals, sb, se);
+            }
+            s.values.alloc(vals.size() * 4 + 16);
+            s.values.upload(vals.data(), vals.size() * 4);
+            idx->device_bytes += s.values.bytes;
+        }
+        // facet sources: anchor-keyed value lists (facet.rs:38-44)
+        s.facet_csr = ends_with(path, ANCHOR_TO_TEXT_ID) || (ends_with(path, PARENT_TO_VALUE_ID) && path.find("[]") == std::string::npos);
+        if (s.facet_csr) {
+            const uint64_t kb = k.key_base, ke = uint64_t(k.key_base) + s.num_keys;
+            const uint64_t nb = std::min<uint64_t>(std::max<uint64_t>(kb, lo), ke);
+            const uint64_t ne = std::max<uint64_t>(nb, std::min<uint64_t>(ke, hi));
+            std::vector<uint64_t> off(ne - nb + 1);
+            const uint64_t first = k.offsets[nb - kb];
+            for (uint64_t r = nb; r <= ne; ++r) off[r - nb] = k.offsets[r - kb] - first;
+            s.csr_off.alloc(off.size() * 8);
+            s.csr_off.upload(off.data(), off.size() * 8);
+            const uint64_t nvals = k.offsets[ne - kb] - first;
+            s.csr_values.alloc(nvals * 4 + 16);
+            s.csr_values.upload(k.values.data() + first, nvals * 4);
+            idx->device_bytes += s.csr_off.bytes + s.csr_values.bytes;
+            s.csr_key_base = uint32_t(nb);
+            s.csr_num_keys = uint32_t(ne - nb);
+        }
+        idx->kv.emplace(path, std::move(s));
+    }
+
+    for (auto& [path, p] : b.phrase) {
+        PhraseStore s;
+        const size_t n = p.t1.size();
+        s.keys.reserve(n);
+        s.start.resize(n);
+        s.len.resize(n);
+        std::vector<uint32_t> vals;
+        for (size_t i = 0; i < n; ++i) {
+            s.keys.push_back({p.t1[i], p.t2[i]});
+            const uint32_t* rb = p.anchors.data() + p.offsets[i];
+            const uint32_t* re = p.anchors.data() + p.offsets[i + 1];
+            const uint32_t *sb, *se;
+            shard_subrange(rb, re, lo, hi, &sb, &se);
+            s.start[i] = vals.size();
+            s.len[i] = uint32_t(se - sb);
+            append_padded(vals, sb, se);
+        }
+        if (!std::is_sorted(s.keys.begin(), s.keys.end())) throw VelociError(vqreq::ERR_INVALID_ARGUMENT, "phrase pair keys must be sorted by (t1, t2): " + path);
+        s.anchors.alloc(vals.size() * 4 + 16);
+        s.anchors.upload(vals.data(), vals.size() * 4);
+        idx->device_bytes += s.anchors.bytes;
+        idx->phrase.emplace(path, std::move(s));
+    }
+
+    for (auto& [path, bc] : b.boost) {
+        BoostColumn c;
+        c.key_base = bc.key_base;
+        c.num_keys = uint32_t(bc.bits.size());
+        c.values.alloc(bc.bits.size() * 4 + 16);
+        c.values.upload(bc.bits.data(), bc.bits.size() * 4);
+        idx->device_bytes += c.values.bytes;
+        if (!bc.present.empty()) {
+            c.has_present = true;
+            std::vector<uint32_t> bits((bc.bits.size() + 31) / 32, 0u);
+            for (size_t i = 0; i < bc.present.size(); ++i)
+                if (bc.present[i]) bits[i >> 5] |= 1u << (i & 31);
+            c.present.alloc(bits.size() * 4 + 16);
+            c.present.upload(bits.data(), bits.size() * 4);
+            idx->device_bytes += c.present.bytes;
+        }
+        idx->boost.emplace(path, std::move(c));
+    }
+    VQ_HIP(hipDeviceSynchronize());
+    return idx;
+}
+
+}  // namespace vq

@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's search surface (src/search.rs:143, src/search/request/mod.rs,
+src/search/result/search_result.rs) over the C ABI: `search(request, index) -> SearchResult`."""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib
+from ._lib import VelociError  # noqa: F401  (re-exported)
+
+
+class Hit:
+    """search::Hit (src/search.rs:53-57)."""
+    __slots__ = ("id", "score")
+
+    def __init__(self, id, score):
+        self.id = int(id)
+        self.score = float(score)
+
+    def __repr__(self):
+        return f"Hit(id={self.id}, score={self.score!r})"
+
+    def __eq__(self, o):
+        return isinstance(o, Hit) and self.id == o.id and self.score == o.score
+
+
+class SearchResult:
+    """search::SearchResult (src/search/result/search_result.rs:9-26)."""
+
+    def __init__(self, num_hits, ids, scores, facets, execution_time_ns):
+        self.num_hits = int(num_hits)
+        self.ids = ids              # np.uint32
+        self.scores = scores        # np.float32
+        self.facets = facets        # None or {field: [(value, count)]}
+        self.execution_time_ns = int(execution_time_ns)
+
+    @property
+    def data(self):
+        return [Hit(i, s) for i, s in zip(self.ids.tolist(), self.scores.tolist())]
+
+    def __repr__(self):
+        return f"SearchResult(num_hits={self.num_hits}, data={self.data[:3]}..., facets={self.facets})"
+
+
+class Request:
+    """A parsed search::Request (`vq_request`).  Accepts the reference's JSON (str/bytes) or a dict."""
+
+    def __init__(self, request):
+        if isinstance(request, dict):
+            request = json.dumps(request)
+        if isinstance(request, str):
+            request = request.encode()
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self.L.vq_request_parse(request, len(request), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.vq_request_free(self.h)
+            self.h = None
+
+
+def _take_result(L, h):
+    try:
+        n = L.vq_result_len(h)
+        ids = np.ctypeslib.as_array(L.vq_result_ids(h), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        scores = np.ctypeslib.as_array(L.vq_result_scores(h), shape=(n,)).copy() if n else np.zeros(0, np.float32)
+        nf = L.vq_result_num_facets(h)
+        facets = None
+        if nf:
+            facets = {}
+            for f in range(nf):
+                fl = L.vq_result_facet_len(h, f)
+                facets[L.vq_result_facet_field(h, f).decode()] = [(L.vq_result_facet_value(h, f, i).decode(), int(L.vq_result_facet_count(h, f, i)))
+                                                                   for i in range(fl)]
+        return SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
+    finally:
+        L.vq_result_free(h)
+
+
+def _as_request(r):
+    return r if isinstance(r, Request) else Request(r)
+
+
+def search(request, index):
+    """== veloci::search::search(request, &persistence) (src/search.rs:143-228)."""
+    L = _lib.lib()
+    req = _as_request(request)
+    out = C.c_void_p()
+    _lib.check(L.vq_search(index.h, req.h, C.byref(out)))
+    return _take_result(L, out)
+
+
+def search_batch(requests, index, raise_on_error=True):
+    """n independent searches executed as one device batch (`vq_search_batch`)."""
+    L = _lib.lib()
+    reqs = [_as_request(r) for r in requests]
+    n = len(reqs)
+    arr = (C.c_void_p * n)(*[r.h for r in reqs])
+    outs = (C.c_void_p * n)()
+    status = (C.c_int * n)()
+    _lib.check(L.vq_search_batch(index.h, arr, n, outs, status))
+    results = []
+    for i in range(n):
+        if status[i] != 0:
+            if raise_on_error:
+                for j in range(i + 1, n):
+                    if outs[j]:
+                        L.vq_result_free(C.c_void_p(outs[j]))
+                raise VelociError(status[i], L.vq_last_error().decode("utf-8", "replace"))
+            results.append(VelociError(status[i], _lib.ERR_NAMES.get(status[i], "error")))
+        else:
+            results.append(_take_result(L, C.c_void_p(outs[i])))
+    return results
+
+
+class PartialBatch:
+    """Shard-local partial results of a batch, resident in HBM (`vq_partial_batch`)."""
+
+    def __init__(self, index, requests):
+        self.L = _lib.lib()
+        self.index = index
+        self.reqs = [_as_request(r) for r in requests]
+        n = len(self.reqs)
+        arr = (C.c_void_p * n)(*[r.h for r in self.reqs])
+        h = C.c_void_p()
+        _lib.check(self.L.vq_search_batch_partial(index.h, arr, n, C.byref(h)))
+        self.h = h
+        self.n = n
+
+    @property
+    def nbytes(self):
+        return int(self.L.vq_partial_bytes(self.h))
+
+    @property
+    def device_ptr(self):
+        return int(self.L.vq_partial_device_ptr(self.h) or 0)
+
+    def merge(self, gathered_device_ptr=None, num_shards=1, raise_on_error=True):
+        outs = (C.c_void_p * self.n)()
+        status = (C.c_int * self.n)()
+        _lib.check(self.L.vq_merge_partials(self.index.h, self.h, C.c_void_p(gathered_device_ptr) if gathered_device_ptr else None, num_shards, outs, status))
+        results = []
+        for i in range(self.n):
+            if status[i] != 0:
+                if raise_on_error:
+                    raise VelociError(status[i], self.L.vq_last_error().decode("utf-8", "replace"))
+                results.append(VelociError(status[i], _lib.ERR_NAMES.get(status[i], "error")))
+            else:
+                results.append(_take_result(self.L, C.c_void_p(outs[i])))
+        return results
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vq_partial_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
