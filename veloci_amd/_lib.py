@@ -42,6 +42,14 @@ def lib():
     if not os.path.exists(_SO):
         raise ImportError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  veloci_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (SONAME libamdhip64.so.7, same as
+    # /opt/rocm's).  Importing torch first makes the loader resolve this library's NEEDED entry to that copy,
+    # so torch.distributed (RCCL) and these kernels share devices, streams and memory.  Loading this library
+    # first and torch later would put two runtimes in the process and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     vp, cp, u32, u64, sz, i = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int
     sig = {

@@ -379,8 +379,32 @@ struct Compiler {
             std::vector<RequestBoostPart> child_boost = boost;  // merge_vec execution_plan.rs:263-270
             if (q.get_options() && q.get_options()->boost) child_boost.insert(child_boost.end(), q.get_options()->boost->begin(), q.get_options()->boost->end());
             ch.push_back(compile_node(q, is_filter, ops, sp, child_boost));
+            if (is_filter && ch.size() >= 2) {
+                // presence only: AND/OR are associative, fold pairwise so the stack stays shallow
+                DOp op{};
+                op.kind = r.kind == SearchRequest::And ? OP_AND : OP_OR;
+                op.nchild = 2;
+                push_op(ops, op, sp);
+            }
         }
         if (ch.size() == 1) return ch[0];  // set_op.rs:93-96 / :372-375: the single operand is passed through
+        if (is_filter) {
+            info.label_known = false;
+            info.emitted = true;
+            if (r.kind == SearchRequest::And) {
+                size_t best = 0;
+                for (size_t i = 1; i < ch.size(); ++i)
+                    if (ch[i].cover_len < ch[best].cover_len) best = i;
+                info.cover = ch[best].cover;
+                info.cover_len = ch[best].cover_len;
+            } else {
+                for (auto& c : ch) {
+                    info.cover.insert(info.cover.end(), c.cover.begin(), c.cover.end());
+                    info.cover_len += c.cover_len;
+                }
+            }
+            return info;
+        }
         if (ch.size() > size_t(kMaxChildren)) unsupported("more than " + std::to_string(kMaxChildren) + " operands in one and/or");
         DOp op{};
         op.nchild = uint8_t(ch.size());
@@ -644,6 +668,7 @@ struct Compiler {
             while (ww > 32 && (uint64_t(ww) << 5) / 2 >= want) ww >>= 1;
         }
         cq.tile_words = ww;
+        cq.stack_depth = std::max<uint32_t>(max_depth, 1);
         uint64_t spans = (cq.total_len + 65535) / 65536;
         const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
         spans = std::min<uint64_t>(spans, tiles);

@@ -19,10 +19,10 @@ namespace vq {
 constexpr int kBlock = 256;         // threads per workgroup (4 waves of 64)
 constexpr int kCandCap = 2048;      // LDS candidate buffer (u64 keys) per workgroup
 constexpr int kMaxTopK = 1024;      // top + skip supported in-kernel
-constexpr int kStackDepth = 8;      // postfix evaluation stack
+constexpr int kStackDepth = 16;     // deepest postfix evaluation stack (LDS is sized to the batch's real depth)
 constexpr int kMaxChildren = 8;     // children per AND/OR node
 constexpr int kMaxLists = 64;       // lists per query in one launch
-constexpr int kMaxOps = 32;
+constexpr int kMaxOps = 160;
 constexpr int kMaxSkipWhen = 4;
 
 enum ListFlags : uint32_t {

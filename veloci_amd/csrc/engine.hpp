@@ -246,7 +246,7 @@ struct CompiledQuery {
     uint32_t top = 10, skip = 0, top_k = 10;
     uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
     uint64_t algorithmic_bytes = 0;
-    uint32_t tile_words = 0, n_spans = 1;
+    uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
 };
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req);

@@ -126,7 +126,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t nq = 0;
     uint64_t total_keys = 0, total_hist = 0, total_span_keys = 0, total_spans = 0, blob_bytes = 0;
     uint32_t max_lists = 1, max_ww = 32;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, var_u32 = 0;
+    uint32_t stack_depth = 1;
+    std::pair<uint32_t, uint32_t> max_lists_ww{0, 0};
     std::vector<uint32_t> keys_base, part_keys_off, span_base;
     std::vector<std::vector<uint32_t>> hist_offs, fac_out_offs;
     std::vector<FacetJob> jobs;
@@ -155,7 +157,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         blob_bytes += pack_blob(cq, idx, nullptr, nullptr, 0, 0, {}, {});
         max_lists = std::max<uint32_t>(max_lists, uint32_t(cq.lists.size()));
         max_ww = std::max(max_ww, cq.tile_words);
-        lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(cq.lists.size()), cq.tile_words));
+        stack_depth = std::max(stack_depth, cq.stack_depth);
+        var_u32 = std::max(var_u32, size_t(cq.tile_words) * (2 + 3 * cq.lists.size()) / 2 + 8);
+        max_lists_ww = std::max(max_lists_ww, std::make_pair(uint32_t(cq.lists.size()), cq.tile_words));
         algo_bytes += cq.algorithmic_bytes;
     }
     if (total_span_keys > 0xFFFFFFFFull || total_hist > 0xFFFFFFFFull || total_spans > 0x7FFFFFFFull)
@@ -212,10 +216,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipMemsetAsync(pb->d_partial, 0, lay.bytes, st));
 
     // ---- the scan
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == 0)
+            lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(idx.ev0, st));
-    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, ws.d_span_keys.as<unsigned long long>(),
+    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, stack_depth, ws.d_span_keys.as<unsigned long long>(),
                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     if (pb->profiled) {
         VQ_HIP(hipEventRecord(idx.ev1, st));

@@ -95,8 +95,10 @@ static void shard_subrange(const uint32_t* b, const uint32_t* e, uint32_t lo, ui
 
 std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        throw VelociError(vqreq::ERR_DEVICE, "no HIP device available: the veloci_amd query path needs an MI355X (no CPU fallback)");
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev <= 0)
+        throw VelociError(vqreq::ERR_DEVICE, std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(de) + ", count " +
+                                                 std::to_string(ndev) + "): the veloci_amd query path needs an MI355X (no CPU fallback)");
     if (device < 0 || device >= ndev) throw VelociError(vqreq::ERR_INVALID_ARGUMENT, "device index out of range");
     VQ_HIP(hipSetDevice(device));
 

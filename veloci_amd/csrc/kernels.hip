@@ -162,20 +162,19 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
 // ------------------------------------------------------------------------------------ k_tile_scan
 // LDS map (u32 units), fixed part first:
 //   [0 .. 2*kCandCap)                        candidate keys (u64)
-//   [.. + kStackDepth*kBlock)                postfix stack, one column per thread (words, then scores)
 //   misc: thr(2) cand_n next_head hits_acc(2) pad
 //   cur[kMaxLists] cnt_lo[kMaxLists] cnt_hi[kMaxLists]
+//   stack[stack_depth*kBlock]               postfix stack, one column per thread (words, then scores)
 //   rootw[WW]  bm[L*WW]  pre[L*WW] (u16)
 constexpr uint32_t kLdsCand = 0;
-constexpr uint32_t kLdsStack = kLdsCand + 2 * kCandCap;
-constexpr uint32_t kLdsMisc = kLdsStack + kStackDepth * kBlock;
+constexpr uint32_t kLdsMisc = kLdsCand + 2 * kCandCap;
 constexpr uint32_t kLdsCur = kLdsMisc + 8;
 constexpr uint32_t kLdsCntLo = kLdsCur + kMaxLists;
 constexpr uint32_t kLdsCntHi = kLdsCntLo + kMaxLists;
-constexpr uint32_t kLdsVar = kLdsCntHi + kMaxLists;
+constexpr uint32_t kLdsStack = kLdsCntHi + kMaxLists;
 
-size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words) {
-    size_t u32s = kLdsVar + (size_t)tile_words + (size_t)n_lists * tile_words + ((size_t)n_lists * tile_words + 1) / 2;
+size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth) {
+    size_t u32s = kLdsStack + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_lists * tile_words + ((size_t)n_lists * tile_words + 1) / 2;
     return u32s * 4 + 16;
 }
 
@@ -204,7 +203,7 @@ __device__ __forceinline__ uint32_t eval_presence_word(const DOp* __restrict__ o
 }
 
 __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                      const uint32_t* __restrict__ span_base, uint32_t nq,
+                                                      const uint32_t* __restrict__ span_base, uint32_t nq, uint32_t stack_depth,
                                                       unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits,
                                                       uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     uint32_t* cur = lds + kLdsCur;
     uint32_t* cnt_lo = lds + kLdsCntLo;
     uint32_t* cnt_hi = lds + kLdsCntHi;
-    uint32_t* rootw = lds + kLdsVar;
+    uint32_t* rootw = lds + kLdsStack + stack_depth * kBlock;
     uint32_t* bm = rootw + WW;
     uint16_t* pre = reinterpret_cast<uint16_t*>(bm + L * WW);
     CandState cs{cand, cand_n, thr};
@@ -657,9 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
 
 // ------------------------------------------------------------------------------------ launchers
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      uint32_t nq, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
+                      uint32_t nq, uint32_t stack_depth, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, nq, span_keys, num_hits, hist);
+    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, nq, stack_depth, span_keys, num_hits, hist);
 }
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {

@@ -12,10 +12,10 @@ struct FacetJob {
     uint32_t hist_off, num_values, top, out_off;
 };
 
-size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words);
+size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth);
 
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      uint32_t nq, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
+                      uint32_t nq, uint32_t stack_depth, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys);
 void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const uint8_t* gathered, uint32_t num_shards,
