@@ -124,7 +124,7 @@ def _bernoulli_list(dev, lo, hi, chunk, key, thr32, shared=None):
     docs = torch.cat(docs_out) if docs_out else torch.zeros(0, dtype=torch.int64, device=dev)
     pos = _h32(key ^ 0xA5A5A5A5, docs) % 16
     ntok = _h32(key ^ 0x5A5A5A5A, docs) % 13
-    return docs.to(torch.int64).cpu().numpy().astype(np.uint32), (pos * 13 + ntok).cpu().numpy().astype(np.int64)
+    return docs.to(torch.int32).cpu().numpy().view(np.uint32), (pos * 13 + ntok).to(torch.int16).cpu().numpy().astype(np.int64)
 
 
 def _zipf_cdf(n):
