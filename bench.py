@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency loop (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,14 +116,14 @@ def main():
 
     # single-query latency (p50) through the same path
     lat = []
-    for i in range(50):
+    for i in range(0 if args.no_latency else 50):
         a = time.perf_counter()
         if searcher is not None:
             searcher.search_batch([reqs[i % len(reqs)]])
         else:
             veloci_amd.search_batch([reqs[i % len(reqs)]], index)
         lat.append((time.perf_counter() - a) * 1e3)
-    p50 = float(np.median(lat[10:]))
+    p50 = float(np.median(lat[10:])) if lat else float('nan')
 
     out = None
     if rank == 0:

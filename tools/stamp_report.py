@@ -1,0 +1,24 @@
+"""Diagnostic: phase shares of k_tile_scan (stamp build).  VQ_LIB=veloci_amd/libveloci_amd_stamp.so python tools/stamp_report.py"""
+import ctypes as C, os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import veloci_amd
+from veloci_amd import synth
+docs = int(os.environ.get("DOCS", "100000000")); tri = int(os.environ.get("TRIPLES", "8"))
+spec = synth.SynthSpec(num_docs=docs, num_terms=10000, triples=tri, with_t2t=False, with_facets=False, with_boost=False, with_phrase=False)
+data, meta = synth.generate(spec)
+idx = veloci_amd.Index(data)
+reqs = [veloci_amd.Request(synth.req_and(list(meta.triples[i % tri]))) for i in range(int(os.environ.get("BATCH", "256")))]
+L = veloci_amd.lib()
+buf = (C.c_ulonglong * 16)()
+veloci_amd.search_batch(reqs, idx)
+L.vq_debug_stamps(buf, 1)
+veloci_amd.search_batch(reqs, idx)
+L.vq_debug_stamps(buf, 1)
+v = list(buf)
+names = ["init", "P0+P1 clear", "P2 scatter", "P3 presence", "P4 prefix", "P5 eval", "final"]
+tot = sum(v[:7])
+for n, x in zip(names, v[:7]):
+    print(f"{n:14s} {x/tot*100:6.2f}%   {x/max(v[7],1):10.1f} ticks/tile")
+print("P2 detail: issue", v[9]/max(v[7],1), "process", v[10]/max(v[7],1), "barrier", v[2]/max(v[7],1))
+print("tiles", v[7], "wgs", v[8], "ticks/tile total", tot / max(v[7], 1))

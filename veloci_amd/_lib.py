@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libveloci_amd.so")
+_SO = os.environ.get("VQ_LIB") or os.path.join(_HERE, "libveloci_amd.so")
 _LIB = None
 
 VQ_OK = 0

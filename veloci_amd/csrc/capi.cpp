@@ -343,4 +343,8 @@ int vq_profile_read(const vq_index* i, int reset, double* scan_kernel_ms, uint64
     });
 }
 
+#ifdef VQ_STAMP
+void vq_debug_stamps(unsigned long long* out, int reset) { vq::debug_read_stamps(out, reset); }
+#endif
+
 }  // extern "C"

@@ -7,6 +7,7 @@
 // lists is NOT done here — it is encoded for k_tile_scan.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 
@@ -465,6 +466,65 @@ struct Compiler {
         return info;
     }
 
+    // Presence program for k_tile_scan P3: simulate the postfix stacks of the score tree and the filter tree on
+    // slot references and emit three-address ops; the last op writes the root words (score root AND filter root).
+    void build_presence_program() {
+        std::vector<uint16_t> free_temps;
+        uint32_t next_temp = 0;
+        auto alloc_temp = [&]() -> uint16_t {
+            if (!free_temps.empty()) {
+                uint16_t t = free_temps.back();
+                free_temps.pop_back();
+                return t;
+            }
+            return uint16_t(kSlotTemp | next_temp++);
+        };
+        auto release = [&](uint16_t ref) {
+            if (ref & kSlotTemp) free_temps.push_back(ref);
+        };
+        auto emit = [&](uint8_t kind, const std::vector<uint16_t>& in, uint16_t out) {
+            DPresOp op{};
+            op.kind = kind;
+            op.out = out;
+            op.n_in = uint16_t(in.size());
+            op.in_begin = uint16_t(cq.pres_in.size());
+            cq.pres_in.insert(cq.pres_in.end(), in.begin(), in.end());
+            cq.pres.push_back(op);
+        };
+        auto run = [&](const std::vector<DOp>& ops) -> uint16_t {
+            std::vector<uint16_t> st;
+            for (const DOp& op : ops) {
+                if (op.kind == OP_LEAF) {
+                    if (op.list_count == 1) {
+                        st.push_back(op.list_begin);
+                    } else {
+                        std::vector<uint16_t> in;
+                        for (uint32_t j = 0; j < op.list_count; ++j) in.push_back(uint16_t(op.list_begin + j));
+                        uint16_t t = alloc_temp();
+                        emit(op.list_count ? PRES_OR : PRES_ZERO, in, t);
+                        st.push_back(t);
+                    }
+                } else {
+                    std::vector<uint16_t> in(st.end() - op.nchild, st.end());
+                    st.resize(st.size() - op.nchild);
+                    uint16_t t = alloc_temp();  // allocated before the inputs are released: never aliases an input
+                    emit(op.kind == OP_AND ? PRES_AND : PRES_OR, in, t);
+                    for (uint16_t r : in) release(r);
+                    st.push_back(t);
+                }
+            }
+            return st.empty() ? uint16_t(0) : st.back();
+        };
+        std::vector<uint16_t> roots;
+        bool any = !cq.ops.empty();
+        if (any) roots.push_back(run(cq.ops));
+        if (!cq.fops.empty()) roots.push_back(run(cq.fops));
+        if (!any) emit(PRES_ZERO, {}, kSlotRoot);
+        else emit(PRES_AND, roots, kSlotRoot);
+        cq.n_temps = next_temp;
+        if (next_temp > 32) unsupported("presence program needs more than 32 temporary bitmaps");
+    }
+
     // ------------------------------------------------------------ the whole request (search.rs:143-228)
     void run() {
         if (req.has_select) unsupported("select");
@@ -653,23 +713,50 @@ struct Compiler {
             }
         cq.algorithmic_bytes += 8ull * cq.top_k;
 
+        build_presence_program();
+        {  // shape that the kernel scores without the interpreter: <= 4 single-list posting leaves under one AND/OR
+            const size_t n = cq.ops.size();
+            auto is_leaf1 = [&](const DOp& o) { return o.kind == OP_LEAF && o.list_count == 1 && (cq.lists[o.list_begin].flags & LIST_HAS_SCORES); };
+            if (n == 1 && is_leaf1(cq.ops[0])) cq.simple_n = 1;
+            else if (n >= 3 && n <= 5 && cq.ops[n - 1].kind != OP_LEAF && cq.ops[n - 1].nchild == n - 1) {
+                bool ok = true;
+                for (size_t i = 0; i + 1 < n; ++i) ok = ok && is_leaf1(cq.ops[i]);
+                if (ok) cq.simple_n = uint32_t(n - 1);
+            }
+        }
+
         // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
         const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
-        uint32_t ww = 1024;  // W = 32768 docs
-        const size_t var_budget = 40 * 1024;
-        while (ww > 32 && (size_t(ww) + size_t(L) * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
-        if ((size_t(ww) + size_t(L) * ww + size_t(L) * ww / 2) * 4 > 96 * 1024) unsupported("too many lists for the LDS tile");
+        static const uint32_t ww_max = [] {  // tuning knobs (experiments): VQ_TILE_WORDS_MAX, VQ_TILE_LDS_KB, VQ_SPAN_POSTINGS
+            const char* e = std::getenv("VQ_TILE_WORDS_MAX");
+            uint32_t v = e ? uint32_t(std::atoi(e)) : 256u;
+            uint32_t p2 = 64;
+            while (p2 < v && p2 < 2048) p2 <<= 1;
+            return p2;
+        }();
+        static const size_t var_budget = [] {
+            const char* e = std::getenv("VQ_TILE_LDS_KB");
+            return size_t(e ? std::atoi(e) : 12) * 1024;
+        }();
+        static const uint64_t span_postings = [] {
+            const char* e = std::getenv("VQ_SPAN_POSTINGS");
+            return uint64_t(e ? std::atoll(e) : 65536);
+        }();
+        uint32_t ww = ww_max;  // W = 32 * ww docs
+        const size_t TL = size_t(L) + cq.n_temps;
+        while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
+        if ((size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > 96 * 1024) unsupported("too many lists for the LDS tile");
         const uint64_t cover_len = std::max<uint64_t>(root.cover_len, 1);
         // a sparse cover visits about one tile per cover doc: shrink the tile until it holds ~1 cover entry,
         // so that the per-tile clear / prefix work stays proportional to what is actually read
         if (cover_len * (uint64_t(ww) << 5) / std::max<uint64_t>(range, 1) < 64) {
-            const uint64_t want = std::max<uint64_t>(range / cover_len, 1024);
-            while (ww > 32 && (uint64_t(ww) << 5) / 2 >= want) ww >>= 1;
+            const uint64_t want = std::max<uint64_t>(range / cover_len, 2048);
+            while (ww > 64 && (uint64_t(ww) << 5) / 2 >= want) ww >>= 1;
         }
         cq.tile_words = ww;
         cq.stack_depth = std::max<uint32_t>(max_depth, 1);
-        uint64_t spans = (cq.total_len + 65535) / 65536;
+        uint64_t spans = (cq.total_len + span_postings - 1) / span_postings;
         const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);

@@ -16,7 +16,7 @@
 
 namespace vq {
 
-constexpr int kBlock = 256;         // threads per workgroup (4 waves of 64)
+constexpr int kBlock = 64;          // threads per workgroup: ONE wave (no cross-wave barriers anywhere in the scan)
 constexpr int kCandCap = 2048;      // LDS candidate buffer (u64 keys) per workgroup
 constexpr int kMaxTopK = 1024;      // top + skip supported in-kernel
 constexpr int kStackDepth = 16;     // deepest postfix evaluation stack (LDS is sized to the batch's real depth)
@@ -50,6 +50,19 @@ struct DOp {  // 24 B
     uint16_t list_count;
     uint8_t child_slot[kMaxChildren];  // OR: term slot of each child, children in stack (request) order
     uint8_t and_order[kMaxChildren];   // AND: child indices in summation order: others first, shortest last (set_op.rs:393,415-416)
+};
+
+// Presence program: the AND/OR/filter trees as three-address code over tile bitmaps (k_tile_scan P3).
+// A slot reference is a list index, or (bit 15 set) a temporary bitmap; 0xFFFF = the root words.
+enum PresKind : uint8_t { PRES_AND = 0, PRES_OR = 1, PRES_ZERO = 2 };
+constexpr uint16_t kSlotTemp = 0x8000;
+constexpr uint16_t kSlotRoot = 0xFFFF;
+struct DPresOp {  // 8 B
+    uint8_t kind;
+    uint8_t pad;
+    uint16_t out;       // temp slot (kSlotTemp | t) or kSlotRoot
+    uint16_t n_in;
+    uint16_t in_begin;  // index into the slot reference array
 };
 
 struct DGroup {  // phrase group: present in ANY list -> multiply once (plan_steps.rs:235-277)
@@ -104,6 +117,10 @@ struct QHeader {
     uint32_t doc_lo, doc_hi;
     uint32_t part_keys_off;  // u64 index of this query's top_k keys inside the partial buffer's key area
     uint32_t blob_bytes;
+    uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
+    uint32_t n_pres, off_pres, off_pres_in, n_temps;
+    uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
+    uint32_t pad[2];
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

@@ -237,6 +237,10 @@ struct CompiledQuery {
     std::vector<HList> lists;
     std::vector<std::vector<uint32_t>> inline_lists;
     std::vector<DOp> ops, fops;
+    std::vector<DPresOp> pres;
+    std::vector<uint16_t> pres_in;
+    uint32_t n_temps = 0;
+    uint32_t simple_n = 0;
     std::vector<DGroup> groups;
     std::vector<DTermBoost> tboosts;
     std::vector<DColBoost> cols;

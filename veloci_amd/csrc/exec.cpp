@@ -30,7 +30,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // serialise one compiled query into `dst` (host), whose device address will be `dev`
 static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst, const uint8_t* dev, uint32_t keys_base, uint32_t part_keys_off,
-                        const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off) {
+                        const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off, size_t* desc_bytes_out = nullptr) {
     size_t off = align_up(sizeof(QHeader), 16);
     QHeader h{};
     auto section = [&](size_t bytes) {
@@ -54,6 +54,13 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_col = uint32_t(section(cq.cols.size() * sizeof(DColBoost)));
     h.off_locf = uint32_t(section(cq.locf.size() * sizeof(DLocField)));
     h.off_facets = uint32_t(section(cq.facets.size() * sizeof(DFacet)));
+    h.n_pres = uint32_t(cq.pres.size());
+    h.off_pres = uint32_t(section(cq.pres.size() * sizeof(DPresOp)));
+    h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
+    h.n_temps = cq.n_temps;
+    h.simple_n = cq.simple_n;
+    h.desc_bytes = uint32_t(off);
+    if (desc_bytes_out) *desc_bytes_out = off;
     std::vector<size_t> inline_off(cq.inline_lists.size());
     for (size_t i = 0; i < cq.inline_lists.size(); ++i) inline_off[i] = section(align_up(cq.inline_lists[i].size(), 4) * 4);
     h.top_k = cq.top_k;
@@ -84,6 +91,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!cq.tboosts.empty()) std::memcpy(dst + h.off_tboost, cq.tboosts.data(), cq.tboosts.size() * sizeof(DTermBoost));
     if (!cq.cols.empty()) std::memcpy(dst + h.off_col, cq.cols.data(), cq.cols.size() * sizeof(DColBoost));
     if (!cq.locf.empty()) std::memcpy(dst + h.off_locf, cq.locf.data(), cq.locf.size() * sizeof(DLocField));
+    if (!cq.pres.empty()) std::memcpy(dst + h.off_pres, cq.pres.data(), cq.pres.size() * sizeof(DPresOp));
+    if (!cq.pres_in.empty()) std::memcpy(dst + h.off_pres_in, cq.pres_in.data(), cq.pres_in.size() * sizeof(uint16_t));
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);
     for (size_t i = 0; i < cq.facets.size(); ++i) {
         DFacet f = cq.facets[i];
@@ -126,9 +135,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t nq = 0;
     uint64_t total_keys = 0, total_hist = 0, total_span_keys = 0, total_spans = 0, blob_bytes = 0;
     uint32_t max_lists = 1, max_ww = 32;
-    size_t lds_bytes = 0, var_u32 = 0;
+    size_t lds_bytes = 0;
     uint32_t stack_depth = 1;
-    std::pair<uint32_t, uint32_t> max_lists_ww{0, 0};
     std::vector<uint32_t> keys_base, part_keys_off, span_base;
     std::vector<std::vector<uint32_t>> hist_offs, fac_out_offs;
     std::vector<FacetJob> jobs;
@@ -158,8 +166,6 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         max_lists = std::max<uint32_t>(max_lists, uint32_t(cq.lists.size()));
         max_ww = std::max(max_ww, cq.tile_words);
         stack_depth = std::max(stack_depth, cq.stack_depth);
-        var_u32 = std::max(var_u32, size_t(cq.tile_words) * (2 + 3 * cq.lists.size()) / 2 + 8);
-        max_lists_ww = std::max(max_lists_ww, std::make_pair(uint32_t(cq.lists.size()), cq.tile_words));
         algo_bytes += cq.algorithmic_bytes;
     }
     if (total_span_keys > 0xFFFFFFFFull || total_hist > 0xFFFFFFFFull || total_spans > 0x7FFFFFFFull)
@@ -216,13 +222,26 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipMemsetAsync(pb->d_partial, 0, lay.bytes, st));
 
     // ---- the scan
+    uint32_t max_top_k = 1;
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == 0) max_top_k = std::max(max_top_k, pb->queries[i].top_k);
+    uint32_t desc_cap = 0;  // bytes of the largest query descriptor (staged into LDS by every workgroup)
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == 0) {
+            size_t d = 0;
+            pack_blob(pb->queries[i], idx, nullptr, nullptr, 0, 0, {}, {}, &d);
+            desc_cap = std::max(desc_cap, uint32_t(d));
+        }
+    desc_cap = uint32_t(align_up(desc_cap, 16));
+    uint32_t cand_cap = 256;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
+    while (cand_cap < 2 * max_top_k) cand_cap <<= 1;
     for (size_t i = 0; i < n; ++i)
         if (pb->queries[i].status == 0)
-            lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth));
+            lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(idx.ev0, st));
-    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, stack_depth, ws.d_span_keys.as<unsigned long long>(),
+    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     if (pb->profiled) {
         VQ_HIP(hipEventRecord(idx.ev1, st));

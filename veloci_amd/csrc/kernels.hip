@@ -5,10 +5,11 @@
 //   k_tile_scan    K1+K2+K3+K4+K5+K6+K7+K10+K11 fused: one workgroup owns a contiguous span of the
 //                  shard's doc-id space for one query and walks it tile by tile:
 //                    stream the doc ids of every list that falls into the tile (16 B/lane coalesced
-//                    loads) -> per-list LDS bitmaps -> postfix presence program on bitmap words
-//                    (AND/OR/filter) -> for surviving docs only: rank = prefix popcount -> gather the
-//                    f16 anchor scores -> reference score arithmetic -> boosts -> facet histogram ->
-//                    per-workgroup exact top-k (64-bit keys, LDS candidate buffer + bitonic prune)
+//                    loads, several lists in flight per lane) -> per-list LDS bitmaps -> postfix presence
+//                    program on bitmap words (AND/OR/filter) -> for surviving docs only: rank = prefix
+//                    popcount -> gather the f16 anchor scores -> reference score arithmetic -> boosts ->
+//                    facet histogram -> per-workgroup exact top-k (64-bit keys, LDS candidate buffer +
+//                    bitonic prune)
 //   k_merge_spans  per query: merge the span-local top-k lists into the shard partial
 //   k_finalize     per query: merge the partials of all shards (after the RCCL all-gather) into the
 //                  final ranked hits; sum hit counts
@@ -22,21 +23,54 @@
 
 namespace vq {
 
+// Pointers read out of the query blob are generic ("flat") to the compiler; every one of them points into
+// HBM.  Casting to the global address space turns flat_load (which also ties up the LDS counter) into
+// global_load.
+#define VQ_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ const VQ_GLOBAL T* as_global(const T* p) {
+    return (const VQ_GLOBAL T*)p;
+}
+
+// Diagnostic build only (make STAMP=1): cycle shares of the scan phases as seen by wave 0 of every workgroup.
+#ifdef VQ_STAMP
+__device__ unsigned long long g_stamp[16];
+#define VQ_STAMP_INIT                                       \
+    unsigned long long _st0 = __builtin_amdgcn_s_memtime(); \
+    unsigned long long _acc[16] = {0};
+#define VQ_STAMP_AT(k)                                              \
+    {                                                               \
+        unsigned long long _st1 = __builtin_amdgcn_s_memtime();     \
+        _acc[k] += _st1 - _st0;                                     \
+        _st0 = _st1;                                                \
+    }
+#define VQ_STAMP_COUNT(k) _acc[k] += 1ull;
+#define VQ_STAMP_FLUSH                                                  \
+    if (threadIdx.x == 0) {                                             \
+        _Pragma("unroll") for (int _k = 0; _k < 16; ++_k) if (_acc[_k]) atomicAdd(&g_stamp[_k], _acc[_k]); \
+    }
+void debug_read_stamps(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z);
+    }
+}
+#else
+#define VQ_STAMP_INIT
+#define VQ_STAMP_AT(k)
+#define VQ_STAMP_COUNT(k)
+#define VQ_STAMP_FLUSH
+#endif
+
 // ------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t y = __shfl_xor(v, o, 64);
-        v = y < v ? y : v;
-    }
-    return v;
-}
-
 // First index in a[0..n) with a[idx] >= target (a ascending).  Whole wave cooperates: 64 probes per
 // round, ~log64(n) dependent rounds instead of log2(n).
-__device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a, uint32_t n, uint32_t target) {
+__device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a_, uint32_t n, uint32_t target) {
+    const VQ_GLOBAL uint32_t* a = as_global(a_);
     uint32_t lo = 0, hi = n;
     const uint32_t lane = lane_id();
     while (hi > lo) {
@@ -59,37 +93,29 @@ __device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a, uint32_t n,
     return lo;
 }
 
-// exclusive prefix popcount of `words[0..ww)` into pre[0..ww) by one wave
-__device__ void wave_prefix_popc(const uint32_t* words, uint16_t* pre, uint32_t ww) {
-    const uint32_t lane = lane_id();
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < ww; c0 += 64) {
-        uint32_t idx = c0 + lane;
-        uint32_t x = idx < ww ? (uint32_t)__popc(words[idx]) : 0u;
-        uint32_t incl = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t y = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += y;
-        }
-        if (idx < ww) pre[idx] = (uint16_t)(carry + incl - x);
-        carry += __shfl(incl, 63, 64);
-    }
-}
-
 // ------------------------------------------------------------------------------------ candidate buffer
 // LDS buffer of 64-bit keys; prune = bitonic sort (descending) + keep k + raise the threshold.
 struct CandState {
-    unsigned long long* cand;  // [kCandCap]
-    uint32_t* n;               // pushes so far (may exceed kCandCap)
+    unsigned long long* cand;  // [cap]
+    uint32_t* n;               // pushes so far (may exceed cap)
     unsigned long long* thr;   // keys <= thr cannot enter the top-k any more
+    uint32_t cap;              // power of two, >= 2 * k
 };
 
-__device__ void cand_prune(const CandState& cs, uint32_t k) {
+// All threads of the workgroup call this together.  Without `force` a buffer that already holds <= k keys
+// is left as it is (the caller only needs the SET of the best k); with `force` the keys end up sorted
+// descending.  On return *cs.n <= k.
+__device__ void cand_prune(const CandState& cs, uint32_t k, bool force = false) {
     __syncthreads();
     uint32_t n = *cs.n;
-    if (n > (uint32_t)kCandCap) n = kCandCap;
-    uint32_t m = 1;
+    if (n > cs.cap) n = cs.cap;
+    __syncthreads();
+    if (n <= k && !force) {
+        if (threadIdx.x == 0) *cs.n = n;
+        __syncthreads();
+        return;
+    }
+    uint32_t m = 2;
     while (m < n) m <<= 1;
     for (uint32_t i = n + threadIdx.x; i < m; i += kBlock) cs.cand[i] = 0ull;
     __syncthreads();
@@ -109,9 +135,8 @@ __device__ void cand_prune(const CandState& cs, uint32_t k) {
         }
     }
     if (threadIdx.x == 0) {
-        uint32_t nn = n < k ? n : k;
-        *cs.n = nn;
-        if (n >= k) *cs.thr = cs.cand[k - 1];
+        *cs.n = n < k ? n : k;
+        if (n >= k && k > 0) *cs.thr = cs.cand[k - 1];
     }
     __syncthreads();
 }
@@ -133,8 +158,8 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
     if (doc < cb.key_base) return score;
     uint32_t row = doc - cb.key_base;
     if (row >= cb.num_keys) return score;
-    if (cb.present && !((cb.present[row >> 5] >> (row & 31u)) & 1u)) return score;
-    float v = cb.values[row];
+    if (cb.present && !((as_global(cb.present)[row >> 5] >> (row & 31u)) & 1u)) return score;
+    float v = as_global(cb.values)[row];
     float vp = v + cb.param;
     switch (cb.fun) {
         case BF_LOG10: score *= log10_f32(vp); break;
@@ -159,53 +184,233 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
     return score;
 }
 
-// ------------------------------------------------------------------------------------ k_tile_scan
-// LDS map (u32 units), fixed part first:
-//   [0 .. 2*kCandCap)                        candidate keys (u64)
-//   misc: thr(2) cand_n next_head hits_acc(2) pad
-//   cur[kMaxLists] cnt_lo[kMaxLists] cnt_hi[kMaxLists]
-//   stack[stack_depth*kBlock]               postfix stack, one column per thread (words, then scores)
-//   rootw[WW]  bm[L*WW]  pre[L*WW] (u16)
-constexpr uint32_t kLdsCand = 0;
-constexpr uint32_t kLdsMisc = kLdsCand + 2 * kCandCap;
-constexpr uint32_t kLdsCur = kLdsMisc + 8;
-constexpr uint32_t kLdsCntLo = kLdsCur + kMaxLists;
-constexpr uint32_t kLdsCntHi = kLdsCntLo + kMaxLists;
-constexpr uint32_t kLdsStack = kLdsCntHi + kMaxLists;
+// ------------------------------------------------------------------------------------ per-hit scoring
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t x, uint32_t* total) {
+    const uint32_t lane = lane_id();
+    uint32_t incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += y;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - x;
+}
 
-size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth) {
-    size_t u32s = kLdsStack + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_lists * tile_words + ((size_t)n_lists * tile_words + 1) / 2;
+struct ScoreCtx {
+    const DList* lists;
+    const DOp* ops;
+    uint32_t n_ops;
+    uint32_t simple_n;  // != 0: ops = simple_n single-list posting leaves (+ one AND/OR root when simple_n > 1)
+    const DGroup* groups;
+    uint32_t n_groups;
+    const DTermBoost* tboosts;
+    uint32_t n_tboost;
+    const DColBoost* cols;
+    uint32_t n_col;
+    const DLocField* locf;
+    uint32_t n_locf;
+    const DFacet* facets;
+    uint32_t n_facets;
+    const uint32_t* bm;
+    const uint16_t* pre;
+    const uint32_t* cur;
+    const uint32_t* cnt_lo;
+    uint32_t WW;
+    float* fstack;  // this lane's column, stride kBlock
+    uint32_t* hist;
+};
+
+__device__ __forceinline__ float pick4(float v0, float v1, float v2, float v3, uint32_t k) { return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3; }
+
+// flat AND / OR / single leaf over <= 4 single-list posting leaves: all gathers are issued together
+__device__ __forceinline__ float tree_score_simple(const ScoreCtx& c, uint32_t w, uint32_t b) {
+    const uint32_t n = c.simple_n;
+    const uint32_t below = (1u << b) - 1u;
+    uint32_t presm = 0;
+    uint32_t idx[4] = {0, 0, 0, 0};
+    uint32_t li[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k < n) {
+            li[k] = c.ops[k].list_begin;
+            const uint32_t word = c.bm[li[k] * c.WW + w];
+            if ((word >> b) & 1u) {
+                presm |= 1u << k;
+                idx[k] = c.cur[li[k]] + c.cnt_lo[li[k]] + (uint32_t)c.pre[li[k] * c.WW + w] + (uint32_t)__popc(word & below);
+            }
+        }
+    }
+    uint16_t raw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if ((presm >> k) & 1u) raw[k] = as_global(c.lists[li[k]].scores)[idx[k]];
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) val[k] = posting_value(c.lists[li[k]].term_score, raw[k]);
+    if (n == 1) return val[0];
+    const DOp& root = c.ops[n];
+    if (root.kind == OP_AND) {  // set_op.rs:415-416: others summed first, the shortest list's score last
+        float s = 0.0f;
+        for (uint32_t k = 0; k < n; ++k) s += pick4(val[0], val[1], val[2], val[3], root.and_order[k]);
+        return s;
+    }
+    float sum = 0.0f, nd = 0.0f;  // set_op.rs:169-186
+    for (uint32_t slot = 0; slot < root.nslots; ++slot) {
+        float m = 0.0f;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n && root.child_slot[k] == slot && ((presm >> k) & 1u)) m = fmaxf(m, val[k]);
+        if (m >= 0.00001f) nd += 1.0f;
+        sum += m;
+    }
+    return sum * nd * nd;
+}
+
+// any tree: postfix interpreter; stack slot index is uniform across lanes
+__device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
+    const uint32_t below = (1u << b) - 1u;
+    uint32_t sp = 0;
+    uint32_t pmask = 0;  // bit s: stack slot s holds a present value
+    for (uint32_t o = 0; o < c.n_ops; ++o) {
+        const DOp& op = c.ops[o];
+        float s = 0.0f;
+        bool present = false;
+        if (op.kind == OP_LEAF) {
+            for (uint32_t j = 0; j < op.list_count; ++j) {
+                const uint32_t li = op.list_begin + j;
+                const uint32_t word = c.bm[li * c.WW + w];
+                if ((word >> b) & 1u) {
+                    float v = 0.0f;
+                    if (c.lists[li].flags & LIST_HAS_SCORES) {
+                        const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
+                        const uint32_t idx = c.cur[li] + c.cnt_lo[li] + rank;
+                        v = posting_value(c.lists[li].term_score, as_global(c.lists[li].scores)[idx]);
+                    }
+                    if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
+                    present = true;
+                }
+            }
+        } else if (op.kind == OP_AND) {
+            const uint32_t base = sp - op.nchild;
+            present = true;
+            for (uint32_t k = 0; k < op.nchild; ++k) present = present && ((pmask >> (base + k)) & 1u);
+            if (present) {
+                s = 0.0f;  // set_op.rs:415-416
+                for (uint32_t k = 0; k < op.nchild; ++k) s += c.fstack[(base + op.and_order[k]) * kBlock];
+            }
+            sp = base;
+        } else {
+            const uint32_t base = sp - op.nchild;
+            float sum = 0.0f;
+            float nd = 0.0f;
+            for (uint32_t slot = 0; slot < op.nslots; ++slot) {  // set_op.rs:169-186
+                float m = 0.0f;
+                for (uint32_t k = 0; k < op.nchild; ++k) {
+                    if (op.child_slot[k] == slot && ((pmask >> (base + k)) & 1u)) {
+                        present = true;
+                        m = fmaxf(m, c.fstack[(base + k) * kBlock]);
+                    }
+                }
+                if (m >= 0.00001f) nd += 1.0f;
+                sum += m;
+            }
+            s = sum * nd * nd;
+            sp = base;
+        }
+        c.fstack[sp * kBlock] = s;
+        pmask = present ? (pmask | (1u << sp)) : (pmask & ~(1u << sp));
+        ++sp;
+    }
+    return c.fstack[0];
+}
+
+// sink stages in the reference's order: column boosts, phrase groups, term boosts, text locality, facets
+__device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint32_t w, uint32_t b) {
+    for (uint32_t k = 0; k < c.n_col; ++k) score = apply_col_boost(score, c.cols[k], doc);
+    for (uint32_t g = 0; g < c.n_groups; ++g) {
+        bool in = false;
+        for (uint32_t j = 0; j < c.groups[g].list_count; ++j) in = in || ((c.bm[(c.groups[g].list_begin + j) * c.WW + w] >> b) & 1u);
+        if (in) score *= c.groups[g].mult;
+    }
+    for (uint32_t t = 0; t < c.n_tboost; ++t)
+        if ((c.bm[c.tboosts[t].list * c.WW + w] >> b) & 1u) score *= c.tboosts[t].mult;
+    if (c.n_locf) {  // boost.rs:11-87: 2*c*c per field with c > 1, the MINIMUM over fields (:25)
+        float best = 0.0f;
+        bool have = false;
+        for (uint32_t f = 0; f < c.n_locf; ++f) {
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += (c.bm[(c.locf[f].list_begin + j) * c.WW + w] >> b) & 1u;
+            if (cnt > 1u) {
+                float bv = 2.0f * (float)cnt * (float)cnt;
+                if (!have || bv < best) best = bv;
+                have = true;
+            }
+        }
+        if (have) score *= best;
+    }
+    for (uint32_t f = 0; f < c.n_facets; ++f) {  // persistence.rs:164-175 count_values_for_ids
+        const DFacet& fa = c.facets[f];
+        if (doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
+            const uint32_t row = doc - fa.key_base;
+            const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+            for (unsigned long long e = e0; e < e1; ++e) {
+                const uint32_t v = as_global(fa.values)[e];
+                if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
+            }
+        }
+    }
+    return score;
+}
+
+// ------------------------------------------------------------------------------------ k_tile_scan
+// LDS map (u32 units):
+//   misc[8]: thr(2) cand_n hits_acc pad
+//   cur[2][64] nxt[2][64]   per-list cursor / doc at the cursor, double buffered by tile parity
+//   nxt_new[64] cnt_lo[64] cnt_hi[64]
+//   desc[desc_cap/4]        the query descriptor (header, lists, programs, sink stages) staged from the blob
+//   cand[2*cand_cap]        candidate keys (u64)
+//   stack[stack_depth*256]  score stack, one column per thread
+//   rootw[WW]  bm[(L+T)*WW] (list bitmaps, then the presence program's temporaries)  pre[L*WW] (u16)
+constexpr uint32_t kLdsMisc = 0;
+constexpr uint32_t kLdsCur = 8;
+constexpr uint32_t kLdsNxt = kLdsCur + 2 * kMaxLists;
+constexpr uint32_t kLdsNxtNew = kLdsNxt + 2 * kMaxLists;
+constexpr uint32_t kLdsCntLo = kLdsNxtNew + kMaxLists;
+constexpr uint32_t kLdsCntHi = kLdsCntLo + kMaxLists;
+constexpr uint32_t kLdsSurv = kLdsCntHi + kMaxLists;  // compacted survivor codes, u16[kSurvCap]
+constexpr uint32_t kSurvCap = 256;
+constexpr uint32_t kLdsDesc = kLdsSurv + kSurvCap / 2;
+
+size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap) {
+    size_t u32s = kLdsDesc + desc_cap / 4 + 2 * (size_t)cand_cap + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_bitmaps * tile_words +
+                  ((size_t)n_lists * tile_words + 1) / 2;
     return u32s * 4 + 16;
 }
 
-__device__ __forceinline__ uint32_t eval_presence_word(const DOp* __restrict__ ops, uint32_t n_ops, const uint32_t* bm, uint32_t ww, uint32_t w,
-                                                       uint32_t* stack /* column of this thread, stride kBlock */) {
-    uint32_t sp = 0;
-    for (uint32_t o = 0; o < n_ops; ++o) {
-        const DOp op = ops[o];
-        uint32_t v;
-        if (op.kind == OP_LEAF) {
-            v = 0;
-            for (uint32_t j = 0; j < op.list_count; ++j) v |= bm[(op.list_begin + j) * ww + w];
-        } else if (op.kind == OP_AND) {
-            v = 0xFFFFFFFFu;
-            for (uint32_t c = 0; c < op.nchild; ++c) v &= stack[(sp - 1 - c) * kBlock];
-            sp -= op.nchild;
-        } else {
-            v = 0;
-            for (uint32_t c = 0; c < op.nchild; ++c) v |= stack[(sp - 1 - c) * kBlock];
-            sp -= op.nchild;
-        }
-        stack[sp * kBlock] = v;
-        ++sp;
+// one posting-list element of the tile scatter
+#define VQ_SCATTER_ELEM(D, IDX)                              \
+    if (!stop && (IDX) >= c0) {                              \
+        if ((IDX) >= len || (D) >= tile_hi) {                \
+            stop = true;                                     \
+            if ((IDX) < len) first_ge = (D);                 \
+        } else {                                             \
+            ++nhi;                                           \
+            if ((D) < tile_lo) ++nlo;                        \
+            else {                                           \
+                const uint32_t rel = (D)-tile_lo;            \
+                atomicOr(&bmi[rel >> 5], 1u << (rel & 31u)); \
+            }                                                \
+        }                                                    \
     }
-    return sp ? stack[0] : 0u;
-}
+
+constexpr int kGroup = 4;  // lists whose first-round loads are issued together
 
 __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                      const uint32_t* __restrict__ span_base, uint32_t nq, uint32_t stack_depth,
-                                                      unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits,
-                                                      uint32_t* __restrict__ hist) {
+                                                      const uint32_t* __restrict__ span_base, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap,
+                                                      uint32_t desc_cap, unsigned long long* __restrict__ span_keys,
+                                                      unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -224,47 +429,66 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         q = lo;
     }
     const uint32_t span = blockIdx.x - span_base[q];
-    const uint8_t* blob = blobs + blob_off[q];
+
+    // ---- stage the query descriptor into LDS: every later phase reads it from there, not from HBM
+    uint32_t* desc = lds + kLdsDesc;
+    {
+        const uint32_t* gblob = reinterpret_cast<const uint32_t*>(blobs + blob_off[q]);
+        const uint32_t n32 = reinterpret_cast<const QHeader*>(gblob)->desc_bytes >> 2;
+        for (uint32_t x = tid; x < n32; x += kBlock) desc[x] = gblob[x];
+    }
+    __syncthreads();
+    const uint8_t* blob = reinterpret_cast<const uint8_t*>(desc);
     const QHeader* H = reinterpret_cast<const QHeader*>(blob);
     const uint32_t L = H->n_lists;
     const uint32_t WW = H->tile_words;
     const uint32_t W = WW << 5;
     const uint32_t top_k = H->top_k;
-    const DList* __restrict__ lists = reinterpret_cast<const DList*>(blob + H->off_lists);
-    const DOp* __restrict__ ops = reinterpret_cast<const DOp*>(blob + H->off_ops);
-    const DOp* __restrict__ fops = reinterpret_cast<const DOp*>(blob + H->off_fops);
-    const DGroup* __restrict__ groups = reinterpret_cast<const DGroup*>(blob + H->off_groups);
-    const DTermBoost* __restrict__ tboosts = reinterpret_cast<const DTermBoost*>(blob + H->off_tboost);
-    const DColBoost* __restrict__ cols = reinterpret_cast<const DColBoost*>(blob + H->off_col);
-    const DLocField* __restrict__ locf = reinterpret_cast<const DLocField*>(blob + H->off_locf);
-    const DFacet* __restrict__ facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
-    const uint32_t n_ops = H->n_ops, n_fops = H->n_fops;
+    const DList* lists = reinterpret_cast<const DList*>(blob + H->off_lists);
+    const DOp* ops = reinterpret_cast<const DOp*>(blob + H->off_ops);
+    const DGroup* groups = reinterpret_cast<const DGroup*>(blob + H->off_groups);
+    const DTermBoost* tboosts = reinterpret_cast<const DTermBoost*>(blob + H->off_tboost);
+    const DColBoost* cols = reinterpret_cast<const DColBoost*>(blob + H->off_col);
+    const DLocField* locf = reinterpret_cast<const DLocField*>(blob + H->off_locf);
+    const DFacet* facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
+    const DPresOp* pres = reinterpret_cast<const DPresOp*>(blob + H->off_pres);
+    const uint16_t* pres_in = reinterpret_cast<const uint16_t*>(blob + H->off_pres_in);
+    const uint32_t n_ops = H->n_ops, n_pres = H->n_pres;
     const uint32_t n_groups = H->n_groups, n_tboost = H->n_tboost, n_col = H->n_col, n_locf = H->n_locf, n_facets = H->n_facets;
 
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kLdsCand);
-    uint32_t* stack = lds + kLdsStack + tid;  // this thread's column
     unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds + kLdsMisc);
     uint32_t* cand_n = lds + kLdsMisc + 2;
-    uint32_t* next_head = lds + kLdsMisc + 3;
-    uint32_t* hits_acc = lds + kLdsMisc + 4;
-    uint32_t* cur = lds + kLdsCur;
+    uint32_t* hits_acc = lds + kLdsMisc + 3;
+    uint32_t* cur2 = lds + kLdsCur;  // [2][kMaxLists]
+    uint32_t* nxt2 = lds + kLdsNxt;  // [2][kMaxLists]
+    uint32_t* nxt_new = lds + kLdsNxtNew;
     uint32_t* cnt_lo = lds + kLdsCntLo;
     uint32_t* cnt_hi = lds + kLdsCntHi;
-    uint32_t* rootw = lds + kLdsStack + stack_depth * kBlock;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kLdsDesc + desc_cap / 4);
+    uint32_t* stack = lds + kLdsDesc + desc_cap / 4 + 2 * cand_cap + tid;  // this thread's column
+    uint32_t* rootw = lds + kLdsDesc + desc_cap / 4 + 2 * cand_cap + stack_depth * kBlock;
     uint32_t* bm = rootw + WW;
-    uint16_t* pre = reinterpret_cast<uint16_t*>(bm + L * WW);
-    CandState cs{cand, cand_n, thr};
+    uint16_t* pre = reinterpret_cast<uint16_t*>(bm + (L + H->n_temps) * WW);
+    CandState cs{cand, cand_n, thr, cand_cap};
 
     // ---- span of the doc-id space owned by this workgroup
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
     const uint32_t span_lo = H->doc_lo + (uint32_t)(range * span / n_spans);
     const uint32_t span_hi = H->doc_lo + (uint32_t)(range * (span + 1) / n_spans);
+    const uint32_t keys_base = H->keys_base;
 
-    // ---- initial cursors: first entry >= span_lo of every list
+    VQ_STAMP_INIT
+    VQ_STAMP_COUNT(8)
+    // ---- initial cursors: first entry >= span_lo of every list, and the doc found there
     for (uint32_t i = wave; i < L; i += kBlock / 64) {
-        uint32_t c = wave_lower_bound(lists[i].docs, lists[i].len, span_lo);
-        if (lane == 0) cur[i] = c;
+        const uint32_t len = lists[i].len;
+        const uint32_t* docs = lists[i].docs;
+        uint32_t c = wave_lower_bound(docs, len, span_lo);
+        if (lane == 0) {
+            cur2[i] = c;
+            nxt2[i] = c < len ? as_global(docs)[c] : 0xFFFFFFFFu;
+        }
     }
     if (tid == 0) {
         *thr = 0ull;
@@ -272,225 +496,238 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         *hits_acc = 0;
     }
     uint32_t my_hits = 0;
+    uint32_t par = 0;  // parity of the cursor buffers
     __syncthreads();
+    VQ_STAMP_AT(0)
 
     while (true) {
-        // ---- P0: next tile = the tile holding the smallest pending doc of the cover lists
-        if (wave == 0) {
-            uint32_t h = 0xFFFFFFFFu;
-            for (uint32_t i = lane; i < L; i += 64) {
-                if (lists[i].flags & LIST_COVER) {
-                    uint32_t c = cur[i];
-                    if (c < lists[i].len) {
-                        uint32_t d = lists[i].docs[c];
-                        h = d < h ? d : h;
-                    }
-                }
+        uint32_t* cur = cur2 + par * kMaxLists;
+        uint32_t* nxt = nxt2 + par * kMaxLists;
+        // ---- P0: next tile = the tile holding the smallest pending doc of the cover lists (LDS only)
+        uint32_t head = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < L; ++i) {
+            if (lists[i].flags & LIST_COVER) {
+                const uint32_t d = nxt[i];
+                head = d < head ? d : head;
             }
-            h = wave_min_u32(h);
-            if (lane == 0) *next_head = h;
         }
-        __syncthreads();
-        const uint32_t head = *next_head;
         if (head >= span_hi) break;  // uniform: span exhausted
         const uint32_t tile_lo = head & ~(W - 1u);
         const uint32_t tile_end = tile_lo + W;  // may wrap to 0 at the top of the id space
         const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
 
-        // ---- P0b: lists outside the cover may be far behind: skip ahead with a wave-wide search
+        // ---- P0b: a list outside the cover that is more than a tile behind skips ahead with a wave-wide search
         for (uint32_t i = wave; i < L; i += kBlock / 64) {
-            const uint32_t c = cur[i];
-            const uint32_t len = lists[i].len;
-            if (c + 256u < len && lists[i].docs[c + 256u] < tile_lo) {  // uniform per wave
-                uint32_t adv = wave_lower_bound(lists[i].docs + c, len - c, tile_lo);
+            const uint32_t d = nxt[i];
+            if (d < tile_lo && tile_lo - d >= W) {  // uniform per wave
+                const uint32_t c = cur[i];
+                uint32_t adv = wave_lower_bound(lists[i].docs + c, lists[i].len - c, tile_lo);
                 if (lane == 0) cur[i] = c + adv;
             }
         }
-        // ---- P1: clear the tile state
-        for (uint32_t x = tid; x < L * WW; x += kBlock) bm[x] = 0u;
+        // ---- P1: clear the tile state (list bitmaps only: every temporary is fully written by its op)
+        for (uint32_t x = tid * 4u; x < L * WW; x += kBlock * 4u) *reinterpret_cast<uint4*>(bm + x) = make_uint4(0u, 0u, 0u, 0u);
         if (tid < L) {
             cnt_lo[tid] = 0u;
             cnt_hi[tid] = 0u;
+            nxt_new[tid] = 0xFFFFFFFFu;
         }
         __syncthreads();
+        VQ_STAMP_AT(1)
+        VQ_STAMP_COUNT(7)
 
-        // ---- P2: stream every list's doc ids of this tile into its bitmap (16 B per lane)
-        for (uint32_t i = 0; i < L; ++i) {
-            const uint32_t c0 = cur[i];
-            const uint32_t len = lists[i].len;
-            const uint4* __restrict__ docs4 = reinterpret_cast<const uint4*>(lists[i].docs);
-            const uint32_t nvec = (len + 3u) >> 2;
-            uint32_t nlo = 0, nhi = 0;
-            uint32_t* bmi = bm + i * WW;
-            for (uint32_t v = (c0 >> 2) + tid; v < nvec; v += kBlock) {
-                const uint4 d4 = docs4[v];
-                const uint32_t base = v << 2;
-                const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
-                bool stop = false;
+        // ---- P2: stream every list's doc ids of this tile into its bitmap.  One wave == one workgroup: each
+        //      round loads 64 x 16 B (1 KiB, coalesced) of a list; how many of those 256 entries belong to the
+        //      tile is counted with wave ballots (the list is sorted: the entries of the tile form a prefix), so
+        //      the cursor bookkeeping needs no atomics.  First rounds of up to kGroup lists are issued together,
+        //      later rounds are prefetched one ahead.
+        const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (uint32_t g0 = 0; g0 < L; g0 += kGroup) {
+            u32x4 first[kGroup];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t idx = base + j;
-                    const uint32_t d = dd[j];
-                    if (idx < c0) continue;
-                    if (idx >= len || d >= tile_hi) {
-                        stop = true;
-                        break;
-                    }
-                    ++nhi;
-                    if (d < tile_lo) {
-                        ++nlo;
-                        continue;
-                    }
-                    const uint32_t rel = d - tile_lo;
-                    atomicOr(&bmi[rel >> 5], 1u << (rel & 31u));
+            for (int j = 0; j < kGroup; ++j) {
+                const uint32_t i = g0 + j;
+                first[j] = kSent;
+                if (i < L) {
+                    const uint32_t v = (cur[i] >> 2) + lane;
+                    if (v < ((lists[i].len + 3u) >> 2)) first[j] = as_global(reinterpret_cast<const u32x4*>(lists[i].docs))[v];
                 }
-                if (stop) break;
             }
-            if (nhi) atomicAdd(&cnt_hi[i], nhi);
-            if (nlo) atomicAdd(&cnt_lo[i], nlo);
+            VQ_STAMP_AT(9)
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const uint32_t i = g0 + j;
+                if (i < L) {  // uniform
+                    const uint32_t c0 = cur[i];
+                    const uint32_t nvec = (lists[i].len + 3u) >> 2;
+                    const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lists[i].docs));
+                    uint32_t* bmi = bm + i * WW;
+                    uint32_t v = (c0 >> 2) + lane;
+                    u32x4 d4 = first[j];
+                    uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
+                    while (true) {  // uniform trip count
+                        const uint32_t vn = v + 64u;
+                        u32x4 nx = kSent;
+                        if (vn < nvec) nx = dptr[vn];  // prefetch the next round
+                        const uint32_t base = v << 2;
+                        // padding and exhausted lanes hold the sentinel 0xFFFFFFFF (>= tile_hi): they stop the list
+                        const bool vx = base >= c0, vy = base + 1u >= c0, vz = base + 2u >= c0, vw = base + 3u >= c0;
+                        const bool ix = vx && d4.x < tile_hi, iy = vy && d4.y < tile_hi, iz = vz && d4.z < tile_hi, iw = vw && d4.w < tile_hi;
+                        total_in += (uint32_t)(__popcll(__ballot(ix)) + __popcll(__ballot(iy)) + __popcll(__ballot(iz)) + __popcll(__ballot(iw)));
+                        const bool lx = ix && d4.x < tile_lo, ly = iy && d4.y < tile_lo, lz = iz && d4.z < tile_lo, lw = iw && d4.w < tile_lo;
+                        if (__ballot(lx || ly || lz || lw))
+                            total_lo += (uint32_t)(__popcll(__ballot(lx)) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
+                        if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+                        if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+                        if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+                        if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+                        const bool sx = vx && !ix, sy = vy && !iy, sz = vz && !iz, sw = vw && !iw;
+                        const unsigned long long stopmask = __ballot(sx || sy || sz || sw);
+                        if (stopmask) {
+                            // first lane that saw an entry >= tile_hi; its first such component is the list's next doc
+                            const uint32_t c = sx ? d4.x : sy ? d4.y : sz ? d4.z : d4.w;
+                            boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(stopmask));
+                            break;
+                        }
+                        d4 = nx;
+                        v = vn;
+                    }
+                    if (lane == 0) {
+                        cnt_hi[i] = total_in;
+                        cnt_lo[i] = total_lo;
+                        nxt_new[i] = boundary;
+                    }
+                }
+            }
+            VQ_STAMP_AT(10)
         }
         __syncthreads();
-
-        // ---- P3: presence program on bitmap words -> root words
-        uint32_t surv = 0;
-        for (uint32_t w = tid; w < WW; w += kBlock) {
-            uint32_t r = eval_presence_word(ops, n_ops, bm, WW, w, stack);
-            if (n_fops) r &= eval_presence_word(fops, n_fops, bm, WW, w, stack);
-            // docs of the tile that lie outside [span_lo, span_hi) can not be set: cursors start at
-            // span_lo and the scatter stops at tile_hi <= span_hi
-            rootw[w] = r;
-            surv += (uint32_t)__popc(r);
+        VQ_STAMP_AT(2)
+        // cursors of the NEXT tile go to the other parity: nobody reads them before the next barrier,
+        // and the score gathers below still see this tile's cursors
+        if (tid < L) {
+            cur2[(par ^ 1u) * kMaxLists + tid] = cur[tid] + cnt_hi[tid];
+            nxt2[(par ^ 1u) * kMaxLists + tid] = nxt_new[tid];
         }
-        const int any = __syncthreads_or(surv != 0);
 
-        if (any) {
-            // ---- P4: rank support for score gathers
-            for (uint32_t i = wave; i < L; i += kBlock / 64)
-                if (lists[i].flags & LIST_HAS_SCORES) wave_prefix_popc(bm + i * WW, pre + i * WW, WW);
-            __syncthreads();
+        // ---- P3: presence program (three-address code over bitmaps; the last op writes the root words).
+        //      A lane owns WPL consecutive words in every op: no synchronisation between ops.
+        const uint32_t WPL = WW >> 6;
+        const uint32_t w0 = lane * WPL;
+        uint32_t surv = 0;
+        for (uint32_t o = 0; o < n_pres; ++o) {
+            const uint32_t kind = pres[o].kind;
+            const uint32_t n_in = pres[o].n_in;
+            const uint16_t* in = pres_in + pres[o].in_begin;
+            const uint32_t out = pres[o].out;
+            uint32_t* dst = (out == kSlotRoot ? rootw : bm + (L + (out & 0x7FFFu)) * WW) + w0;
+            if ((WPL & 3u) == 0) {
+                for (uint32_t k = 0; k < WPL; k += 4) {
+                    uint4 v = kind == PRES_AND ? make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu) : make_uint4(0u, 0u, 0u, 0u);
+                    for (uint32_t c = 0; c < n_in; ++c) {
+                        const uint32_t ref = in[c];
+                        const uint4 x = *reinterpret_cast<const uint4*>(bm + ((ref & kSlotTemp) ? L + (ref & 0x7FFFu) : ref) * WW + w0 + k);
+                        if (kind == PRES_AND) {
+                            v.x &= x.x; v.y &= x.y; v.z &= x.z; v.w &= x.w;
+                        } else {
+                            v.x |= x.x; v.y |= x.y; v.z |= x.z; v.w |= x.w;
+                        }
+                    }
+                    if (kind == PRES_ZERO) v = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(dst + k) = v;
+                    if (out == kSlotRoot) surv += (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+                }
+            } else {
+                for (uint32_t k = 0; k < WPL; ++k) {
+                    uint32_t v = kind == PRES_AND ? 0xFFFFFFFFu : 0u;
+                    for (uint32_t c = 0; c < n_in; ++c) {
+                        const uint32_t ref = in[c];
+                        const uint32_t x = bm[((ref & kSlotTemp) ? L + (ref & 0x7FFFu) : ref) * WW + w0 + k];
+                        v = kind == PRES_AND ? (v & x) : (v | x);
+                    }
+                    if (kind == PRES_ZERO) v = 0u;
+                    dst[k] = v;
+                    if (out == kSlotRoot) surv += (uint32_t)__popc(v);
+                }
+            }
+        }
+        uint32_t S = 0;
+        const uint32_t my_excl = wave_excl_scan_u32(surv, &S);
+        VQ_STAMP_AT(3)
 
-            // ---- P5: score the surviving docs, run the sink stages, feed the top-k
-            uint32_t w = tid;
-            uint32_t r = w < WW ? rootw[w] : 0u;
+        if (S) {  // uniform
+            // ---- P4: rank support for the score gathers: exclusive prefix popcount per posting list
+            for (uint32_t i = 0; i < L; ++i) {
+                if (lists[i].flags & LIST_HAS_SCORES) {
+                    const uint32_t* words = bm + i * WW + w0;
+                    uint32_t local = 0;
+                    for (uint32_t k = 0; k < WPL; ++k) local += (uint32_t)__popc(words[k]);
+                    uint32_t tot;
+                    uint32_t run = wave_excl_scan_u32(local, &tot);
+                    uint16_t* pw = pre + i * WW + w0;
+                    for (uint32_t k = 0; k < WPL; ++k) {
+                        pw[k] = (uint16_t)run;
+                        run += (uint32_t)__popc(words[k]);
+                    }
+                }
+            }
+            // ---- P5: score the surviving docs, run the sink stages, feed the top-k.  Few survivors (AND):
+            //      compact them so that every lane scores at most ceil(S/64); many (OR): each lane walks its own words.
+            const bool compact = S <= kSurvCap;
+            uint16_t* surv_list = reinterpret_cast<uint16_t*>(lds + kLdsSurv);
+            if (compact) {
+                uint32_t pos = my_excl;
+                for (uint32_t k = 0; k < WPL; ++k) {
+                    uint32_t r = rootw[w0 + k];
+                    while (r) {
+                        const uint32_t b = (uint32_t)__ffs((int)r) - 1u;
+                        r &= r - 1u;
+                        surv_list[pos++] = (uint16_t)(((w0 + k) << 5) | b);
+                    }
+                }
+            }
+            __syncthreads();  // one wave: orders the LDS writes above before the reads below
+            VQ_STAMP_AT(4)
+
+            ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, n_locf, facets, n_facets,
+                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist};
+            uint32_t it_a = compact ? lane : 0u;
+            uint32_t it_r = compact ? 0u : rootw[w0];
             bool pending = false;
             unsigned long long pend_key = 0ull;
-            float* fstack = reinterpret_cast<float*>(stack);
             while (true) {
                 while (true) {
                     if (pending) {
                         if (pend_key > *thr) {
                             uint32_t pos = atomicAdd(cand_n, 1u);
-                            if (pos < (uint32_t)kCandCap) {
+                            if (pos < cand_cap) {
                                 cand[pos] = pend_key;
                                 pending = false;
                             } else break;
                         } else pending = false;
                     }
-                    if (r == 0u) {
-                        w += kBlock;
-                        if (w >= WW) break;
-                        r = rootw[w];
-                        continue;
+                    uint32_t w, b;
+                    if (compact) {
+                        if (it_a >= S) break;
+                        const uint32_t code = surv_list[it_a];
+                        it_a += 64u;
+                        w = code >> 5;
+                        b = code & 31u;
+                    } else {
+                        while (it_r == 0u && ++it_a < WPL) it_r = rootw[w0 + it_a];
+                        if (it_r == 0u) break;
+                        b = (uint32_t)__ffs((int)it_r) - 1u;
+                        it_r &= it_r - 1u;
+                        w = w0 + it_a;
                     }
-                    const uint32_t b = (uint32_t)__ffs((int)r) - 1u;
-                    r &= r - 1u;
                     const uint32_t doc = tile_lo + (w << 5) + b;
-                    const uint32_t below = (1u << b) - 1u;
-
-                    // -- score tree (postfix), stack slot = uniform program counter state
-                    uint32_t sp = 0;
-                    uint32_t pmask = 0;  // bit s: stack slot s holds a present value
-                    for (uint32_t o = 0; o < n_ops; ++o) {
-                        const DOp op = ops[o];
-                        float s = 0.0f;
-                        bool present = false;
-                        if (op.kind == OP_LEAF) {
-                            for (uint32_t j = 0; j < op.list_count; ++j) {
-                                const uint32_t li = op.list_begin + j;
-                                const uint32_t word = bm[li * WW + w];
-                                if ((word >> b) & 1u) {
-                                    float v = 0.0f;
-                                    if (lists[li].flags & LIST_HAS_SCORES) {
-                                        const uint32_t rank = (uint32_t)pre[li * WW + w] + (uint32_t)__popc(word & below);
-                                        const uint32_t idx = cur[li] + cnt_lo[li] + rank;
-                                        v = posting_value(lists[li].term_score, lists[li].scores[idx]);
-                                    }
-                                    if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
-                                    present = true;
-                                }
-                            }
-                        } else if (op.kind == OP_AND) {
-                            const uint32_t base = sp - op.nchild;
-                            present = true;
-                            for (uint32_t c = 0; c < op.nchild; ++c) present = present && ((pmask >> (base + c)) & 1u);
-                            if (present) {
-                                s = 0.0f;  // set_op.rs:415-416: others summed first, the shortest list's score last
-                                for (uint32_t c = 0; c < op.nchild; ++c) s += fstack[(base + op.and_order[c]) * kBlock];
-                            }
-                            sp = base;
-                        } else {
-                            const uint32_t base = sp - op.nchild;
-                            float sum = 0.0f;
-                            float nd = 0.0f;
-                            for (uint32_t slot = 0; slot < op.nslots; ++slot) {  // set_op.rs:169-186
-                                float m = 0.0f;
-                                for (uint32_t c = 0; c < op.nchild; ++c) {
-                                    if (op.child_slot[c] == slot && ((pmask >> (base + c)) & 1u)) {
-                                        present = true;
-                                        m = fmaxf(m, fstack[(base + c) * kBlock]);
-                                    }
-                                }
-                                if (m >= 0.00001f) nd += 1.0f;
-                                sum += m;
-                            }
-                            s = sum * nd * nd;
-                            sp = base;
-                        }
-                        fstack[sp * kBlock] = s;
-                        pmask = present ? (pmask | (1u << sp)) : (pmask & ~(1u << sp));
-                        ++sp;
-                    }
-                    float score = fstack[0];
-
-                    // -- sink stages in the reference's order
-                    for (uint32_t c = 0; c < n_col; ++c) score = apply_col_boost(score, cols[c], doc);
-                    for (uint32_t g = 0; g < n_groups; ++g) {
-                        bool in = false;
-                        for (uint32_t j = 0; j < groups[g].list_count; ++j) in = in || ((bm[(groups[g].list_begin + j) * WW + w] >> b) & 1u);
-                        if (in) score *= groups[g].mult;
-                    }
-                    for (uint32_t t = 0; t < n_tboost; ++t)
-                        if ((bm[tboosts[t].list * WW + w] >> b) & 1u) score *= tboosts[t].mult;
-                    if (n_locf) {  // boost.rs:11-87: 2*c*c per field with c > 1, the MINIMUM over fields (:25)
-                        float best = 0.0f;
-                        bool have = false;
-                        for (uint32_t f = 0; f < n_locf; ++f) {
-                            uint32_t c = 0;
-                            for (uint32_t j = 0; j < locf[f].list_count; ++j) c += (bm[(locf[f].list_begin + j) * WW + w] >> b) & 1u;
-                            if (c > 1u) {
-                                float bv = 2.0f * (float)c * (float)c;
-                                if (!have || bv < best) best = bv;
-                                have = true;
-                            }
-                        }
-                        if (have) score *= best;
-                    }
-                    for (uint32_t f = 0; f < n_facets; ++f) {  // persistence.rs:164-175 count_values_for_ids
-                        const DFacet& fa = facets[f];
-                        if (doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
-                            const uint32_t row = doc - fa.key_base;
-                            const unsigned long long e0 = fa.offsets[row], e1 = fa.offsets[row + 1];
-                            for (unsigned long long e = e0; e < e1; ++e) {
-                                const uint32_t v = fa.values[e];
-                                if (v < fa.num_values) atomicAdd(&hist[fa.hist_off + v], 1u);
-                            }
-                        }
-                    }
+                    float score = sc.simple_n ? tree_score_simple(sc, w, b) : tree_score_generic(sc, w, b);
+                    score = sink_stages(sc, score, doc, w, b);
                     ++my_hits;
                     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
                     if (key > *thr) {
                         uint32_t pos = atomicAdd(cand_n, 1u);
-                        if (pos < (uint32_t)kCandCap) cand[pos] = key;
+                        if (pos < cand_cap) cand[pos] = key;
                         else {
                             pending = true;
                             pend_key = key;
@@ -502,23 +739,23 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
                 if (!need) break;
                 cand_prune(cs, top_k);
             }
+            VQ_STAMP_AT(5)
         }
-        // ---- P6: advance the cursors past this tile
-        __syncthreads();
-        if (tid < L) cur[tid] += cnt_hi[tid];
-        // cur[] is next read by wave 0 (P0) — same wave as the writers (L <= 64), LDS is in order
+        par ^= 1u;
     }
 
-    // ---- span done: publish the local top-k and the hit count
+    // ---- span done: publish the local top-k (as a set) and the hit count
     cand_prune(cs, top_k);
     {
         const uint32_t n = *cand_n;
-        unsigned long long* out = span_keys + (size_t)H->keys_base + (size_t)span * top_k;
+        unsigned long long* out = span_keys + (size_t)keys_base + (size_t)span * top_k;
         for (uint32_t i = tid; i < top_k; i += kBlock) out[i] = i < n ? cand[i] : 0ull;
     }
     if (my_hits) atomicAdd(hits_acc, my_hits);
     __syncthreads();
     if (tid == 0 && *hits_acc) atomicAdd(&num_hits[q], (unsigned long long)*hits_acc);
+    VQ_STAMP_AT(6)
+    VQ_STAMP_FLUSH
 }
 
 // ------------------------------------------------------------------------------------ merges
@@ -529,24 +766,26 @@ __global__ __launch_bounds__(kBlock) void k_merge_spans(const uint8_t* __restric
     const QHeader* H = reinterpret_cast<const QHeader*>(blobs + blob_off[blockIdx.x]);
     const uint32_t top_k = H->top_k;
     const unsigned long long* src = span_keys + H->keys_base;
-    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc)};
+    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
     if (threadIdx.x == 0) {
         *cs.thr = 0ull;
         *cs.n = 0;
     }
     __syncthreads();
-    for (uint32_t s = 0; s < H->n_spans; ++s) {
-        if (*cs.n + top_k > (uint32_t)kCandCap) cand_prune(cs, top_k);
+    // rounds: fill the buffer with as many spans as fit next to the kept top_k, prune, continue
+    const uint32_t per_round = ((uint32_t)kCandCap - top_k) / top_k;
+    for (uint32_t s0 = 0; s0 < H->n_spans; s0 += per_round) {
+        const uint32_t cnt = (H->n_spans - s0 < per_round ? H->n_spans - s0 : per_round) * top_k;
         const uint32_t base = *cs.n;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) cand[base + i] = src[(size_t)s * top_k + i];
+        for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) cand[base + i] = src[(size_t)s0 * top_k + i];
         __syncthreads();
-        if (threadIdx.x == 0) *cs.n = base + top_k;
-        __syncthreads();
+        if (threadIdx.x == 0) *cs.n = base + cnt;
+        cand_prune(cs, top_k, true);  // sorted descending: empty slots (0) sink to the end
     }
-    cand_prune(cs, top_k);
     unsigned long long* out = part_keys + H->part_keys_off;
-    for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) out[i] = i < *cs.n ? cand[i] : 0ull;
+    const uint32_t n = *cs.n;
+    for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) out[i] = i < n ? cand[i] : 0ull;
 }
 
 // gathered: num_shards packed partial buffers, shard-major, each `part_bytes` long.
@@ -559,7 +798,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     const uint32_t q = blockIdx.x;
     const QHeader* H = reinterpret_cast<const QHeader*>(blobs + blob_off[q]);
     const uint32_t top_k = H->top_k;
-    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc)};
+    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
     if (threadIdx.x == 0) {
         *cs.thr = 0ull;
         *cs.n = 0;
@@ -570,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
         const uint8_t* pb = gathered + (size_t)s * lay.bytes;
         const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(pb + lay.off_keys) + H->part_keys_off;
         hits += reinterpret_cast<const unsigned long long*>(pb + lay.off_hits)[q];
-        if (*cs.n + top_k > (uint32_t)kCandCap) cand_prune(cs, top_k);
+        if (*cs.n + top_k > (uint32_t)kCandCap) cand_prune(cs, top_k);  // uniform: *cs.n is stable here
         const uint32_t base = *cs.n;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) cand[base + i] = keys[i];
@@ -578,21 +817,18 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
         if (threadIdx.x == 0) *cs.n = base + top_k;
         __syncthreads();
     }
-    cand_prune(cs, top_k);
+    cand_prune(cs, top_k, true);  // final ranking: (score desc, id desc); empty slots (0) last
     const uint32_t n = *cs.n;
-    uint32_t real = 0;
     for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) {
         const unsigned long long k = i < n ? cand[i] : 0ull;
         res_ids[H->part_keys_off + i] = (uint32_t)(k & 0xFFFFFFFFull);
         res_scores[H->part_keys_off + i] = __uint_as_float(unorder_f32((uint32_t)(k >> 32)));
-        if (k != 0ull) ++real;
     }
     // number of real hits in the top-k window = min(total hits, top_k): keys are unique and non-zero
     if (threadIdx.x == 0) {
         res_hits[q] = hits;
         res_n[q] = hits < (unsigned long long)top_k ? (uint32_t)hits : top_k;
     }
-    (void)real;
 }
 
 __global__ void k_hist_reduce(const uint8_t* __restrict__ gathered, uint32_t num_shards, PartialLayout lay, uint32_t* __restrict__ out) {
@@ -611,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
     __shared__ unsigned long long cand[kCandCap];
     __shared__ uint32_t misc[4];
     const FacetJob job = jobs[blockIdx.x];
-    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc)};
+    CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
     if (threadIdx.x == 0) {
         *cs.thr = 0ull;
         *cs.n = 0;
@@ -644,7 +880,7 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
             if (pending && !(key > *cs.thr)) pending = false;
         }
     }
-    cand_prune(cs, k);
+    cand_prune(cs, k, true);
     const uint32_t n = *cs.n;
     for (uint32_t i = threadIdx.x; i < k; i += kBlock) {
         const unsigned long long key = i < n ? cand[i] : 0ull;
@@ -656,9 +892,11 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
 
 // ------------------------------------------------------------------------------------ launchers
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      uint32_t nq, uint32_t stack_depth, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
+                      uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys,
+                      unsigned long long* num_hits, uint32_t* hist) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, nq, stack_depth, span_keys, num_hits, hist);
+    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, nq, stack_depth, cand_cap, desc_cap,
+                       span_keys, num_hits, hist);
 }
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {

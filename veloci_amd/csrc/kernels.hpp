@@ -12,10 +12,10 @@ struct FacetJob {
     uint32_t hist_off, num_values, top, out_off;
 };
 
-size_t tile_scan_lds_bytes(uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth);
+size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap);
 
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      uint32_t nq, uint32_t stack_depth, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
+                      uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys);
 void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const uint8_t* gathered, uint32_t num_shards,
@@ -23,5 +23,9 @@ void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const ui
 void launch_hist_reduce(hipStream_t st, const uint8_t* gathered, uint32_t num_shards, const PartialLayout& lay, uint32_t* out);
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n);
+
+#ifdef VQ_STAMP
+void debug_read_stamps(unsigned long long* out, int reset);
+#endif
 
 }  // namespace vq
