@@ -346,6 +346,11 @@ struct Compiler {
                     h.global_len = ps.global_len[tid];
                     h.flags = LIST_HAS_SCORES;
                     h.term_score = score;
+                    if (!ps.bm_start.empty() && ps.bm_start[tid] >= 0) {
+                        h.flags |= LIST_BITMAP;
+                        h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[tid];
+                        h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[tid];
+                    }
                     uint32_t li = add_list(h);
                     info.cover.push_back(li);
                     info.cover_len += h.len;

@@ -28,15 +28,18 @@ constexpr int kMaxSkipWhen = 4;
 enum ListFlags : uint32_t {
     LIST_HAS_SCORES = 1u,  // posting list: f16 anchor scores, value = term_score * (f16 / 100)
     LIST_COVER = 2u,       // part of the cover set that decides which tiles are visited
+    LIST_BITMAP = 4u,      // a bitmap image of the list exists in HBM (dense lists): tiles are copied, not scattered
 };
 
-struct DList {  // 32 B
+struct DList {  // 48 B
     const uint32_t* docs;    // 16-byte aligned, padded to a multiple of 4 with 0xFFFFFFFF
     const uint16_t* scores;  // f16 bits, same indexing as docs (null for id-only lists)
     uint32_t len;
     uint32_t flags;
     float term_score;        // s_t (search_field.rs:426), request.boost folded in (:359-364)
     uint32_t pad;
+    const uint32_t* bitmap;    // LIST_BITMAP: bit (doc - bitmap_base) set for every doc of the list
+    const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + 2048 * k
 };
 
 enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2 };
@@ -119,8 +122,9 @@ struct QHeader {
     uint32_t blob_bytes;
     uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
+    uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
-    uint32_t pad[2];
+    uint32_t pad[1];
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

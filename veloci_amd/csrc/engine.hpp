@@ -121,6 +121,11 @@ struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segment
     DevBuf docs;                        // u32, lists padded to a multiple of 4 with 0xFFFFFFFF
     DevBuf scores;                      // f16 bits (u16), same indexing
     uint64_t total_padded = 0;
+    // dense lists (>= 1/64 of the shard's docs) also get a bitmap image + a rank directory
+    std::vector<int64_t> bm_start;      // word offset of list t inside `bitmaps`, or -1
+    std::vector<int64_t> rd_start;      // entry offset of list t inside `rank_dir`, or -1
+    DevBuf bitmaps;                     // u32 words; bit (doc - Index::bitmap_base)
+    DevBuf rank_dir;                    // u32: entries below bitmap_base + 2048 * k
 };
 
 struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device images
@@ -194,6 +199,8 @@ struct Profile {
 struct Index {
     int device = 0;
     uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;
+    uint32_t bitmap_base = 0;   // doc id of bit 0 of the list bitmaps: doc_lo rounded down to 65536
+    uint64_t bitmap_words = 0;  // words of one list bitmap
     std::map<std::string, Dictionary> dict;
     std::map<std::string, PostingStore> postings;
     std::map<std::string, KVStore> kv;
@@ -221,6 +228,8 @@ struct HList {
     uint32_t flags = 0;
     float term_score = 0.f;
     uint64_t global_len = 0;
+    const uint32_t* d_bitmap = nullptr;
+    const uint32_t* d_rank_dir = nullptr;
     int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
 };
 

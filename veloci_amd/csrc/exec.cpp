@@ -59,6 +59,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.n_temps = cq.n_temps;
     h.simple_n = cq.simple_n;
+    h.bitmap_base = idx.bitmap_base;
     h.desc_bytes = uint32_t(off);
     if (desc_bytes_out) *desc_bytes_out = off;
     std::vector<size_t> inline_off(cq.inline_lists.size());
@@ -83,6 +84,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         d.len = l.len;
         d.flags = l.flags;
         d.term_score = l.term_score;
+        d.bitmap = l.d_bitmap;
+        d.rank_dir = l.d_rank_dir;
         dl[i] = d;
     }
     if (!cq.ops.empty()) std::memcpy(dst + h.off_ops, cq.ops.data(), cq.ops.size() * sizeof(DOp));

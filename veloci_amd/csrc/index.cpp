@@ -113,6 +113,9 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     VQ_HIP(hipEventCreate(&idx->ev0));
     VQ_HIP(hipEventCreate(&idx->ev1));
     const uint32_t lo = b.doc_lo, hi = b.doc_hi;
+    idx->bitmap_base = lo & ~65535u;
+    // one bitmap covers [bitmap_base, hi) rounded up to 65536 docs, plus one tile of slack for the last tile's copy
+    idx->bitmap_words = ((uint64_t(hi) - idx->bitmap_base + 65535u) / 65536u) * 2048u + 2048u;
 
     for (auto& [path, f] : b.fst) {
         Dictionary d;
@@ -145,6 +148,39 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             while (scores.size() < docs.size()) scores.push_back(0);
         }
         ps.total_padded = docs.size();
+        // ---- bitmap images of the dense lists (reading a tile of a dense list becomes a straight 16 B/lane copy)
+        ps.bm_start.assign(ps.num_tokens, -1);
+        ps.rd_start.assign(ps.num_tokens, -1);
+        {
+            const uint64_t range = uint64_t(hi) - lo;
+            const uint64_t words = idx->bitmap_words, blocks = words / 64;  // rank directory: one entry per 2048 docs
+            std::vector<uint32_t> dense;
+            for (uint32_t t = 0; t < ps.num_tokens; ++t)
+                if (range >= 65536 && uint64_t(ps.len[t]) * 64 >= range) dense.push_back(t);
+            if (!dense.empty()) {
+                std::vector<uint32_t> bits(words * dense.size(), 0u);
+                std::vector<uint32_t> rdir((blocks + 1) * dense.size(), 0u);
+                for (size_t k = 0; k < dense.size(); ++k) {
+                    const uint32_t t = dense[k];
+                    uint32_t* bw = bits.data() + words * k;
+                    uint32_t* rd = rdir.data() + (blocks + 1) * k;
+                    const uint32_t* d = docs.data() + ps.start[t];
+                    for (uint32_t i = 0; i < ps.len[t]; ++i) {
+                        const uint32_t rel = d[i] - idx->bitmap_base;
+                        bw[rel >> 5] |= 1u << (rel & 31u);
+                        rd[(rel >> 11) + 1] += 1;
+                    }
+                    for (uint64_t bl = 1; bl <= blocks; ++bl) rd[bl] += rd[bl - 1];
+                    ps.bm_start[t] = int64_t(words * k);
+                    ps.rd_start[t] = int64_t((blocks + 1) * k);
+                }
+                ps.bitmaps.alloc(bits.size() * 4 + 16);
+                ps.bitmaps.upload(bits.data(), bits.size() * 4);
+                ps.rank_dir.alloc(rdir.size() * 4 + 16);
+                ps.rank_dir.upload(rdir.data(), rdir.size() * 4);
+                idx->device_bytes += ps.bitmaps.bytes + ps.rank_dir.bytes;
+            }
+        }
         ps.docs.alloc(docs.size() * 4 + 16);
         ps.docs.upload(docs.data(), docs.size() * 4);
         ps.scores.alloc(scores.size() * 2 + 16);

@@ -185,15 +185,19 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
 }
 
 // ------------------------------------------------------------------------------------ per-hit scoring
+// wave64 inclusive add-scan with DPP row shifts / row broadcasts (gfx9 family), ~6 VALU instead of 6 LDS permutes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xE, false);  // row_shr:4, banks 1-3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xC, false);  // row_shr:8, banks 2-3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2,3
+    return x;
+}
 __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t x, uint32_t* total) {
-    const uint32_t lane = lane_id();
-    uint32_t incl = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += y;
-    }
-    *total = __shfl(incl, 63, 64);
+    const uint32_t incl = wave_incl_scan_u32(x);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     return incl - x;
 }
 
@@ -474,8 +478,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     // ---- span of the doc-id space owned by this workgroup
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
-    const uint32_t span_lo = H->doc_lo + (uint32_t)(range * span / n_spans);
-    const uint32_t span_hi = H->doc_lo + (uint32_t)(range * (span + 1) / n_spans);
+    // span boundaries sit on tile boundaries (multiples of W), so a tile never straddles two workgroups
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(W - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(W - 1u));
+    const uint32_t bitmap_base = H->bitmap_base;
     const uint32_t keys_base = H->keys_base;
 
     VQ_STAMP_INIT
@@ -515,6 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         const uint32_t tile_lo = head & ~(W - 1u);
         const uint32_t tile_end = tile_lo + W;  // may wrap to 0 at the top of the id space
         const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
+        const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;  // entries below it are not this tile's
 
         // ---- P0b: a list outside the cover that is more than a tile behind skips ahead with a wave-wide search
         for (uint32_t i = wave; i < L; i += kBlock / 64) {
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             for (int j = 0; j < kGroup; ++j) {
                 const uint32_t i = g0 + j;
                 first[j] = kSent;
-                if (i < L) {
+                if (i < L && (lists[i].flags & (LIST_BITMAP | LIST_COVER)) != LIST_BITMAP) {
                     const uint32_t v = (cur[i] >> 2) + lane;
                     if (v < ((lists[i].len + 3u) >> 2)) first[j] = as_global(reinterpret_cast<const u32x4*>(lists[i].docs))[v];
                 }
@@ -557,44 +564,93 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
                 const uint32_t i = g0 + j;
-                if (i < L) {  // uniform
-                    const uint32_t c0 = cur[i];
+                if (i < L && (lists[i].flags & (LIST_BITMAP | LIST_COVER)) == LIST_BITMAP) {  // uniform
+                    // dense list with a bitmap image in HBM: the tile is a straight 16 B/lane copy, ranks come
+                    // from the rank directory (tiles are aligned to W >= 2048 docs)
+                    const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(lists[i].bitmap + ((tile_lo - bitmap_base) >> 5)));
+                    for (uint32_t k = lane; k < (WW >> 2); k += 64u) reinterpret_cast<u32x4*>(bm + i * WW)[k] = gb[k];
+                    if (lane == 0) {
+                        cur[i] = as_global(lists[i].rank_dir)[(tile_lo - bitmap_base) >> 11];
+                        cnt_hi[i] = 0;
+                        cnt_lo[i] = 0;
+                        nxt_new[i] = 0xFFFFFFFFu;
+                    }
+                } else if (i < L) {  // uniform
+                    // Entries before the cursor inside its 16-byte vector are < lo_bound (already consumed, or
+                    // below this span), so counting from the vector-aligned cursor keeps every index consistent:
+                    //   next cursor = c0v + total_in,  first in-tile entry = c0v + total_lo.
+                    const uint32_t c0v = cur[i] & ~3u;
                     const uint32_t nvec = (lists[i].len + 3u) >> 2;
                     const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lists[i].docs));
                     uint32_t* bmi = bm + i * WW;
-                    uint32_t v = (c0 >> 2) + lane;
+                    uint32_t v = (c0v >> 2) + lane;
                     u32x4 d4 = first[j];
                     uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
                     while (true) {  // uniform trip count
                         const uint32_t vn = v + 64u;
                         u32x4 nx = kSent;
                         if (vn < nvec) nx = dptr[vn];  // prefetch the next round
-                        const uint32_t base = v << 2;
-                        // padding and exhausted lanes hold the sentinel 0xFFFFFFFF (>= tile_hi): they stop the list
-                        const bool vx = base >= c0, vy = base + 1u >= c0, vz = base + 2u >= c0, vw = base + 3u >= c0;
-                        const bool ix = vx && d4.x < tile_hi, iy = vy && d4.y < tile_hi, iz = vz && d4.z < tile_hi, iw = vw && d4.w < tile_hi;
-                        total_in += (uint32_t)(__popcll(__ballot(ix)) + __popcll(__ballot(iy)) + __popcll(__ballot(iz)) + __popcll(__ballot(iw)));
-                        const bool lx = ix && d4.x < tile_lo, ly = iy && d4.y < tile_lo, lz = iz && d4.z < tile_lo, lw = iw && d4.w < tile_lo;
-                        if (__ballot(lx || ly || lz || lw))
-                            total_lo += (uint32_t)(__popcll(__ballot(lx)) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
-                        if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
-                        if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
-                        if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
-                        if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
-                        const bool sx = vx && !ix, sy = vy && !iy, sz = vz && !iz, sw = vw && !iw;
-                        const unsigned long long stopmask = __ballot(sx || sy || sz || sw);
-                        if (stopmask) {
-                            // first lane that saw an entry >= tile_hi; its first such component is the list's next doc
-                            const uint32_t c = sx ? d4.x : sy ? d4.y : sz ? d4.z : d4.w;
-                            boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)__builtin_ctzll(stopmask));
+                        // padding and exhausted lanes hold the sentinel 0xFFFFFFFF (>= tile_hi): they end the list.
+                        // The list is sorted: the in-tile entries of this round are a prefix in (lane, component) order.
+                        const bool ix = d4.x < tile_hi, iy = d4.y < tile_hi, iz = d4.z < tile_hi, iw = d4.w < tile_hi;
+                        const uint32_t mine = (uint32_t)ix + (uint32_t)iy + (uint32_t)iz + (uint32_t)iw;
+                        const uint32_t full = (uint32_t)__popcll(__ballot(iw));  // lanes with all four entries inside
+                        uint32_t n_in = full << 2;
+                        if (full < 64u) n_in += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)full);
+                        total_in += n_in;
+                        const unsigned long long lom = __ballot(d4.x < lo_bound);
+                        if (lom) {  // rare: entries in front of the tile (a list that lags behind, or the span start)
+                            const bool lx = d4.x < lo_bound, ly = d4.y < lo_bound, lz = d4.z < lo_bound, lw = d4.w < lo_bound;
+                            total_lo += (uint32_t)(__popcll(lom) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
+                            if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+                            if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+                            if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+                            if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+                        } else if (ix) {
+                            // merge the bits of entries that share a bitmap word: one LDS atomic per distinct word
+                            uint32_t wi = (d4.x - tile_lo) >> 5;
+                            uint32_t m = 1u << ((d4.x - tile_lo) & 31u);
+                            if (iy) {
+                                const uint32_t w2 = (d4.y - tile_lo) >> 5, b2 = 1u << ((d4.y - tile_lo) & 31u);
+                                if (w2 == wi) m |= b2;
+                                else {
+                                    atomicOr(&bmi[wi], m);
+                                    wi = w2;
+                                    m = b2;
+                                }
+                            }
+                            if (iz) {
+                                const uint32_t w2 = (d4.z - tile_lo) >> 5, b2 = 1u << ((d4.z - tile_lo) & 31u);
+                                if (w2 == wi) m |= b2;
+                                else {
+                                    atomicOr(&bmi[wi], m);
+                                    wi = w2;
+                                    m = b2;
+                                }
+                            }
+                            if (iw) {
+                                const uint32_t w2 = (d4.w - tile_lo) >> 5, b2 = 1u << ((d4.w - tile_lo) & 31u);
+                                if (w2 == wi) m |= b2;
+                                else {
+                                    atomicOr(&bmi[wi], m);
+                                    wi = w2;
+                                    m = b2;
+                                }
+                            }
+                            atomicOr(&bmi[wi], m);
+                        }
+                        if (full < 64u) {
+                            // lane `full` holds the first entry >= tile_hi: component index == its in-tile count
+                            const uint32_t c = mine == 0 ? d4.x : mine == 1 ? d4.y : mine == 2 ? d4.z : d4.w;
+                            boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)full);
                             break;
                         }
                         d4 = nx;
                         v = vn;
                     }
                     if (lane == 0) {
-                        cnt_hi[i] = total_in;
-                        cnt_lo[i] = total_lo;
+                        cnt_hi[i] = total_in - (cur[i] & 3u);  // cursor advance
+                        cnt_lo[i] = total_lo - (cur[i] & 3u);  // entries between the cursor and the first in-tile entry
                         nxt_new[i] = boundary;
                     }
                 }
