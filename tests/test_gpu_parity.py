@@ -240,3 +240,17 @@ def test_two_shards_merge_equals_unsharded(corpus):
     p1.merge(None, 1)  # releases the shard's workspace
     for r, got in zip(reqs, res):
         assert_same(r, got, ora.search_json(json.dumps(r)))
+
+
+def test_generic_kernel_also_matches_for_simple_queries():
+    """Pure simple queries normally run on k_scan_simple; force them through the generic k_tile_scan in a
+    child process (the switch is read once per process) and re-run the parity tests that cover them."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VQ_FORCE_GENERIC="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -730,6 +730,28 @@ struct Compiler {
             }
         }
 
+        {  // pure simple queries run on k_scan_simple (fixed 8192-doc tiles)
+            static const bool force_generic = std::getenv("VQ_FORCE_GENERIC") != nullptr;
+            const bool pure = cq.simple_n && cq.fops.empty() && cq.groups.empty() && cq.tboosts.empty() && cq.cols.empty() && cq.locf.empty() &&
+                              cq.facets.empty() && uint64_t(idx.doc_hi) - idx.doc_lo >= 65536;
+            if (pure && !force_generic) {
+                uint32_t f = 1u << 17;
+                bool seq = false;
+                for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                    const HList& l = cq.lists[cq.ops[k].list_begin];
+                    if ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP)) seq = true;
+                }
+                if (seq) f |= 1u << 16;
+                for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                    const HList& l = cq.lists[cq.ops[k].list_begin];
+                    const bool cover = l.flags & LIST_COVER;
+                    if (cover) f |= 1u << (8 + k);
+                    if ((l.flags & LIST_BITMAP) && (seq || !cover)) f |= 1u << k;
+                }
+                cq.simple_flags = f;
+            }
+        }
+
         // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
         const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
@@ -759,6 +781,7 @@ struct Compiler {
             const uint64_t want = std::max<uint64_t>(range / cover_len, 2048);
             while (ww > 64 && (uint64_t(ww) << 5) / 2 >= want) ww >>= 1;
         }
+        if (cq.simple_flags) ww = 256;
         cq.tile_words = ww;
         cq.stack_depth = std::max<uint32_t>(max_depth, 1);
         uint64_t spans = (cq.total_len + span_postings - 1) / span_postings;

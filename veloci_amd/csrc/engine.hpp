@@ -250,6 +250,7 @@ struct CompiledQuery {
     std::vector<uint16_t> pres_in;
     uint32_t n_temps = 0;
     uint32_t simple_n = 0;
+    uint32_t simple_flags = 0;
     std::vector<DGroup> groups;
     std::vector<DTermBoost> tboosts;
     std::vector<DColBoost> cols;

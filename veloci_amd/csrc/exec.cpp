@@ -60,6 +60,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.n_temps = cq.n_temps;
     h.simple_n = cq.simple_n;
     h.bitmap_base = idx.bitmap_base;
+    h.simple_flags = cq.simple_flags;
     h.desc_bytes = uint32_t(off);
     if (desc_bytes_out) *desc_bytes_out = off;
     std::vector<size_t> inline_off(cq.inline_lists.size());
@@ -190,13 +191,20 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
 
     // ---- upload area: [blobs][blob_off][span_base][facet jobs]
     const size_t up_blob_off = align_up(blob_bytes, 256);
-    const size_t up_span_base = up_blob_off + align_up(size_t(nq + 1) * 4, 256);
-    const size_t up_jobs = up_span_base + align_up(size_t(nq + 1) * 4, 256);
+    // two scan launches: pure simple queries (k_scan_simple) and everything else (k_tile_scan); each has its own
+    // span table (prefix sums of n_spans over its queries) and a map from its local query index to the blob slot
+    const size_t tbl = align_up(size_t(nq + 1) * 4, 256);
+    const size_t up_span_base = up_blob_off + tbl;   // generic: span_base_g
+    const size_t up_qmap_g = up_span_base + tbl;
+    const size_t up_span_s = up_qmap_g + tbl;
+    const size_t up_qmap_s = up_span_s + tbl;
+    const size_t up_jobs = up_qmap_s + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
     uint8_t* hup = ws.h_up.as<uint8_t>();
     uint8_t* dup = ws.d_up.as<uint8_t>();
+    uint32_t n_simple = 0, n_generic = 0, spans_simple = 0, spans_generic = 0;
     {
         size_t off = 0;
         uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
@@ -209,7 +217,30 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             ++qi;
         }
         hbo[nq] = uint32_t(off);
-        std::memcpy(hup + up_span_base, span_base.data(), span_base.size() * 4);
+        uint32_t* sg = reinterpret_cast<uint32_t*>(hup + up_span_base);
+        uint32_t* mg = reinterpret_cast<uint32_t*>(hup + up_qmap_g);
+        uint32_t* ss = reinterpret_cast<uint32_t*>(hup + up_span_s);
+        uint32_t* ms = reinterpret_cast<uint32_t*>(hup + up_qmap_s);
+        uint32_t accg = 0, accs = 0;
+        qi = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const CompiledQuery& cq = pb->queries[i];
+            if (cq.status != 0) continue;
+            if (cq.simple_flags) {
+                ss[n_simple] = accs;
+                ms[n_simple++] = qi;
+                accs += cq.n_spans;
+            } else {
+                sg[n_generic] = accg;
+                mg[n_generic++] = qi;
+                accg += cq.n_spans;
+            }
+            ++qi;
+        }
+        sg[n_generic] = accg;
+        ss[n_simple] = accs;
+        spans_generic = accg;
+        spans_simple = accs;
         if (!jobs.empty()) std::memcpy(hup + up_jobs, jobs.data(), jobs.size() * sizeof(FacetJob));
     }
     pb->d_blobs = dup;
@@ -239,12 +270,17 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t cand_cap = 256;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
     while (cand_cap < 2 * max_top_k) cand_cap <<= 1;
     for (size_t i = 0; i < n; ++i)
-        if (pb->queries[i].status == 0)
+        if (pb->queries[i].status == 0 && !pb->queries[i].simple_flags)
             lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(idx.ev0, st));
-    launch_tile_scan(st, pb->total_spans, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, nq, stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
+    launch_scan_simple(st, spans_simple, scan_simple_lds_bytes(cand_cap), pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+                       reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+    VQ_HIP(hipGetLastError());
+    launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, reinterpret_cast<const uint32_t*>(dup + up_qmap_g), n_generic,
+                     stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     if (pb->profiled) {
         VQ_HIP(hipEventRecord(idx.ev1, st));

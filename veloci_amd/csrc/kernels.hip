@@ -412,8 +412,9 @@ size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_w
 constexpr int kGroup = 4;  // lists whose first-round loads are issued together
 
 __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                      const uint32_t* __restrict__ span_base, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap,
-                                                      uint32_t desc_cap, unsigned long long* __restrict__ span_keys,
+                                                      const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                      uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap,
+                                                      unsigned long long* __restrict__ span_keys,
                                                       unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -432,7 +433,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         }
         q = lo;
     }
-    const uint32_t span = blockIdx.x - span_base[q];
+    const uint32_t ql = q;
+    q = qmap[ql];
+    const uint32_t span = blockIdx.x - span_base[ql];
 
     // ---- stage the query descriptor into LDS: every later phase reads it from there, not from HBM
     uint32_t* desc = lds + kLdsDesc;
@@ -948,11 +951,11 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
 
 // ------------------------------------------------------------------------------------ launchers
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys,
+                      const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys,
                       unsigned long long* num_hits, uint32_t* hist) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, nq, stack_depth, cand_cap, desc_cap,
-                       span_keys, num_hits, hist);
+    hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, stack_depth, cand_cap,
+                       desc_cap, span_keys, num_hits, hist);
 }
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {
@@ -974,6 +977,368 @@ void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, 
                          uint32_t* out_n) {
     if (!n_jobs) return;
     hipLaunchKernelGGL(k_facet_select, dim3(n_jobs), dim3(kBlock), 0, st, jobs, hist, out_vals, out_counts, out_n);
+}
+
+}  // namespace vq
+
+// ====================================================================================================
+// k_scan_simple — the scan for "pure simple" queries: 1..4 single-list posting leaves under one AND / OR
+// (or a single leaf), no filter and no sink stages.  This is the shape of the headline workloads
+// (single-term scan, 3-term AND, 3-term OR), so it gets its own kernel with everything that does not
+// change from tile to tile in registers:
+//   * fixed tile of 8192 docs: every lane owns 4 consecutive bitmap words (one 16-byte vector)
+//   * dense lists are read as bitmap words straight from HBM into registers (no LDS round trip);
+//     sparse lists are scattered into an LDS bitmap with the ballot-counted cursor logic
+//   * presence = register AND/OR of the word vectors; ranks = lane-local popcounts + one DPP scan per list
+//   * survivors are appended to an LDS queue and scored 64 at a time: all score gathers of a flush are
+//     in flight together (an AND tile usually has far fewer than 64 survivors)
+// Same results as k_tile_scan bit for bit (tests run every simple query through both kernels).
+// ====================================================================================================
+namespace vq {
+
+constexpr uint32_t kSW = 8192;   // docs per tile
+constexpr uint32_t kSWW = 256;   // bitmap words per tile
+constexpr uint32_t kQCap = 128;  // survivor queue entries
+// LDS map (u32): misc[8] | qdoc[kQCap] | qidx[4][kQCap] | cand[2*cand_cap] | bm[4][kSWW]
+constexpr uint32_t kSLdsQDoc = 8;
+constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
+constexpr uint32_t kSLdsCand = kSLdsQIdx + 4 * kQCap;
+
+size_t scan_simple_lds_bytes(uint32_t cand_cap) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW) * 4 + 16; }
+
+struct SimpleLeaf {
+    const uint32_t* docs;
+    const uint16_t* scores;
+    const uint32_t* bitmap;
+    const uint32_t* rank_dir;
+    uint32_t len;
+    float ts;
+};
+
+__device__ __forceinline__ uint32_t popc4(const u32x4& v) { return (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w)); }
+__device__ __forceinline__ uint32_t comp4(const u32x4& v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+// Score queue entries [0, count) (count <= 64), push the keys into the candidate buffer.
+__device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const SimpleLeaf (&lf)[4], const uint8_t (&order)[4], const uint8_t (&slot)[4],
+                             uint32_t nslots, const uint32_t* qdoc, const uint32_t* qidx, const CandState& cs, uint32_t top_k) {
+    const uint32_t lane = threadIdx.x;
+    const bool have = lane < count;
+    uint32_t doc = 0;
+    uint32_t idx[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (have) {
+        doc = qdoc[lane];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n) idx[k] = qidx[k * kQCap + lane];
+    }
+    uint16_t raw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n && idx[k] != 0xFFFFFFFFu) raw[k] = as_global(lf[k].scores)[idx[k]];
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) val[k] = posting_value(lf[k].ts, raw[k]);
+    float score;
+    if (n == 1) score = val[0];
+    else if (kind == OP_AND) {  // set_op.rs:415-416: others summed first, the shortest list's score last
+        score = 0.0f;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n) score += pick4(val[0], val[1], val[2], val[3], order[k]);
+    } else {  // set_op.rs:169-186
+        float sum = 0.0f, nd = 0.0f;
+        for (uint32_t s = 0; s < nslots; ++s) {
+            float m = 0.0f;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < n && slot[k] == s && idx[k] != 0xFFFFFFFFu) m = fmaxf(m, val[k]);
+            if (m >= 0.00001f) nd += 1.0f;
+            sum += m;
+        }
+        score = sum * nd * nd;
+    }
+    const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+    bool pending = have && key > *cs.thr;
+    while (true) {
+        if (pending) {
+            if (key > *cs.thr) {
+                uint32_t pos = atomicAdd(cs.n, 1u);
+                if (pos < cs.cap) {
+                    cs.cand[pos] = key;
+                    pending = false;
+                }
+            } else pending = false;
+        }
+        const int need = __syncthreads_or(pending ? 1 : 0);
+        if (!need) break;
+        cand_prune(cs, top_k);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                    const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                    uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
+                                                    unsigned long long* __restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t ql;
+    {
+        uint32_t lo = 0, hi = nq;
+        const uint32_t wg = blockIdx.x;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (span_base[mid] <= wg) lo = mid;
+            else hi = mid;
+        }
+        ql = lo;
+    }
+    const uint32_t span = blockIdx.x - span_base[ql];
+    const uint32_t q = qmap[ql];
+    const uint8_t* blob = blobs + blob_off[q];
+    const QHeader* H = reinterpret_cast<const QHeader*>(blob);
+    const uint32_t n = H->simple_n;
+    const uint32_t sflags = H->simple_flags;
+    const uint32_t top_k = H->top_k;
+    const DList* gl = reinterpret_cast<const DList*>(blob + H->off_lists);
+    const DOp* gops = reinterpret_cast<const DOp*>(blob + H->off_ops);
+    const bool seq = (sflags >> 16) & 1u;
+
+    SimpleLeaf lf[4];
+    uint8_t order[4] = {0, 1, 2, 3}, slot[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        lf[k] = SimpleLeaf{nullptr, nullptr, nullptr, nullptr, 0u, 0.f};
+        if (k < n) {
+            const DList& d = gl[gops[k].list_begin];
+            lf[k] = SimpleLeaf{d.docs, d.scores, d.bitmap, d.rank_dir, d.len, d.term_score};
+        }
+    }
+    uint32_t kind = OP_LEAF, nslots = 1;
+    if (n > 1) {
+        kind = gops[n].kind;
+        nslots = gops[n].nslots;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            order[k] = gops[n].and_order[k];
+            slot[k] = gops[n].child_slot[k];
+        }
+    }
+
+    unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t* cand_n = lds + 2;
+    uint32_t* qdoc = lds + kSLdsQDoc;
+    uint32_t* qidx = lds + kSLdsQIdx;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kSLdsCand);
+    uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [4][kSWW]
+    CandState cs{cand, cand_n, thr, cand_cap};
+
+    const uint32_t n_spans = H->n_spans;
+    const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(kSW - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(kSW - 1u));
+    const uint32_t bitmap_base = H->bitmap_base;
+    const uint32_t keys_base = H->keys_base;
+
+    // cursors of the id (scattered) lists
+    uint32_t cur[4] = {0, 0, 0, 0}, nxt[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k < n && !((sflags >> k) & 1u)) {
+            cur[k] = wave_lower_bound(lf[k].docs, lf[k].len, span_lo);
+            nxt[k] = cur[k] < lf[k].len ? as_global(lf[k].docs)[cur[k]] : 0xFFFFFFFFu;
+        }
+    }
+    if (lane == 0) {
+        *thr = 0ull;
+        *cand_n = 0;
+    }
+    __syncthreads();
+    uint32_t qlen = 0;
+    unsigned long long hits = 0;
+    uint32_t pos = span_lo;  // sequential mode: next doc to cover
+    const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const u32x4 kZero = u32x4{0u, 0u, 0u, 0u};
+
+    while (true) {
+        uint32_t head = 0xFFFFFFFFu;
+        if (seq) head = pos;
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < n && ((sflags >> (8 + k)) & 1u)) head = nxt[k] < head ? nxt[k] : head;
+        }
+        if (head >= span_hi) break;
+        const uint32_t tile_lo = head & ~(kSW - 1u);
+        const uint32_t tile_end = tile_lo + kSW;
+        const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
+        const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
+        pos = tile_end > tile_lo ? tile_end : 0xFFFFFFFFu;
+
+        // issue every first load of the tile: bitmap words (+ rank directory entry) or the first id vector
+        u32x4 wk[4];
+        uint32_t base_idx[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            wk[k] = kZero;
+            if (k < n) {
+                if ((sflags >> k) & 1u) {
+                    wk[k] = as_global(reinterpret_cast<const u32x4*>(lf[k].bitmap + ((tile_lo - bitmap_base) >> 5)))[lane];
+                    base_idx[k] = as_global(lf[k].rank_dir)[(tile_lo - bitmap_base) >> 11];
+                } else {
+                    // a list outside the cover that fell more than a tile behind skips ahead first
+                    if (nxt[k] < tile_lo && tile_lo - nxt[k] >= kSW) cur[k] += wave_lower_bound(lf[k].docs + cur[k], lf[k].len - cur[k], tile_lo);
+                    const uint32_t v = (cur[k] >> 2) + lane;
+                    wk[k] = v < ((lf[k].len + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(lf[k].docs))[v] : kSent;
+                    reinterpret_cast<u32x4*>(bml + k * kSWW)[lane] = kZero;
+                }
+            }
+        }
+        // scatter the id lists (rounds of 64 x 16 B, counted with ballots; see k_tile_scan P2)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k < n && !((sflags >> k) & 1u)) {
+                const uint32_t c0v = cur[k] & ~3u;
+                const uint32_t nvec = (lf[k].len + 3u) >> 2;
+                const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lf[k].docs));
+                uint32_t* bmi = bml + k * kSWW;
+                uint32_t v = (c0v >> 2) + lane;
+                u32x4 d4 = wk[k];
+                uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
+                while (true) {
+                    const uint32_t vn = v + 64u;
+                    u32x4 nx = kSent;
+                    if (vn < nvec) nx = dptr[vn];
+                    const bool ix = d4.x < tile_hi, iy = d4.y < tile_hi, iz = d4.z < tile_hi, iw = d4.w < tile_hi;
+                    const uint32_t mine = (uint32_t)ix + (uint32_t)iy + (uint32_t)iz + (uint32_t)iw;
+                    const uint32_t full = (uint32_t)__popcll(__ballot(iw));
+                    uint32_t n_in = full << 2;
+                    if (full < 64u) n_in += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)full);
+                    total_in += n_in;
+                    const unsigned long long lom = __ballot(d4.x < lo_bound);
+                    if (lom) {
+                        const bool lx = d4.x < lo_bound, ly = d4.y < lo_bound, lz = d4.z < lo_bound, lw = d4.w < lo_bound;
+                        total_lo += (uint32_t)(__popcll(lom) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
+                        if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+                        if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+                        if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+                        if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+                    } else {
+                        if (ix) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+                        if (iy) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+                        if (iz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+                        if (iw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+                    }
+                    if (full < 64u) {
+                        const uint32_t c = mine == 0 ? d4.x : mine == 1 ? d4.y : mine == 2 ? d4.z : d4.w;
+                        boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)full);
+                        break;
+                    }
+                    d4 = nx;
+                    v = vn;
+                }
+                base_idx[k] = c0v + total_lo;  // index of the first in-tile entry
+                cur[k] = c0v + total_in;
+                nxt[k] = boundary;
+            }
+        }
+        __syncthreads();  // one wave: LDS atomics above are ordered before the reads below
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n && !((sflags >> k) & 1u)) wk[k] = reinterpret_cast<const u32x4*>(bml + k * kSWW)[lane];
+
+        // presence of the root
+        u32x4 r = wk[0];
+        if (kind == OP_AND) {
+#pragma unroll
+            for (uint32_t k = 1; k < 4; ++k)
+                if (k < n) r &= wk[k];
+        } else if (kind == OP_OR) {
+#pragma unroll
+            for (uint32_t k = 1; k < 4; ++k)
+                if (k < n) r |= wk[k];
+        }
+        uint32_t S;
+        (void)wave_excl_scan_u32(popc4(r), &S);
+        if (S) {  // uniform
+            hits += S;
+            // rank of each list at this lane's first word
+            uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < n) {
+                    uint32_t tot;
+                    run[k] = base_idx[k] + wave_excl_scan_u32(popc4(wk[k]), &tot);
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                uint32_t rw = comp4(r, j);
+                const uint32_t wdoc = tile_lo + (((lane << 2) + j) << 5);
+                while (true) {  // uniform
+                    const bool has = rw != 0u;
+                    const unsigned long long mask = __ballot(has);
+                    if (!mask) break;
+                    if (has) {
+                        const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
+                        rw &= rw - 1u;
+                        const uint32_t below = (1u << b) - 1u;
+                        const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        qdoc[p] = wdoc + b;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            if (k < n) {
+                                const uint32_t word = comp4(wk[k], j);
+                                qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
+                            }
+                        }
+                    }
+                    qlen += (uint32_t)__popcll(mask);
+                    if (qlen >= 64u) {  // uniform
+                        __syncthreads();
+                        simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+                        // move the remainder to the front
+                        const uint32_t rem = qlen - 64u;
+                        uint32_t td = 0, ti[4] = {0, 0, 0, 0};
+                        if (lane < rem) {
+                            td = qdoc[64u + lane];
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                if (k < n) ti[k] = qidx[k * kQCap + 64u + lane];
+                        }
+                        __syncthreads();
+                        if (lane < rem) {
+                            qdoc[lane] = td;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                if (k < n) qidx[k * kQCap + lane] = ti[k];
+                        }
+                        __syncthreads();
+                        qlen = rem;
+                    }
+                }
+                // ranks move on past this word
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (k < n) run[k] += (uint32_t)__popc(comp4(wk[k], j));
+            }
+        }
+    }
+    __syncthreads();
+    if (qlen) simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+    cand_prune(cs, top_k);
+    {
+        const uint32_t cn = *cand_n;
+        unsigned long long* out = span_keys + (size_t)keys_base + (size_t)span * top_k;
+        for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
+    }
+    if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
+}
+
+void launch_scan_simple(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+    if (!total_spans) return;
+    hipLaunchKernelGGL(k_scan_simple, dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
 }
 
 }  // namespace vq
