@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="and", choices=["and", "or", "single"], help="and = the headline metric; or / single = extra shapes")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency loop (profiling runs)")
     args = ap.parse_args()
@@ -78,7 +79,12 @@ def main():
     if rank == 0:
         log(f"docs={args.docs} shard=[{lo},{hi}) postings/shard={postings} gen={t_gen:.1f}s load={t_load:.1f}s hbm={index.device_bytes / 1e9:.2f} GB")
 
-    reqs_json = [synth.req_and(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
+    if args.workload == "and":
+        reqs_json = [synth.req_and(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
+    elif args.workload == "or":
+        reqs_json = [synth.req_or(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
+    else:
+        reqs_json = [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(args.batch)]
     reqs = [veloci_amd.Request(r) for r in reqs_json]
     searcher = vdist.ShardedSearcher(index) if world > 1 else None
 
@@ -136,11 +142,12 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 doc ids + f16->f32 scores", "data": "synthetic",
-            "config": {"workload": f"{args.docs}-doc synthetic index, 3-term AND (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
+            "config": {"workload": f"{args.docs}-doc synthetic index, " + {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan"}[args.workload] +
+                       f" (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},
             "p50_latency_ms_single_query": round(p50, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_tile_scan", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_scan_simple", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches)},
         }

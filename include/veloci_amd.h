@@ -169,6 +169,13 @@ int vq_search_json(const vq_index*, const char* json, size_t len, vq_result** ou
 int vq_search_batch(const vq_index*, const vq_request* const* requests, size_t n,
                     vq_result** out, int* status);
 
+/* Same batch, flat output without per-result objects (facets are not reported through this entry):
+ * request i's hits go to ids/scores[i * stride .. i * stride + counts[i]).  `stride` must be >= the
+ * largest `top` of the batch. */
+int vq_search_batch_flat(const vq_index*, const vq_request* const* requests, size_t n, size_t stride,
+                         uint64_t* num_hits /* [n] */, uint32_t* counts /* [n] */,
+                         uint32_t* ids /* [n*stride] */, float* scores /* [n*stride] */, int* status /* [n] */);
+
 /* ------------------------------------------------- shard-partial interface
  *
  * New surface (the reference has no sharding): a shard returns

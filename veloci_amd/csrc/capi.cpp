@@ -282,6 +282,35 @@ int vq_search_batch(const vq_index* index, const vq_request* const* requests, si
     });
 }
 
+int vq_search_batch_flat(const vq_index* index, const vq_request* const* requests, size_t n, size_t stride, uint64_t* num_hits, uint32_t* counts,
+                         uint32_t* ids, float* scores, int* status) {
+    return guard([&] {
+        if (!index || (n && (!requests || !num_hits || !counts || !ids || !scores))) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_flat: null argument");
+        std::vector<const Request*> reqs(n);
+        for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
+        auto pb = run_partial(*index->idx, reqs.data(), n);
+        std::vector<std::unique_ptr<Result>> results;
+        std::vector<int> st;
+        std::vector<std::string> errs;
+        finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
+        for (size_t i = 0; i < n; ++i) {
+            if (status) status[i] = st[i];
+            num_hits[i] = 0;
+            counts[i] = 0;
+            if (st[i] != 0) {
+                if (g_err.empty()) g_err = errs[i];
+                continue;
+            }
+            const Result& r = *results[i];
+            if (r.ids.size() > stride) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_flat: stride smaller than a request's top");
+            num_hits[i] = r.num_hits;
+            counts[i] = uint32_t(r.ids.size());
+            std::memcpy(ids + i * stride, r.ids.data(), r.ids.size() * 4);
+            std::memcpy(scores + i * stride, r.scores.data(), r.scores.size() * 4);
+        }
+    });
+}
+
 // ------------------------------------------------------------------ shard partials
 int vq_search_batch_partial(const vq_index* index, const vq_request* const* requests, size_t n, vq_partial_batch** out) {
     return guard([&] {

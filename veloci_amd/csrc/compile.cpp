@@ -747,6 +747,7 @@ struct Compiler {
                     const bool cover = l.flags & LIST_COVER;
                     if (cover) f |= 1u << (8 + k);
                     if ((l.flags & LIST_BITMAP) && (seq || !cover)) f |= 1u << k;
+                    if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);
                 }
                 cq.simple_flags = f;
             }

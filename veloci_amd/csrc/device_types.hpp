@@ -125,7 +125,8 @@ struct QHeader {
     uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are
-                             // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple
+                             // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
+                             // bits 20-23: leaf k has enough entries per tile to prefetch its next 1 KiB round
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

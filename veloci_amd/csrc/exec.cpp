@@ -1,7 +1,10 @@
 // Batch executor: compile n requests, pack their device programs, launch the kernels, assemble results.
 // One batch == one k_tile_scan launch over all (query, span) pairs (SURVEY.md §7 "design for batches").
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "engine.hpp"
 
@@ -113,7 +116,14 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     return off;
 }
 
+static bool timing_enabled() {
+    static const bool on = std::getenv("VQ_TIMING") != nullptr;
+    return on;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n) {
+    const double t_start = now_ms();
     auto pb = std::make_unique<PartialBatch>();
     pb->index = &idx;
     pb->t0 = std::chrono::steady_clock::now();
@@ -125,16 +135,23 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     // ---- compile
     pb->queries.reserve(n);
     pb->slot.assign(n, UINT32_MAX);
-    for (size_t i = 0; i < n; ++i) {
-        if (!reqs[i]) {
-            CompiledQuery cq;
-            cq.status = ERR_INVALID_ARGUMENT;
-            cq.error = "null request";
-            pb->queries.push_back(std::move(cq));
-            continue;
+    pb->queries.resize(n);
+    auto compile_range = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            if (!reqs[i]) {
+                pb->queries[i].status = ERR_INVALID_ARGUMENT;
+                pb->queries[i].error = "null request";
+            } else pb->queries[i] = compile_query(idx, *reqs[i]);
         }
-        pb->queries.push_back(compile_query(idx, *reqs[i]));
-    }
+    };
+    if (n >= 256) {  // query compilation is independent per request: fan out over a few host threads
+        const size_t nt = 4;
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < nt; ++t) th.emplace_back(compile_range, n * t / nt, n * (t + 1) / nt);
+        compile_range(0, n / nt);
+        for (auto& t : th) t.join();
+    } else compile_range(0, n);
+    const double t_compiled = now_ms();
     // ---- layout
     uint32_t nq = 0;
     uint64_t total_keys = 0, total_hist = 0, total_span_keys = 0, total_spans = 0, blob_bytes = 0;
@@ -291,6 +308,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     launch_merge_spans(st, nq, pb->d_blobs, pb->d_blob_off, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_keys));
     VQ_HIP(hipGetLastError());
+    if (timing_enabled())
+        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms, pack+launch %.3f ms\n", n, t_compiled - t_start, now_ms() - t_compiled);
     return pb;
 }
 
@@ -346,6 +365,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         }
     }
     const uint64_t ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pb.t0).count());
+    const double t_synced = now_ms();
 
     const uint8_t* hd = ws.h_down.as<uint8_t>();
     size_t key_off = 0, job = 0, fac_off = 0;
@@ -392,6 +412,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         out[i] = std::move(r);
     }
     pb.lock.unlock();
+    if (timing_enabled()) std::fprintf(stderr, "[vq timing] batch wall %.3f ms, result assembly %.3f ms\n", double(ns) * 1e-6, now_ms() - t_synced);
 }
 
 }  // namespace vq

@@ -1208,10 +1208,12 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
                 while (true) {
                     const uint32_t vn = v + 64u;
                     u32x4 nx = kSent;
-                    if (vn < nvec) nx = dptr[vn];
+                    const bool prefetch = (sflags >> (20 + k)) & 1u;  // lists with >= ~200 entries per tile
+                    if (prefetch && vn < nvec) nx = dptr[vn];
                     const bool ix = d4.x < tile_hi, iy = d4.y < tile_hi, iz = d4.z < tile_hi, iw = d4.w < tile_hi;
                     const uint32_t mine = (uint32_t)ix + (uint32_t)iy + (uint32_t)iz + (uint32_t)iw;
                     const uint32_t full = (uint32_t)__popcll(__ballot(iw));
+                    if (!prefetch && full == 64u && vn < nvec) nx = dptr[vn];  // sparse list: load the next round only when needed
                     uint32_t n_in = full << 2;
                     if (full < 64u) n_in += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)full);
                     total_in += n_in;
@@ -1262,65 +1264,70 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
         (void)wave_excl_scan_u32(popc4(r), &S);
         if (S) {  // uniform
             hits += S;
-            // rank of each list at this lane's first word
+            // rank of each list at this lane's first word, and the popcounts of the lane's words before word j
             uint32_t run[4] = {0, 0, 0, 0};
+            uint32_t c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, c3[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 if (k < n) {
+                    c1[k] = (uint32_t)__popc(wk[k].x);
+                    c2[k] = c1[k] + (uint32_t)__popc(wk[k].y);
+                    c3[k] = c2[k] + (uint32_t)__popc(wk[k].z);
                     uint32_t tot;
-                    run[k] = base_idx[k] + wave_excl_scan_u32(popc4(wk[k]), &tot);
+                    run[k] = base_idx[k] + wave_excl_scan_u32(c3[k] + (uint32_t)__popc(wk[k].w), &tot);
                 }
             }
+            // every round each lane emits its next surviving doc (lowest word, lowest bit first): the number of
+            // rounds is the largest survivor count of a lane (1-2 for an AND tile, up to 128 for a dense OR tile)
+            u32x4 rr = r;
+            while (true) {  // uniform
+                const uint32_t j = rr.x ? 0u : rr.y ? 1u : rr.z ? 2u : 3u;
+                const uint32_t rw = comp4(rr, j);
+                const bool has = rw != 0u;
+                const unsigned long long mask = __ballot(has);
+                if (!mask) break;
+                if (has) {
+                    const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
+                    const uint32_t cleared = rw & (rw - 1u);
+                    if (j == 0) rr.x = cleared;
+                    else if (j == 1) rr.y = cleared;
+                    else if (j == 2) rr.z = cleared;
+                    else rr.w = cleared;
+                    const uint32_t below = (1u << b) - 1u;
+                    const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    qdoc[p] = tile_lo + (((lane << 2) + j) << 5) + b;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                uint32_t rw = comp4(r, j);
-                const uint32_t wdoc = tile_lo + (((lane << 2) + j) << 5);
-                while (true) {  // uniform
-                    const bool has = rw != 0u;
-                    const unsigned long long mask = __ballot(has);
-                    if (!mask) break;
-                    if (has) {
-                        const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
-                        rw &= rw - 1u;
-                        const uint32_t below = (1u << b) - 1u;
-                        const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                        qdoc[p] = wdoc + b;
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            if (k < n) {
-                                const uint32_t word = comp4(wk[k], j);
-                                qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
-                            }
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        if (k < n) {
+                            const uint32_t word = comp4(wk[k], j);
+                            const uint32_t before = j == 0 ? 0u : j == 1 ? c1[k] : j == 2 ? c2[k] : c3[k];
+                            qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + before + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
                         }
-                    }
-                    qlen += (uint32_t)__popcll(mask);
-                    if (qlen >= 64u) {  // uniform
-                        __syncthreads();
-                        simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
-                        // move the remainder to the front
-                        const uint32_t rem = qlen - 64u;
-                        uint32_t td = 0, ti[4] = {0, 0, 0, 0};
-                        if (lane < rem) {
-                            td = qdoc[64u + lane];
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k)
-                                if (k < n) ti[k] = qidx[k * kQCap + 64u + lane];
-                        }
-                        __syncthreads();
-                        if (lane < rem) {
-                            qdoc[lane] = td;
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k)
-                                if (k < n) qidx[k * kQCap + lane] = ti[k];
-                        }
-                        __syncthreads();
-                        qlen = rem;
                     }
                 }
-                // ranks move on past this word
+                qlen += (uint32_t)__popcll(mask);
+                if (qlen >= 64u) {  // uniform
+                    __syncthreads();
+                    simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+                    // move the remainder to the front
+                    const uint32_t rem = qlen - 64u;
+                    uint32_t td = 0, ti[4] = {0, 0, 0, 0};
+                    if (lane < rem) {
+                        td = qdoc[64u + lane];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k)
-                    if (k < n) run[k] += (uint32_t)__popc(comp4(wk[k], j));
+                        for (uint32_t k = 0; k < 4; ++k)
+                            if (k < n) ti[k] = qidx[k * kQCap + 64u + lane];
+                    }
+                    __syncthreads();
+                    if (lane < rem) {
+                        qdoc[lane] = td;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k)
+                            if (k < n) qidx[k * kQCap + lane] = ti[k];
+                    }
+                    __syncthreads();
+                    qlen = rem;
+                }
             }
         }
     }

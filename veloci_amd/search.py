@@ -115,6 +115,31 @@ def search_batch(requests, index, raise_on_error=True):
     return results
 
 
+class RequestBatch:
+    """n parsed requests as one C array: build once, search many times (the throughput path)."""
+
+    def __init__(self, requests):
+        self.reqs = [_as_request(r) for r in requests]
+        self.n = len(self.reqs)
+        self.arr = (C.c_void_p * self.n)(*[r.h for r in self.reqs])
+
+
+def search_batch_flat(batch, index, stride=10):
+    """`vq_search_batch_flat`: returns (num_hits u64[n], counts u32[n], ids u32[n, stride], scores f32[n, stride], status i32[n])."""
+    L = _lib.lib()
+    if not isinstance(batch, RequestBatch):
+        batch = RequestBatch(batch)
+    n = batch.n
+    num_hits = np.zeros(n, np.uint64)
+    counts = np.zeros(n, np.uint32)
+    ids = np.zeros((n, stride), np.uint32)
+    scores = np.zeros((n, stride), np.float32)
+    status = np.zeros(n, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(L.vq_search_batch_flat(index.h, batch.arr, n, stride, p(num_hits), p(counts), p(ids), p(scores), p(status)))
+    return num_hits, counts, ids, scores, status
+
+
 class PartialBatch:
     """Shard-local partial results of a batch, resident in HBM (`vq_partial_batch`)."""
 
