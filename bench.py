@@ -146,11 +146,21 @@ def main():
                        f" (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},
-            "p50_latency_ms_single_query": round(p50, 3),
+            "p50_latency_ms_single_query": (round(p50, 3) if p50 == p50 else None),
             "roofline": {"bound": "hbm", "kernel": "k_scan_simple", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches)},
         }
+        # HBM traffic per launch from the committed PMC passes (profiles/r01_traffic.json), when they were taken on this configuration
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f)
+            c = tr["config"]
+            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (args.docs, args.triples, args.batch, args.workload, world):
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not args.no_cpu and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(data, meta, reqs_json, args)
     if rank == 0:
