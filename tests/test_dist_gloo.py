@@ -1,0 +1,142 @@
+"""N>1 path on CPU: two gloo ranks, doc-range shards, all-gather of packed partials, merge.
+
+No GPU here, so each rank's shard engine is the CPU oracle run on that rank's shard of the synthetic index;
+what is under test is the sharding scheme and the collective plumbing of veloci_amd.dist: shard ranges, the
+shard == slice-of-the-unsharded-index property of the generator, the all-reduce of list lengths, the
+all-gather of equal-sized packed partial buffers and the exactness of "per-shard top-k + merge"."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _order_f32(bits):
+    bits = np.uint32(bits)
+    return np.uint32(~bits) if bits & np.uint32(0x80000000) else np.uint32(bits | np.uint32(0x80000000))
+
+
+def _pack(results, top_k, hist_sizes):
+    """Same layout as the device partial: [u64 hits[nq]][u64 keys[nq*top_k]][u32 hist[...]]."""
+    nq = len(results)
+    hits = np.zeros(nq, np.uint64)
+    keys = np.zeros(nq * top_k, np.uint64)
+    hist = []
+    for q, r in enumerate(results):
+        hits[q] = r.num_hits
+        for j, (d, s) in enumerate(zip(r.ids.tolist(), r.scores.tolist())):
+            bits = np.float32(s).view(np.uint32)
+            keys[q * top_k + j] = (np.uint64(_order_f32(bits)) << np.uint64(32)) | np.uint64(d)
+        for (field, entries), (fname, C, names) in zip(r.facets, hist_sizes):
+            h = np.zeros(C, np.uint32)
+            for v, c in entries:
+                h[names[v]] = c
+            hist.append(h)
+    buf = np.concatenate([hits.view(np.uint8), keys.view(np.uint8)] + [h.view(np.uint8) for h in hist])
+    return torch.from_numpy(buf.copy())
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from veloci_amd import dist as vdist
+    from veloci_amd import synth
+    from oracle import binding as O
+
+    N = 60_000
+    spec = synth.SynthSpec(num_docs=N, num_terms=500, triples=1, extra_probe_dfs=(400,), background_terms=5, cat_values=16, tag_values=64)
+    lo, hi = vdist.shard_range(N, rank, world)
+    data, meta = synth.generate(spec, doc_lo=lo, doc_hi=hi, device="cpu")
+    path = "body.textindex.to_anchor_id_score"
+    local_lens = np.diff(data.token_to_anchor_score[path][0].astype(np.int64))
+    vdist.all_reduce_global_lens(data)
+    global_lens = data.token_to_anchor_score[path][3].astype(np.int64)
+
+    ora = O.OracleIndex(N)
+    data.load_into(ora)
+    a, b, c = meta.triples[0]
+    top_k = 7
+    cats = [("cat", 16, {("cat%05d" % i): i for i in range(16)})]
+    reqs = [synth.req_and([a, b, c], top=top_k), synth.req_or([a, b], top=top_k), synth.req_single(meta.extra_probes[0], top=top_k)]
+    reqs[1]["facets"] = [{"field": "cat", "top": 16}]
+    res = [ora.search_json(json.dumps(r)) for r in reqs]
+    local = _pack(res, top_k, cats)
+    gathered = vdist.gather_partials(local)
+    assert gathered.numel() == world * local.numel()
+
+    if rank == 0:
+        full, _ = synth.generate(spec, device="cpu")
+        assert np.array_equal(np.diff(full.token_to_anchor_score[path][0].astype(np.int64)), global_lens), "all-reduced lengths != unsharded lengths"
+        # shard == slice of the unsharded index
+        fo, fa, fs, _ = full.token_to_anchor_score[path]
+        so, sa, ss, _ = data.token_to_anchor_score[path]
+        for t in np.nonzero(local_lens)[0][:50]:
+            fl = fa[int(fo[t]):int(fo[t + 1])]
+            m = (fl >= lo) & (fl < hi)
+            assert np.array_equal(fl[m], sa[int(so[t]):int(so[t + 1])])
+            assert np.array_equal(fs[int(fo[t]):int(fo[t + 1])][m], ss[int(so[t]):int(so[t + 1])])
+        want_ora = O.OracleIndex(N)
+        full.load_into(want_ora)
+        want = [want_ora.search_json(json.dumps(r)) for r in reqs]
+        nq = len(reqs)
+        per = local.numel()
+        g = gathered.numpy().reshape(world, per)
+        hits = np.zeros(nq, np.uint64)
+        keys = [[] for _ in range(nq)]
+        hist = np.zeros(16, np.uint64)
+        for p in range(world):
+            hits += g[p, :nq * 8].view(np.uint64)
+            k = g[p, nq * 8:nq * 8 + nq * top_k * 8].view(np.uint64).reshape(nq, top_k)
+            for q in range(nq):
+                keys[q] += [int(x) for x in k[q] if x]
+            hist += g[p, nq * 8 + nq * top_k * 8:].view(np.uint32)
+        problems = []
+        for q in range(nq):
+            merged = sorted(keys[q], reverse=True)[:top_k]
+            ids = [x & 0xFFFFFFFF for x in merged]
+            if int(hits[q]) != want[q].num_hits:
+                problems.append(f"q{q} hits {hits[q]} != {want[q].num_hits}")
+            if ids != want[q].ids.tolist():
+                problems.append(f"q{q} ids {ids} != {want[q].ids.tolist()}")
+        wf = dict(want[1].facets)["cat"]
+        got_counts = sorted([int(x) for x in hist if x], reverse=True)
+        if got_counts != [c for _, c in wf]:
+            problems.append(f"facet counts {got_counts} != {[c for _, c in wf]}")
+        with open(out_path, "w") as f:
+            json.dump(problems, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_search(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "problems.json")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    with open(out) as f:
+        problems = json.load(f)
+    assert problems == []
+
+
+def test_shard_range_partitions_everything():
+    from veloci_amd.dist import shard_range
+    for n in (1, 7, 100_000_000, 2**32 - 2):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
