@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--workload", default="and", choices=["and", "or", "single"], help="and = the headline metric; or / single = extra shapes")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency loop (profiling runs)")
     args = ap.parse_args()
 
@@ -53,11 +55,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import veloci_amd
     from veloci_amd import dist as vdist
@@ -86,12 +93,21 @@ def main():
     else:
         reqs_json = [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(args.batch)]
     reqs = [veloci_amd.Request(r) for r in reqs_json]
+    batch = veloci_amd.RequestBatch(reqs)
     searcher = vdist.ShardedSearcher(index) if world > 1 else None
 
+    class Row:  # what the bench looks at of a result
+        def __init__(self, nh):
+            self.num_hits = int(nh)
+
     def step():
+        # flat C-ABI entry points: no per-result Python objects inside the timed region
         if searcher is not None:
-            return searcher.search_batch(reqs)
-        return veloci_amd.search_batch(reqs, index)
+            num_hits, counts, ids, scores, status = searcher.search_batch_flat(batch, stride=10)
+        else:
+            num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(batch, index, stride=10)
+        assert not status.any()
+        return [Row(x) for x in num_hits[:3]]
 
     def sync():
         torch.cuda.synchronize()
@@ -106,15 +122,21 @@ def main():
     index.profile_read(reset=True)
     sync()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = step()
+        step_times.append(time.perf_counter() - ts)
+    t_loop = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("VQ_TIMING"):
+        log("step times ms:", [round(x * 1e3, 2) for x in step_times], "loop", round(t_loop * 1e3, 2), "with final sync", round(dt * 1e3, 2))
     scan_ms, launches, algo_bytes = index.profile_read(reset=True)
     index.profile_enable(False)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_q = args.batch * args.steps

@@ -195,6 +195,9 @@ void* vq_partial_device_ptr(vq_partial_batch*);
  * each `vq_partial_bytes` long) into final results. */
 int vq_merge_partials(const vq_index*, vq_partial_batch* local, const void* gathered_device,
                       uint32_t num_shards, vq_result** out, int* status);
+/* Same merge with flat output (see vq_search_batch_flat). */
+int vq_merge_partials_flat(const vq_index*, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t stride,
+                           uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status);
 void vq_partial_free(vq_partial_batch*);
 
 /* ------------------------------------------------------------ measurement */

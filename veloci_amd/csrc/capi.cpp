@@ -1,4 +1,7 @@
 // extern "C" boundary (include/veloci_amd.h).  No torch types, no exceptions across the ABI.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/veloci_amd.h"
@@ -163,8 +166,9 @@ void vq_index_free(vq_index* i) { delete i; }
 int vq_index_set_stream(vq_index* i, void* hip_stream) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_stream: null index");
-        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
         i->idx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_stream;
+        i->idx->fin_stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_fin_stream;
     });
 }
 uint64_t vq_index_device_bytes(const vq_index* i) { return i ? i->idx->device_bytes : 0; }
@@ -282,32 +286,51 @@ int vq_search_batch(const vq_index* index, const vq_request* const* requests, si
     });
 }
 
+static void copy_flat(const std::vector<std::unique_ptr<Result>>& results, const std::vector<int>& st, const std::vector<std::string>& errs, size_t base,
+                      size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status) {
+    for (size_t k = 0; k < results.size(); ++k) {
+        const size_t i = base + k;
+        if (status) status[i] = st[k];
+        num_hits[i] = 0;
+        counts[i] = 0;
+        if (st[k] != 0) {
+            if (g_err.empty()) g_err = errs[k];
+            continue;
+        }
+        const Result& r = *results[k];
+        if (r.ids.size() > stride) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "flat output: stride smaller than a request's top");
+        num_hits[i] = r.num_hits;
+        counts[i] = uint32_t(r.ids.size());
+        std::memcpy(ids + i * stride, r.ids.data(), r.ids.size() * 4);
+        std::memcpy(scores + i * stride, r.scores.data(), r.scores.size() * 4);
+    }
+}
+
 int vq_search_batch_flat(const vq_index* index, const vq_request* const* requests, size_t n, size_t stride, uint64_t* num_hits, uint32_t* counts,
                          uint32_t* ids, float* scores, int* status) {
     return guard([&] {
         if (!index || (n && (!requests || !num_hits || !counts || !ids || !scores))) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_flat: null argument");
         std::vector<const Request*> reqs(n);
         for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
-        auto pb = run_partial(*index->idx, reqs.data(), n);
-        std::vector<std::unique_ptr<Result>> results;
-        std::vector<int> st;
-        std::vector<std::string> errs;
-        finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
-        for (size_t i = 0; i < n; ++i) {
-            if (status) status[i] = st[i];
-            num_hits[i] = 0;
-            counts[i] = 0;
-            if (st[i] != 0) {
-                if (g_err.empty()) g_err = errs[i];
-                continue;
-            }
-            const Result& r = *results[i];
-            if (r.ids.size() > stride) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_flat: stride smaller than a request's top");
-            num_hits[i] = r.num_hits;
-            counts[i] = uint32_t(r.ids.size());
-            std::memcpy(ids + i * stride, r.ids.data(), r.ids.size() * 4);
-            std::memcpy(scores + i * stride, r.scores.data(), r.scores.size() * 4);
+        // Large batches run as a software pipeline of chunks over the index's two workspaces: while the GPU scans chunk c
+        // the host compiles chunk c+1, and chunk c-1's merge + download run on the finish stream.
+        const size_t nchunks = n >= 512 ? 4 : 1;
+        std::vector<std::unique_ptr<PartialBatch>> inflight(nchunks);
+        auto bounds = [&](size_t c) { return std::make_pair(n * c / nchunks, n * (c + 1) / nchunks); };
+        auto finish = [&](size_t c) {
+            std::vector<std::unique_ptr<Result>> results;
+            std::vector<int> st;
+            std::vector<std::string> errs;
+            finish_batch(*index->idx, *inflight[c], nullptr, 1, results, st, errs);
+            copy_flat(results, st, errs, bounds(c).first, stride, num_hits, counts, ids, scores, status);
+            inflight[c].reset();
+        };
+        for (size_t c = 0; c < nchunks; ++c) {
+            if (c >= size_t(kWorkspaces)) finish(c - kWorkspaces);
+            auto [b, e] = bounds(c);
+            inflight[c] = run_partial(*index->idx, reqs.data() + b, e - b, int(c % kWorkspaces));
         }
+        for (size_t c = nchunks >= size_t(kWorkspaces) ? nchunks - kWorkspaces : 0; c < nchunks; ++c) finish(c);
     });
 }
 
@@ -319,7 +342,9 @@ int vq_search_batch_partial(const vq_index* index, const vq_request* const* requ
         std::vector<const Request*> reqs(n);
         for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
         auto pb = run_partial(*index->idx, reqs.data(), n);
-        VQ_HIP(hipStreamSynchronize(index->idx->stream));  // the packed buffer is handed to another library (RCCL)
+        // on the index's own stream the packed buffer must be complete before another library (RCCL) reads it; on a
+        // caller-provided stream the caller's collective is ordered behind the scan by the stream itself
+        if (index->idx->stream == index->idx->own_stream) VQ_HIP(hipStreamSynchronize(index->idx->stream));
         auto* h = new vq_partial_batch();
         h->pb = std::move(pb);
         *out = h;
@@ -346,20 +371,31 @@ int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void
         }
     });
 }
+int vq_merge_partials_flat(const vq_index* index, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t stride,
+                           uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status) {
+    return guard([&] {
+        if (!index || !local || !num_hits || !counts || !ids || !scores) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_merge_partials_flat: null argument");
+        std::vector<std::unique_ptr<Result>> results;
+        std::vector<int> st;
+        std::vector<std::string> errs;
+        finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
+        copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
+    });
+}
 void vq_partial_free(vq_partial_batch* p) { delete p; }
 
 // ------------------------------------------------------------------ measurement
 int vq_profile_enable(vq_index* i, int on) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_profile_enable: null index");
-        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        std::lock_guard<std::mutex> g(i->idx->profile_mutex);
         i->idx->profile.enabled = on != 0;
     });
 }
 int vq_profile_read(const vq_index* i, int reset, double* scan_kernel_ms, uint64_t* scan_launches, uint64_t* algorithmic_bytes) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_profile_read: null index");
-        std::lock_guard<std::mutex> g(i->idx->exec_mutex);
+        std::lock_guard<std::mutex> g(i->idx->profile_mutex);
         Profile& p = i->idx->profile;
         if (scan_kernel_ms) *scan_kernel_ms = p.scan_ms;
         if (scan_launches) *scan_launches = p.scan_launches;

@@ -180,7 +180,12 @@ struct PinnedBuf {  // page-locked host staging
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct Workspace {  // per-index scratch reused by every batch (guarded by Index::exec_mutex)
+constexpr int kWorkspaces = 2;  // batches in flight per index (host compile of one overlaps the scan of the other)
+
+struct Workspace {  // scratch of one in-flight batch
+    std::mutex mu;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scan launch (profiling)
+    hipEvent_t ev_done = nullptr;             // scan + span merge finished: the finish stream waits on it
     PinnedBuf h_up, h_down;
     DevBuf d_up;        // blobs + blob_off + span_base + facet jobs
     DevBuf d_span_keys;
@@ -208,12 +213,13 @@ struct Index {
     std::map<std::string, BoostColumn> boost;
     std::map<std::string, ColumnMeta> columns;
     uint64_t device_bytes = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    mutable std::mutex exec_mutex;  // one batch at a time per index (workspace is shared)
+    hipStream_t own_stream = nullptr, own_fin_stream = nullptr;
+    hipStream_t stream = nullptr;      // scans + span merges
+    hipStream_t fin_stream = nullptr;  // shard merge, facet selection, result download (== stream when the caller set one)
+    mutable std::mutex profile_mutex;
     mutable Profile profile;
-    mutable Workspace ws;
-    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mutable Workspace ws[kWorkspaces];
+    mutable std::atomic<uint32_t> next_ws{0};
     ~Index();
     bool is_anchor_identity(const std::string& textindex_path) const;
 };
@@ -282,7 +288,8 @@ struct Result {
 
 struct PartialBatch {
     const Index* index = nullptr;
-    std::unique_lock<std::mutex> lock;    // holds the index workspace until the batch is finished
+    Workspace* ws = nullptr;
+    std::unique_lock<std::mutex> lock;    // holds the workspace until the batch is finished
     std::vector<CompiledQuery> queries;   // status != 0: failed at compile time
     std::vector<uint32_t> slot;           // slot[i]: position of request i among the device queries, or UINT32_MAX
     uint32_t nq_dev = 0;
@@ -300,7 +307,7 @@ struct PartialBatch {
     std::chrono::steady_clock::time_point t0;
 };
 
-std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n);
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot = -1);
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
                   std::vector<int>& status, std::vector<std::string>& errors);
 

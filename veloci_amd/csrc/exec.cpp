@@ -122,14 +122,16 @@ static bool timing_enabled() {
 }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n) {
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot) {
     const double t_start = now_ms();
     auto pb = std::make_unique<PartialBatch>();
     pb->index = &idx;
     pb->t0 = std::chrono::steady_clock::now();
-    pb->lock = std::unique_lock<std::mutex>(idx.exec_mutex);
+    if (slot < 0) slot = int(idx.next_ws.fetch_add(1) % kWorkspaces);
+    pb->ws = &idx.ws[slot % kWorkspaces];
+    pb->lock = std::unique_lock<std::mutex>(pb->ws->mu);
     VQ_HIP(hipSetDevice(idx.device));
-    Workspace& ws = idx.ws;
+    Workspace& ws = *pb->ws;
     hipStream_t st = idx.stream;
 
     // ---- compile
@@ -291,7 +293,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
-    if (pb->profiled) VQ_HIP(hipEventRecord(idx.ev0, st));
+    if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
     launch_scan_simple(st, spans_simple, scan_simple_lds_bytes(cand_cap), pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
@@ -300,7 +302,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                      stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     if (pb->profiled) {
-        VQ_HIP(hipEventRecord(idx.ev1, st));
+        VQ_HIP(hipEventRecord(ws.ev1, st));
+        std::lock_guard<std::mutex> g(idx.profile_mutex);
         idx.profile.scan_launches += 1;
         idx.profile.algorithmic_bytes += algo_bytes;
     }
@@ -308,6 +311,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     launch_merge_spans(st, nq, pb->d_blobs, pb->d_blob_off, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_keys));
     VQ_HIP(hipGetLastError());
+    VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
         std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms, pack+launch %.3f ms\n", n, t_compiled - t_start, now_ms() - t_compiled);
     return pb;
@@ -320,8 +324,8 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
     out.resize(n);
     status.assign(n, 0);
     errors.assign(n, std::string());
-    Workspace& ws = idx.ws;
-    hipStream_t st = idx.stream;
+    Workspace& ws = *pb.ws;
+    hipStream_t st = idx.fin_stream;
     const PartialLayout& lay = pb.layout;
     const uint32_t nq = pb.nq_dev;
     VQ_HIP(hipSetDevice(idx.device));
@@ -342,6 +346,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         if (!gathered_device) num_shards = 1;
         ws.d_down.ensure(down_bytes);
         ws.h_down.ensure(down_bytes);
+        if (st != idx.stream) VQ_HIP(hipStreamWaitEvent(st, ws.ev_done, 0));
         uint8_t* dd = ws.d_down.as<uint8_t>();
         launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, lay, reinterpret_cast<uint32_t*>(dd + o_ids),
                         reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
@@ -361,7 +366,8 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         VQ_HIP(hipStreamSynchronize(st));
         if (pb.profiled) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, idx.ev0, idx.ev1) == hipSuccess) idx.profile.scan_ms += ms;
+            std::lock_guard<std::mutex> g(idx.profile_mutex);
+            if (hipEventElapsedTime(&ms, ws.ev0, ws.ev1) == hipSuccess) idx.profile.scan_ms += ms;
         }
     }
     const uint64_t ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pb.t0).count());

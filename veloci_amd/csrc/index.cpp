@@ -44,9 +44,13 @@ void DevBuf::upload(const void* src, size_t n, hipStream_t st) {
 }
 
 Index::~Index() {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    for (auto& w : ws) {
+        if (w.ev0) (void)hipEventDestroy(w.ev0);
+        if (w.ev1) (void)hipEventDestroy(w.ev1);
+        if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    }
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    if (own_fin_stream) (void)hipStreamDestroy(own_fin_stream);
 }
 
 bool Index::is_anchor_identity(const std::string& textindex_path) const {
@@ -109,9 +113,14 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     idx->doc_hi = b.doc_hi;
     idx->columns = b.columns;
     VQ_HIP(hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking));
+    VQ_HIP(hipStreamCreateWithFlags(&idx->own_fin_stream, hipStreamNonBlocking));
     idx->stream = idx->own_stream;
-    VQ_HIP(hipEventCreate(&idx->ev0));
-    VQ_HIP(hipEventCreate(&idx->ev1));
+    idx->fin_stream = idx->own_fin_stream;
+    for (auto& w : idx->ws) {
+        VQ_HIP(hipEventCreate(&w.ev0));
+        VQ_HIP(hipEventCreate(&w.ev1));
+        VQ_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+    }
     const uint32_t lo = b.doc_lo, hi = b.doc_hi;
     idx->bitmap_base = lo & ~65535u;
     // one bitmap covers [bitmap_base, hi) rounded up to 65536 docs, plus one tile of slack for the last tile's copy

@@ -44,6 +44,10 @@ def gather_partials(local, group=None):
     """All-gather equal-sized packed partial buffers (uint8 tensors) into one shard-major tensor."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # rehearsal on a backend without device collectives (gloo): stage through the host
+        host = gather_partials(local.cpu(), group)
+        return host.to(local.device)
     out = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
     if local.is_cuda:
         dist.all_gather_into_tensor(out, local, group=group)
@@ -61,13 +65,34 @@ class ShardedSearcher:
         self.index = index
         self.group = group
         self.world = dist.get_world_size(group)
+        if self.world > 1 and dist.get_backend(group) == "nccl":
+            # scans, the RCCL all-gather and the merge are ordered on ONE stream (torch's current one): no host
+            # synchronisation between the shard scan and the collective
+            index.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _gather(self, pb):
+        import torch.distributed as dist
+        local = device_view(pb.device_ptr, pb.nbytes)
+        gathered = gather_partials(local, self.group)
+        if dist.get_backend(self.group) != "nccl":
+            torch.cuda.current_stream().synchronize()
+        return gathered
 
     def search_batch(self, requests):
         from .search import PartialBatch
         pb = PartialBatch(self.index, requests)
         if self.world == 1:
             return pb.merge(None, 1)
-        local = device_view(pb.device_ptr, pb.nbytes)
-        gathered = gather_partials(local, self.group)
-        torch.cuda.current_stream().synchronize()
+        gathered = self._gather(pb)
         return pb.merge(gathered.data_ptr(), self.world)
+
+    def search_batch_flat(self, requests, stride=10):
+        """Flat-output variant (see veloci_amd.search_batch_flat): no per-result Python objects."""
+        from .search import PartialBatch
+        pb = PartialBatch(self.index, requests)
+        if self.world == 1:
+            return pb.merge_flat(None, 1, stride)
+        gathered = self._gather(pb)
+        out = pb.merge_flat(gathered.data_ptr(), self.world, stride)
+        pb.close()
+        return out

@@ -146,9 +146,12 @@ class PartialBatch:
     def __init__(self, index, requests):
         self.L = _lib.lib()
         self.index = index
-        self.reqs = [_as_request(r) for r in requests]
-        n = len(self.reqs)
-        arr = (C.c_void_p * n)(*[r.h for r in self.reqs])
+        if isinstance(requests, RequestBatch):
+            self.reqs, n, arr = requests.reqs, requests.n, requests.arr
+        else:
+            self.reqs = [_as_request(r) for r in requests]
+            n = len(self.reqs)
+            arr = (C.c_void_p * n)(*[r.h for r in self.reqs])
         h = C.c_void_p()
         _lib.check(self.L.vq_search_batch_partial(index.h, arr, n, C.byref(h)))
         self.h = h
@@ -175,6 +178,18 @@ class PartialBatch:
             else:
                 results.append(_take_result(self.L, C.c_void_p(outs[i])))
         return results
+
+    def merge_flat(self, gathered_device_ptr=None, num_shards=1, stride=10):
+        n = self.n
+        num_hits = np.zeros(n, np.uint64)
+        counts = np.zeros(n, np.uint32)
+        ids = np.zeros((n, stride), np.uint32)
+        scores = np.zeros((n, stride), np.float32)
+        status = np.zeros(n, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L.vq_merge_partials_flat(self.index.h, self.h, C.c_void_p(gathered_device_ptr) if gathered_device_ptr else None, num_shards, stride,
+                                                 p(num_hits), p(counts), p(ids), p(scores), p(status)))
+        return num_hits, counts, ids, scores, status
 
     def close(self):
         if getattr(self, "h", None):
