@@ -65,17 +65,24 @@ class ShardedSearcher:
         self.index = index
         self.group = group
         self.world = dist.get_world_size(group)
+        self.stream = None
         if self.world > 1 and dist.get_backend(group) == "nccl":
-            # scans, the RCCL all-gather and the merge are ordered on ONE stream (torch's current one): no host
-            # synchronisation between the shard scan and the collective
-            index.set_stream(torch.cuda.current_stream().cuda_stream)
+            # scans, the RCCL all-gather and the merge are ordered on ONE side stream: no host synchronisation between
+            # the shard scan and the collective.  (Not torch's default stream: its handle is 0, which the C ABI reads as
+            # "use the index's own streams".)
+            self.stream = torch.cuda.Stream()
+            index.set_stream(self.stream.cuda_stream)
 
     def _gather(self, pb):
-        import torch.distributed as dist
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                local = device_view(pb.device_ptr, pb.nbytes)
+                return gather_partials(local, self.group)
+        # rehearsal backends: the partial is complete (vq_search_batch_partial synchronised the index's own stream);
+        # make sure the gathered copy is, too, before the merge kernels (own stream) read it
         local = device_view(pb.device_ptr, pb.nbytes)
         gathered = gather_partials(local, self.group)
-        if dist.get_backend(self.group) != "nccl":
-            torch.cuda.current_stream().synchronize()
+        torch.cuda.synchronize()
         return gathered
 
     def search_batch(self, requests):
@@ -86,13 +93,30 @@ class ShardedSearcher:
         gathered = self._gather(pb)
         return pb.merge(gathered.data_ptr(), self.world)
 
-    def search_batch_flat(self, requests, stride=10):
-        """Flat-output variant (see veloci_amd.search_batch_flat): no per-result Python objects."""
-        from .search import PartialBatch
-        pb = PartialBatch(self.index, requests)
-        if self.world == 1:
-            return pb.merge_flat(None, 1, stride)
-        gathered = self._gather(pb)
-        out = pb.merge_flat(gathered.data_ptr(), self.world, stride)
-        pb.close()
-        return out
+    def search_batch_flat(self, requests, stride=10, chunks=None):
+        """Flat-output variant (see veloci_amd.search_batch_flat): no per-result Python objects.  A large batch runs as
+        a pipeline of chunks over the index's two workspaces: the host compiles chunk c+1 while the GPU scans chunk c;
+        every chunk has its own all-gather (equal sizes on all ranks by construction)."""
+        from .search import PartialBatch, RequestBatch
+        batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
+        subs = batch.split(chunks if chunks is not None else (4 if batch.n >= 512 else 1))
+
+        def finish(pb):
+            if self.world == 1:
+                out = pb.merge_flat(None, 1, stride)
+            else:
+                gathered = self._gather(pb)
+                out = pb.merge_flat(gathered.data_ptr(), self.world, stride)
+            pb.close()
+            return out
+
+        outs, inflight = [], []
+        for sb in subs:
+            if len(inflight) >= 2:
+                outs.append(finish(inflight.pop(0)))
+            inflight.append(PartialBatch(self.index, sb))
+        while inflight:
+            outs.append(finish(inflight.pop(0)))
+        if len(outs) == 1:
+            return outs[0]
+        return tuple(np.concatenate([o[i] for o in outs]) for i in range(5))

@@ -122,6 +122,15 @@ class RequestBatch:
         self.reqs = [_as_request(r) for r in requests]
         self.n = len(self.reqs)
         self.arr = (C.c_void_p * self.n)(*[r.h for r in self.reqs])
+        self._splits = {}
+
+    def split(self, k):
+        """k contiguous sub-batches (cached): used to pipeline a large batch."""
+        if k <= 1:
+            return [self]
+        if k not in self._splits:
+            self._splits[k] = [RequestBatch(self.reqs[self.n * c // k:self.n * (c + 1) // k]) for c in range(k)]
+        return self._splits[k]
 
 
 def search_batch_flat(batch, index, stride=10):
