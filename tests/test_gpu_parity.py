@@ -254,3 +254,15 @@ def test_generic_kernel_also_matches_for_simple_queries():
                         "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_fast_div100_is_exact_for_every_f16():
+    """The dense-tile path divides by 100 with a 3-instruction sequence; it must equal the correctly rounded
+    f32 division for every finite f16 input (the only inputs it ever sees)."""
+    import ctypes as C
+    import veloci_amd
+    L = veloci_amd.lib()
+    L.vq_debug_div100_mismatches.restype = C.c_uint32
+    import torch
+    torch.cuda.init()
+    assert L.vq_debug_div100_mismatches() == 0

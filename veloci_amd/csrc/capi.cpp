@@ -61,6 +61,8 @@ extern "C" {
 
 const char* vq_last_error(void) { return g_err.c_str(); }
 const char* vq_version(void) { return "veloci_amd 0.1 (gfx950)"; }
+/* self-check (tests): inputs for which the kernels' fast a/100 differs from the correctly rounded division, over all f16 values */
+uint32_t vq_debug_div100_mismatches(void) { return vq::debug_div100_mismatches(); }
 
 // ------------------------------------------------------------------ index
 vq_index_builder* vq_index_builder_new(uint32_t num_anchors, uint32_t doc_lo, uint32_t doc_hi) {
