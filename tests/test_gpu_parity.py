@@ -266,3 +266,91 @@ def test_fast_div100_is_exact_for_every_f16():
     import torch
     torch.cuda.init()
     assert L.vq_debug_div100_mismatches() == 0
+
+
+# ---------------------------------------------------------------------------------------- fuzzy / prefix (K9)
+@pytest.fixture(scope="module")
+def words():
+    import veloci_amd
+    import wordcorpus
+    from oracle import binding as O
+    data, terms = wordcorpus.build()
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    return data, terms, idx, ora
+
+
+def _part(term, **kw):
+    p = {"path": "body", "terms": [term]}
+    p.update(kw)
+    return p
+
+
+PROBES = ["majestic", "Majestic", "searhc", "saerch", "strasse", "Straße", "über", "привет", "ПРИВЕТ", "their", "thier", "weather", "niece", "東京", "a", "ab",
+          "letter", "zzzzqqq", "im", "se"]
+
+
+def test_fuzzy_single_term(words):
+    n_hits = 0
+    for t in PROBES:
+        for lev in (1, 2, 3):
+            for ic in (None, True, False):
+                p = _part(t, levenshtein_distance=lev)
+                if ic is not None:
+                    p["ignore_case"] = ic
+                r = check(words, {"search_req": {"search": p}, "top": 20})
+                n_hits += r.num_hits
+    assert n_hits > 1000
+
+
+def test_starts_with(words):
+    n_hits = 0
+    for t in PROBES + ["m", "ma", "maj", "S", "th", "при"]:
+        for lev in (None, 1):
+            for ic in (None, False):
+                p = _part(t, starts_with=True)
+                if lev is not None:
+                    p["levenshtein_distance"] = lev
+                if ic is not None:
+                    p["ignore_case"] = ic
+                r = check(words, {"search_req": {"search": p}, "top": 20})
+                n_hits += r.num_hits
+    assert n_hits > 1000
+
+
+def test_fuzzy_in_trees_filters_and_boosts(words):
+    f = lambda t, **kw: {"search": _part(t, **kw)}
+    check(words, {"search_req": {"or": {"queries": [f("majestic", levenshtein_distance=1), f("search", levenshtein_distance=2), f("there")]}}, "top": 30})
+    check(words, {"search_req": {"and": {"queries": [f("the", starts_with=True), f("letter", levenshtein_distance=2)]}}, "top": 30})
+    # three run-time-sized operands: the summation order follows the merged lengths (set_op.rs:388-416)
+    r = check(words, {"search_req": {"and": {"queries": [f("the", starts_with=True), f("letter", levenshtein_distance=2), f("ma", starts_with=True)]}}, "top": 30})
+    assert r.num_hits > 0
+    r = check(words, {"search_req": {"and": {"queries": [f("s", starts_with=True), f("a", starts_with=True), f("m", starts_with=True), f("t", starts_with=True)]}}, "top": 30})
+    assert r.num_hits > 0
+    check(words, {"search_req": f("weather", levenshtein_distance=2), "filter": f("ma", starts_with=True), "top": 30})
+    check(words, {"search_req": f("ma", starts_with=True), "boost_term": [_part("magic", levenshtein_distance=1, boost=3.0)], "top": 30})
+    check(words, {"search_req": f("sea", starts_with=True, boost=1.5), "top": 15, "skip": 3})
+
+
+def test_leaf_top_limits_the_expansion(words):
+    for t, kw in (("s", {"starts_with": True}), ("letter", {"levenshtein_distance": 2}), ("a", {"starts_with": True})):
+        for top in (1, 3, 10):
+            p = _part(t, top=top, **kw)
+            # the reference's final sort of the limited term hits is unstable (search_field.rs:373-376); the oracle and
+            # the product both keep FST order among equal scores
+            check(words, {"search_req": {"search": p}, "top": 10})
+
+
+def test_fuzzy_batch_and_clamp(words):
+    import veloci_amd
+    from parity import assert_same
+    _, terms, idx, ora = words
+    reqs = []
+    rng = np.random.default_rng(3)
+    for i in rng.choice(len(terms), size=120, replace=False):
+        t = terms[int(i)]
+        reqs.append({"search_req": {"search": _part(t, levenshtein_distance=int(rng.integers(0, 9)), starts_with=bool(rng.integers(0, 2)))}, "top": 10})
+    got = veloci_amd.search_batch(reqs, idx)
+    for r, g in zip(reqs, got):
+        assert_same(r, g, ora.search_json(json.dumps(r)))

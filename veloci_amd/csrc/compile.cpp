@@ -55,6 +55,37 @@ float default_score_for_distance(uint8_t distance, bool prefix_matches) {
 
 bool cp_eq(uint32_t a, uint32_t b, bool ci) { return a == b || (ci && vqtext::lower_cp(a) == vqtext::lower_cp(b)); }
 
+// Distance the reference scores a dictionary hit with (search_field.rs:691-732): the scoring automaton is built
+// over the lower-cased term with transpositions at cost one; beyond its maximum it falls back to the plain
+// character Levenshtein distance in u8 (255 for strings of 255 bytes or more).
+uint8_t scoring_distance(const std::string& lower_hit, const std::string& lower_term, uint32_t dfa_max) {
+    const auto h = vqtext::decode_utf8(lower_hit), t = vqtext::decode_utf8(lower_term);
+    const size_t n = h.size(), m = t.size(), w = m + 1;
+    std::vector<uint32_t> osa((n + 1) * w), lev((n + 1) * w);
+    for (size_t j = 0; j <= m; ++j) osa[j] = lev[j] = uint32_t(j);
+    for (size_t i = 1; i <= n; ++i) {
+        osa[i * w] = lev[i * w] = uint32_t(i);
+        for (size_t j = 1; j <= m; ++j) {
+            const uint32_t sub = h[i - 1] == t[j - 1] ? 0u : 1u;
+            lev[i * w + j] = std::min({lev[(i - 1) * w + j] + 1, lev[i * w + j - 1] + 1, lev[(i - 1) * w + j - 1] + sub});
+            uint32_t v = std::min({osa[(i - 1) * w + j] + 1, osa[i * w + j - 1] + 1, osa[(i - 1) * w + j - 1] + sub});
+            if (i > 1 && j > 1 && h[i - 1] == t[j - 2] && h[i - 2] == t[j - 1]) v = std::min(v, osa[(i - 2) * w + j - 2] + 1);
+            osa[i * w + j] = v;
+        }
+    }
+    if (osa[n * w + m] <= dfa_max) return uint8_t(osa[n * w + m]);
+    if (lower_hit.size() >= 255 || lower_term.size() >= 255) return 255;
+    return uint8_t(lev[n * w + m]);
+}
+
+// levenshtein_distance after the clamp of search_field.rs:285-287 (0 when absent; the empty-term error is raised by the compiler)
+uint32_t clamped_lev(const RequestSearchPart& p) {
+    if (!p.levenshtein_distance) return 0;
+    const size_t chars = vqtext::decode_utf8(vqtext::to_lower_utf8(p.terms.empty() ? std::string() : p.terms[0])).size();
+    if (chars == 0) return 0;
+    return std::min<uint32_t>(*p.levenshtein_distance, uint32_t(chars) - 1);
+}
+
 // expression.rs:48-95 — "x op y", x/y = $SCORE or a float
 void parse_expression(const std::string& expression, DColBoost& cb) {
     struct Tok {
@@ -119,7 +150,10 @@ struct Compiler {
     std::map<std::string, std::map<std::string, std::vector<uint32_t>>> term_id_hits;  // path -> term -> term ids
     uint32_t max_depth = 0;
 
-    Compiler(const Index& i, const Request& r) : idx(i), req(r) {}
+    const FuzzyTable* fuzzy = nullptr;
+    const UnionTable* unions = nullptr;
+
+    Compiler(const Index& i, const Request& r, const FuzzyTable* f) : idx(i), req(r), fuzzy(f) {}
 
     // ------------------------------------------------------------ leaves
     void add_to_cache(const RequestSearchPart& part, bool ids_only) {  // execution_plan.rs:108-130
@@ -152,7 +186,7 @@ struct Compiler {
     }
 
     // get_term_ids_in_field (search_field.rs:277-398) — dictionary side only
-    static void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
+    void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
         const RequestSearchPart& p = l.part;
         if (p.is_regex) unsupported("is_regex");
         if (p.token_value) unsupported("token_value");
@@ -171,33 +205,59 @@ struct Compiler {
         auto dit = idx.dict.find(l.path);
         if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "field does not exist " + l.path + " (fst not found)");
         const Dictionary& dict = dit->second;
-        if (lev != 0 || p.starts_with) unsupported("levenshtein_distance > 0 / starts_with (dictionary scan kernel not in this build)");
-        if (p.top) unsupported("top/skip on a search part");
-
         const bool ci = p.ignore_case.value_or(true);  // search_field.rs:88
         const auto query_cps = vqtext::decode_utf8(p.terms[0]);
         std::vector<uint32_t> cand;
-        if (ci) {
+        const bool scan = lev != 0 || p.starts_with;
+        if (scan) {  // match set computed on the device before compilation (k_dict_scan), ascending == FST stream order
+            const FuzzyProbe* fp = nullptr;
+            if (fuzzy) {
+                auto it = fuzzy->find(fuzzy_key(p));
+                if (it != fuzzy->end()) fp = &it->second;
+            }
+            if (!fp) unsupported("levenshtein_distance > 0 / starts_with without a dictionary scan (internal)");
+            if (fp->status != 0) throw VelociError(fp->status, fp->error);
+            cand = fp->matches;
+        } else if (ci) {
             auto it = dict.lower_map.find(lower_term);
             if (it != dict.lower_map.end()) cand = it->second;
         } else {
             auto it = std::lower_bound(dict.terms.begin(), dict.terms.end(), p.terms[0]);
             if (it != dict.terms.end() && *it == p.terms[0]) cand.push_back(uint32_t(it - dict.terms.begin()));
         }
+        const bool limit_result = p.top.has_value();  // :292
+        const size_t top_n_search = p.top.value_or(10) + p.skip.value_or(0);
+        float worst_score = -std::numeric_limits<float>::max();
+        const bool check_prefix = p.starts_with || lev != 0;  // :302
         for (uint32_t id : cand) {  // ascending ids == FST stream order
-            const auto cps = vqtext::decode_utf8(dict.terms[id]);
-            if (cps.size() != query_cps.size()) continue;
-            bool eq = true;
-            for (size_t i = 0; i < cps.size() && eq; ++i) eq = cp_eq(cps[i], query_cps[i], ci);
-            if (!eq) continue;
+            if (!scan) {
+                const auto cps = vqtext::decode_utf8(dict.terms[id]);
+                if (cps.size() != query_cps.size()) continue;
+                bool eq = true;
+                for (size_t i = 0; i < cps.size() && eq; ++i) eq = cp_eq(cps[i], query_cps[i], ci);
+                if (!eq) continue;
+            }
             if (get_ids) l.hits_ids.push_back(id);
-            if (get_scores) {
-                // distance 0 under the scoring automaton (lowercased hit == lowercased term), no prefix bonus (:302,315-317)
-                const bool same_lower = vqtext::to_lower_utf8(dict.terms[id]) == lower_term;
-                float score = default_score_for_distance(same_lower ? 0 : 1, false);
-                if (p.boost) score *= *p.boost;  // :359-364
+            if (get_scores) {  // :304-354
+                const std::string lower_hit = vqtext::to_lower_utf8(dict.terms[id]);
+                const bool prefix_matches = check_prefix && lower_hit.compare(0, lower_term.size(), lower_term) == 0 && lower_hit.size() >= lower_term.size();
+                const float score = default_score_for_distance(scoring_distance(lower_hit, lower_term, lev), prefix_matches);
+                if (limit_result) {
+                    if (score < worst_score) continue;
+                    if (!l.hits_scores.empty() && l.hits_scores.size() == top_n_search + 200) {  // sort.rs:24-34
+                        std::sort(l.hits_scores.begin(), l.hits_scores.end(), [](auto& a, auto& b) { return a.second == b.second ? a.first > b.first : a.second > b.second; });
+                        l.hits_scores.resize(top_n_search);
+                        worst_score = l.hits_scores.back().second;
+                    }
+                }
                 l.hits_scores.push_back({id, score});
             }
+        }
+        if (p.boost)  // :359-364
+            for (auto& h : l.hits_scores) h.second *= *p.boost;
+        if (limit_result) {  // :373-376 (the reference's sort is unstable: tie order is unspecified there)
+            std::stable_sort(l.hits_scores.begin(), l.hits_scores.end(), [](auto& a, auto& b) { return a.second > b.second; });
+            if (l.hits_scores.size() > top_n_search) l.hits_scores.resize(top_n_search);
         }
     }
     Leaf& field_result(const RequestSearchPart& part) {
@@ -256,7 +316,7 @@ struct Compiler {
             return out;
         }
         const KVStore& t2a = kv_store(l.path + TEXT_ID_TO_ANCHOR);
-        if (!with_multiplicity || (l.hits_ids.size() == 1 && t2a.rows_sorted_unique)) {
+        if ((!with_multiplicity && l.hits_ids.size() <= union_min()) || (l.hits_ids.size() == 1 && t2a.rows_sorted_unique)) {
             for (uint32_t id : l.hits_ids) {
                 if (id < t2a.key_base || id - t2a.key_base >= t2a.num_keys) continue;
                 const uint32_t r = id - t2a.key_base;
@@ -275,6 +335,7 @@ struct Compiler {
             if (t2a.host_row(id, &b, &e)) all.insert(all.end(), b, e);
         }
         std::sort(all.begin(), all.end());
+        if (!with_multiplicity) all.erase(std::unique(all.begin(), all.end()), all.end());  // wide expansion: united on the host
         return layered_inline(all);
     }
     // sorted ids with duplicates -> layers of unique lists (layer j holds the ids occurring more than j times)
@@ -291,6 +352,18 @@ struct Compiler {
         std::vector<uint32_t> out;
         for (auto& l : layers) out.push_back(add_inline_list(std::move(l)));
         return out;
+    }
+
+    static size_t union_min() {  // leaves with more posting lists than this are materialised by k_union first
+        static const size_t v = std::getenv("VQ_UNION_MIN") ? size_t(std::atoi(std::getenv("VQ_UNION_MIN"))) : 4;
+        return v;
+    }
+    static bool has_wide_and(const SearchRequest& r) {
+        if (r.kind == SearchRequest::Search) return false;
+        if (r.kind == SearchRequest::And && r.tree.queries.size() >= 3) return true;
+        for (auto& q : r.tree.queries)
+            if (has_wide_and(q)) return true;
+        return false;
     }
 
     // ------------------------------------------------------------ trees
@@ -335,6 +408,54 @@ struct Compiler {
                 const PostingStore& ps = posting_store(l.path);
                 uint32_t count = 0;
                 uint32_t with_entries = 0;
+                size_t nonempty = 0;
+                for (auto& [tid, score] : l.hits_scores)
+                    if (tid < ps.num_tokens && ps.len[tid]) ++nonempty;
+                if (nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req))) {
+                    // K2: the leaf's hits are materialised once per batch (union, max per doc) and scanned as one list
+                    UnionJob job;
+                    job.store_path = l.path + TO_ANCHOR_ID_SCORE;
+                    key_s(job.key, job.store_path);
+                    for (auto& [tid, score] : l.hits_scores)
+                        if (tid < ps.num_tokens && ps.len[tid]) {
+                            job.terms.push_back({tid, score});
+                            job.key += std::to_string(tid) + ":";
+                            key_f(job.key, score);
+                            job.input_postings += ps.len[tid];
+                        }
+                    const UnionJob* done = nullptr;
+                    if (unions) {
+                        auto it = unions->find(job.key);
+                        if (it != unions->end()) done = &it->second;
+                    }
+                    info.glen = 0;
+                    if (!done) {
+                        cq.union_requests.push_back(std::move(job));  // compiled again after the jobs ran
+                        info.len_known = true;
+                    } else {
+                        if (done->len) {
+                            HList h;
+                            h.d_docs = done->d_docs;
+                            h.d_scores = reinterpret_cast<const uint16_t*>(done->d_vals);
+                            h.len = done->len;
+                            h.global_len = done->len;
+                            h.flags = LIST_HAS_SCORES | LIST_F32;
+                            h.term_score = 1.0f;
+                            uint32_t li = add_list(h);
+                            info.cover.push_back(li);
+                            info.cover_len += h.len;
+                            count = 1;
+                        }
+                        cq.algorithmic_bytes += 6ull * done->input_postings + 8ull * done->len;
+                        info.glen = done->len;
+                        // the merged length is this shard's only: known globally when the index is not sharded
+                        info.len_known = !req.filter && idx.doc_lo == 0 && idx.doc_hi == idx.num_anchors;
+                    }
+                    op.list_count = uint16_t(count);
+                    push_op(ops, op, sp);
+                    info.emitted = true;
+                    return info;
+                }
                 for (auto& [tid, score] : l.hits_scores) {
                     if (tid >= ps.num_tokens) continue;
                     if (ps.global_len[tid]) ++with_entries;
@@ -721,7 +842,9 @@ struct Compiler {
         build_presence_program();
         {  // shape that the kernel scores without the interpreter: <= 4 single-list posting leaves under one AND/OR
             const size_t n = cq.ops.size();
-            auto is_leaf1 = [&](const DOp& o) { return o.kind == OP_LEAF && o.list_count == 1 && (cq.lists[o.list_begin].flags & LIST_HAS_SCORES); };
+            auto is_leaf1 = [&](const DOp& o) {
+                return o.kind == OP_LEAF && o.list_count == 1 && (cq.lists[o.list_begin].flags & LIST_HAS_SCORES) && !(cq.lists[o.list_begin].flags & LIST_F32);
+            };
             if (n == 1 && is_leaf1(cq.ops[0])) cq.simple_n = 1;
             else if (n >= 3 && n <= 5 && cq.ops[n - 1].kind != OP_LEAF && cq.ops[n - 1].nchild == n - 1) {
                 bool ok = true;
@@ -795,10 +918,76 @@ struct Compiler {
 
 }  // namespace
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req) {
-    Compiler c(idx, req);
+// ---- dictionary scans requested by a batch (collected before compilation, answered by k_dict_scan)
+std::string fuzzy_key(const RequestSearchPart& p) {
+    std::string path = p.path;
+    if (!ends_with(path, TEXTINDEX)) path += TEXTINDEX;
+    std::string k;
+    key_s(k, path);
+    key_s(k, p.terms.empty() ? std::string() : p.terms[0]);
+    k += std::to_string(clamped_lev(p)) + (p.starts_with ? "p" : "-") + (p.ignore_case ? (*p.ignore_case ? "T" : "F") : "N");
+    return k;
+}
+bool needs_dictionary_scan(const RequestSearchPart& p) { return !p.terms.empty() && (clamped_lev(p) != 0 || p.starts_with); }
+
+static void probe_part(const Index& idx, const RequestSearchPart& p, FuzzyTable& table) {
+    if (!needs_dictionary_scan(p)) return;
+    const std::string key = fuzzy_key(p);
+    if (table.count(key)) return;
+    FuzzyProbe fp;
+    fp.key = key;
+    fp.path = p.path;
+    if (!ends_with(fp.path, TEXTINDEX)) fp.path += TEXTINDEX;
+    auto dit = idx.dict.find(fp.path);
+    if (dit == idx.dict.end()) return;  // the compiler reports FstNotFound
+    // match-set automaton (search_field.rs:85-95): built from the ORIGINAL term
+    fp.max_d = std::min<uint32_t>(clamped_lev(p), 4);
+    fp.transposition = p.ignore_case.value_or(false);
+    fp.ci = p.ignore_case.value_or(true);
+    fp.prefix = p.starts_with;
+    const auto cps = vqtext::decode_utf8(p.terms[0]);
+    if (!dit->second.bmp_only) {
+        fp.status = ERR_UNSUPPORTED;
+        fp.error = "fuzzy / prefix search on " + fp.path + ": dictionary holds code points above U+FFFF";
+    } else if (cps.size() > 64) {
+        fp.status = ERR_UNSUPPORTED;
+        fp.error = "fuzzy / prefix search with a term longer than 64 characters";
+    }
+    for (uint32_t cp : cps) {
+        if (cp > 0xFFFFu && fp.status == 0) {
+            fp.status = ERR_UNSUPPORTED;
+            fp.error = "fuzzy / prefix search with a code point above U+FFFF";
+        }
+        fp.query.push_back(uint16_t(fp.ci ? vqtext::lower_cp(cp) : cp));
+    }
+    table.emplace(key, std::move(fp));
+}
+static void probe_tree(const Index& idx, const SearchRequest& r, FuzzyTable& table) {
+    if (r.kind == SearchRequest::Search) probe_part(idx, r.part, table);
+    else
+        for (auto& q : r.tree.queries) probe_tree(idx, q, table);
+}
+void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& table) {
+    if (req.search_req) probe_tree(idx, *req.search_req, table);
+    if (req.filter) probe_tree(idx, *req.filter, table);
+    if (req.phrase_boosts)
+        for (auto& pb : *req.phrase_boosts) {
+            probe_part(idx, pb.search1, table);
+            probe_part(idx, pb.search2, table);
+        }
+    if (req.boost_term)
+        for (auto& p : *req.boost_term) probe_part(idx, p, table);
+}
+
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions) {
+    Compiler c(idx, req, fuzzy);
+    c.unions = unions;
     try {
         c.run();
+        if (!c.cq.union_requests.empty()) {
+            c.cq.status = kStatusNeedsUnion;
+            c.cq.error = "internal: union jobs pending";
+        }
     } catch (const VelociError& e) {
         c.cq.status = e.code;
         c.cq.error = e.what();

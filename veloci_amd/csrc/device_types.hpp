@@ -29,6 +29,7 @@ enum ListFlags : uint32_t {
     LIST_HAS_SCORES = 1u,  // posting list: f16 anchor scores, value = term_score * (f16 / 100)
     LIST_COVER = 2u,       // part of the cover set that decides which tiles are visited
     LIST_BITMAP = 4u,      // a bitmap image of the list exists in HBM (dense lists): tiles are copied, not scattered
+    LIST_F32 = 8u,         // materialised leaf (k_union): scores are final f32 values, term_score is not applied
 };
 
 struct DList {  // 48 B

@@ -108,10 +108,47 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct Dictionary {  // term dictionary of one text field (host side: exact lookups; device side: fuzzy scan, later)
+struct Dictionary {  // term dictionary of one text field
     std::vector<std::string> terms;
-    std::unordered_map<std::string, std::vector<uint32_t>> lower_map;  // lowercase(term) -> ascending term ids
+    std::unordered_map<std::string, std::vector<uint32_t>> lower_map;  // lowercase(term) -> ascending term ids (exact lookups)
+    // device image for the fuzzy / prefix scan (k_dict_scan): code points as u16, raw and lower-cased
+    bool bmp_only = true;  // false: some term has a code point above U+FFFF -> no device image, fuzzy unsupported on this field
+    DevBuf d_off;          // u32 [T + 1]
+    DevBuf d_raw;          // u16
+    DevBuf d_low;          // u16
 };
+
+struct Index;
+struct FuzzyProbe {  // one dictionary scan of a batch (get_text_lines_from_fst, search_field.rs:68-99)
+    std::string key;
+    std::string path;                 // "<field>.textindex"
+    std::vector<uint16_t> query;      // code points of the ORIGINAL term (lower-cased when case-insensitive)
+    uint32_t max_d = 0;
+    bool transposition = false, prefix = false, ci = true;
+    std::vector<uint32_t> matches;    // ascending term ids == FST stream order
+    int status = 0;
+    std::string error;
+};
+using FuzzyTable = std::map<std::string, FuzzyProbe>;
+std::string fuzzy_key(const vqreq::RequestSearchPart& p);
+bool needs_dictionary_scan(const vqreq::RequestSearchPart& p);
+void collect_fuzzy_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
+void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st);
+
+// A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the
+// terms' posting lists with the per-doc maximum of term_score * (f16 / 100).
+struct UnionJob {
+    std::string key;
+    std::string store_path;                            // "<field>.textindex.to_anchor_id_score"
+    std::vector<std::pair<uint32_t, float>> terms;     // (token id, term score) with entries in this shard
+    // result (valid until the batch that ran it is finished; lives in the batch workspace)
+    const uint32_t* d_docs = nullptr;
+    const float* d_vals = nullptr;
+    uint32_t len = 0;
+    uint64_t input_postings = 0;
+};
+using UnionTable = std::map<std::string, UnionJob>;
+constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union jobs have run
 
 struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segmented arrays in HBM
     uint32_t num_tokens = 0;
@@ -192,6 +229,7 @@ struct Workspace {  // scratch of one in-flight batch
     DevBuf d_partial;
     DevBuf d_hist_sum;
     DevBuf d_down;      // results
+    DevBuf d_union_docs[2], d_union_vals[2], d_union_meta;  // materialised leaves (k_union), level 1 / level 2
 };
 
 struct Profile {
@@ -249,6 +287,7 @@ struct FacetOut {
 struct CompiledQuery {
     int status = 0;
     std::string error;
+    std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
     std::vector<HList> lists;
     std::vector<std::vector<uint32_t>> inline_lists;
     std::vector<DOp> ops, fops;
@@ -269,7 +308,8 @@ struct CompiledQuery {
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
 };
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req);
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr);
+void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 
 // ------------------------------------------------------------------ results
 struct ResultFacet {

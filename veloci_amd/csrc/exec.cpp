@@ -116,6 +116,206 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     return off;
 }
 
+// Answer every dictionary scan of a batch with k_dict_scan launches (grid.y = probe), then bring the match
+// sets back sorted ascending (== FST stream order, which is what the reference's callback order is).
+void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
+    std::vector<FuzzyProbe*> todo;
+    for (auto& kv : table)
+        if (kv.second.status == 0) todo.push_back(&kv.second);
+    if (todo.empty()) return;
+    std::vector<uint32_t> cap(todo.size(), 0u);
+    for (size_t i = 0; i < todo.size(); ++i) cap[i] = std::min<uint32_t>(uint32_t(idx.dict.at(todo[i]->path).terms.size()), 1u << 16);
+    std::vector<size_t> active(todo.size());
+    for (size_t i = 0; i < todo.size(); ++i) active[i] = i;
+    for (int pass = 0; pass < 2 && !active.empty(); ++pass) {  // pass 1 re-runs the probes whose match set outgrew the first guess
+        const size_t chunk = 4096;                               // probes per launch (grid.y limit 65535, bounded scratch)
+        std::vector<size_t> overflow;
+        for (size_t c0 = 0; c0 < active.size(); c0 += chunk) {
+            const size_t c1 = std::min(active.size(), c0 + chunk);
+            std::vector<DictProbe> probes(c1 - c0);
+            std::vector<uint64_t> out_off(c1 - c0 + 1, 0);
+            uint32_t max_terms = 0;
+            for (size_t i = c0; i < c1; ++i) out_off[i - c0 + 1] = out_off[i - c0] + cap[active[i]];
+            DevBuf d_probes, d_counts, d_ids;
+            d_probes.alloc(probes.size() * sizeof(DictProbe));
+            d_counts.alloc(probes.size() * 4 + 16);
+            d_ids.alloc(out_off.back() * 4 + 16);
+            for (size_t i = c0; i < c1; ++i) {
+                const FuzzyProbe& fp = *todo[active[i]];
+                const Dictionary& d = idx.dict.at(fp.path);
+                DictProbe& P = probes[i - c0];
+                std::memset(&P, 0, sizeof P);
+                P.off = d.d_off.as<uint32_t>();
+                P.chars = fp.ci ? d.d_low.as<uint16_t>() : d.d_raw.as<uint16_t>();
+                P.num_terms = uint32_t(d.terms.size());
+                P.m = uint32_t(fp.query.size());
+                P.max_d = fp.max_d;
+                P.flags = (fp.transposition ? 1u : 0u) | (fp.prefix ? 2u : 0u);
+                P.out_cap = cap[active[i]];
+                P.out_count = d_counts.as<uint32_t>() + (i - c0);
+                P.out_ids = d_ids.as<uint32_t>() + out_off[i - c0];
+                for (size_t j = 0; j < fp.query.size(); ++j) P.query[j] = fp.query[j];
+                max_terms = std::max(max_terms, P.num_terms);
+            }
+            VQ_HIP(hipMemsetAsync(d_counts.p, 0, probes.size() * 4, st));
+            VQ_HIP(hipMemcpyAsync(d_probes.p, probes.data(), probes.size() * sizeof(DictProbe), hipMemcpyHostToDevice, st));
+            launch_dict_scan(st, d_probes.as<DictProbe>(), uint32_t(probes.size()), max_terms);
+            VQ_HIP(hipGetLastError());
+            std::vector<uint32_t> counts(probes.size());
+            VQ_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
+            VQ_HIP(hipStreamSynchronize(st));
+            for (size_t i = c0; i < c1; ++i) {
+                FuzzyProbe& fp = *todo[active[i]];
+                const uint32_t cnt = counts[i - c0];
+                if (cnt > cap[active[i]]) {
+                    cap[active[i]] = cnt;
+                    overflow.push_back(active[i]);
+                    continue;
+                }
+                fp.matches.resize(cnt);
+                if (cnt) VQ_HIP(hipMemcpy(fp.matches.data(), d_ids.as<uint32_t>() + out_off[i - c0], size_t(cnt) * 4, hipMemcpyDeviceToHost));
+                std::sort(fp.matches.begin(), fp.matches.end());
+            }
+        }
+        active.swap(overflow);
+    }
+}
+
+// K2: run the union jobs of a batch.  Level 1 merges groups of <= 64 posting lists (one lane per list); a job with
+// more lists gets a level-2 task over the level-1 outputs.  Each level: count pass -> host prefix sums -> write pass.
+namespace {
+struct UnionTaskH {
+    std::vector<UList> lists;
+    UnionJob* job = nullptr;   // level 1: set when this task IS the job's result (<= 64 lists); level 2: always
+    size_t parent = SIZE_MAX;  // level 1: index of the level-2 task that consumes this output
+    uint64_t out_off = 0;
+    uint32_t len = 0;
+};
+
+void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals, DevBuf& meta, hipStream_t st) {
+    if (tasks.empty()) return;
+    std::vector<UList> ulists;
+    std::vector<UTask> utasks;
+    std::vector<uint32_t> span_task;
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        UTask u{};
+        u.list_begin = uint32_t(ulists.size());
+        u.n_lists = uint32_t(tasks[t].lists.size());
+        uint64_t total = 0;
+        uint32_t piv = 0;
+        for (uint32_t i = 0; i < u.n_lists; ++i) {
+            total += tasks[t].lists[i].len;
+            if (tasks[t].lists[i].len > tasks[t].lists[piv].len) piv = i;
+            ulists.push_back(tasks[t].lists[i]);
+        }
+        u.pivot = u.list_begin + piv;
+        uint64_t spans = std::min<uint64_t>(std::max<uint64_t>(total / 16384, 1), 256);
+        spans = std::min<uint64_t>(spans, std::max<uint32_t>(tasks[t].lists[piv].len, 1u));
+        u.span_begin = uint32_t(span_task.size());
+        u.n_spans = uint32_t(spans);
+        for (uint32_t k = 0; k < u.n_spans; ++k) span_task.push_back(uint32_t(t));
+        utasks.push_back(u);
+    }
+    const size_t n_spans = span_task.size();
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_lists = 0, o_tasks = al(ulists.size() * sizeof(UList)), o_st = o_tasks + al(utasks.size() * sizeof(UTask)),
+                 o_cnt = o_st + al(n_spans * 4), o_off = o_cnt + al(n_spans * 4), bytes = o_off + al(n_spans * 8);
+    meta.ensure(bytes);
+    uint8_t* m = meta.as<uint8_t>();
+    VQ_HIP(hipMemcpyAsync(m + o_lists, ulists.data(), ulists.size() * sizeof(UList), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_tasks, utasks.data(), utasks.size() * sizeof(UTask), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_st, span_task.data(), n_spans * 4, hipMemcpyHostToDevice, st));
+    auto launch = [&](bool write) {
+        launch_union(st, write, uint32_t(n_spans), reinterpret_cast<const UList*>(m + o_lists), reinterpret_cast<const UTask*>(m + o_tasks),
+                     reinterpret_cast<const uint32_t*>(m + o_st), reinterpret_cast<uint32_t*>(m + o_cnt), reinterpret_cast<const uint64_t*>(m + o_off),
+                     docs.as<uint32_t>(), vals.as<float>());
+        VQ_HIP(hipGetLastError());
+    };
+    launch(false);
+    std::vector<uint32_t> cnt(n_spans);
+    VQ_HIP(hipMemcpyAsync(cnt.data(), m + o_cnt, n_spans * 4, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> off(n_spans);
+    uint64_t cursor = 0;
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        tasks[t].out_off = cursor;
+        uint64_t len = 0;
+        for (uint32_t k = 0; k < utasks[t].n_spans; ++k) {
+            off[utasks[t].span_begin + k] = cursor + len;
+            len += cnt[utasks[t].span_begin + k];
+        }
+        if (len > 0xFFFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "materialised leaf longer than 2^32 entries");
+        tasks[t].len = uint32_t(len);
+        cursor += (len + 8 + 3) / 4 * 4;  // 8 sentinel entries behind every list, starts stay 16-byte aligned
+    }
+    docs.ensure(cursor * 4 + 64);
+    vals.ensure(cursor * 4 + 64);
+    VQ_HIP(hipMemcpyAsync(m + o_off, off.data(), n_spans * 8, hipMemcpyHostToDevice, st));
+    launch(true);
+}
+}  // namespace
+
+void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st) {
+    std::vector<UnionTaskH> l1, l2;
+    for (auto& kv : table) {
+        UnionJob& job = kv.second;
+        const PostingStore& ps = idx.postings.at(job.store_path);
+        std::vector<UList> raw;
+        for (auto& [tid, score] : job.terms) {
+            UList u{};
+            u.docs = ps.docs.as<uint32_t>() + ps.start[tid];
+            u.scores = ps.scores.as<uint16_t>() + ps.start[tid];
+            u.len = ps.len[tid];
+            u.term_score = score;
+            raw.push_back(u);
+        }
+        if (raw.size() > 64 * 64) throw VelociError(ERR_UNSUPPORTED, "leaf expansion with more than 4096 posting lists");
+        if (raw.size() <= 64) {
+            UnionTaskH t;
+            t.lists = std::move(raw);
+            t.job = &job;
+            l1.push_back(std::move(t));
+        } else {
+            UnionTaskH top;
+            top.job = &job;
+            for (size_t b = 0; b < raw.size(); b += 64) {
+                UnionTaskH t;
+                t.lists.assign(raw.begin() + b, raw.begin() + std::min(raw.size(), b + 64));
+                t.parent = l2.size();
+                l1.push_back(std::move(t));
+            }
+            l2.push_back(std::move(top));
+        }
+    }
+    run_union_level(l1, ws.d_union_docs[0], ws.d_union_vals[0], ws.d_union_meta, st);
+    for (auto& t : l1) {
+        const uint32_t* d = ws.d_union_docs[0].as<uint32_t>() + t.out_off;
+        const float* v = ws.d_union_vals[0].as<float>() + t.out_off;
+        if (t.job) {
+            t.job->d_docs = d;
+            t.job->d_vals = v;
+            t.job->len = t.len;
+        } else {
+            UList u{};
+            u.docs = d;
+            u.scores = v;
+            u.len = t.len;
+            u.term_score = 1.0f;
+            u.flags = 1u;
+            l2[t.parent].lists.push_back(u);
+        }
+    }
+    if (!l2.empty()) {
+        VQ_HIP(hipStreamSynchronize(st));  // the level-2 meta upload reuses the level-1 meta buffer
+        run_union_level(l2, ws.d_union_docs[1], ws.d_union_vals[1], ws.d_union_meta, st);
+        for (auto& t : l2) {
+            t.job->d_docs = ws.d_union_docs[1].as<uint32_t>() + t.out_off;
+            t.job->d_vals = ws.d_union_vals[1].as<float>() + t.out_off;
+            t.job->len = t.len;
+        }
+    }
+}
+
 static bool timing_enabled() {
     static const bool on = std::getenv("VQ_TIMING") != nullptr;
     return on;
@@ -134,7 +334,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     Workspace& ws = *pb->ws;
     hipStream_t st = idx.stream;
 
-    // ---- compile
+    // ---- dictionary scans (fuzzy / prefix leaves) of the whole batch, then compile
+    FuzzyTable fuzzy;
+    for (size_t i = 0; i < n; ++i)
+        if (reqs[i]) collect_fuzzy_probes(idx, *reqs[i], fuzzy);
+    if (!fuzzy.empty()) run_fuzzy_probes(idx, fuzzy, st);
     pb->queries.reserve(n);
     pb->slot.assign(n, UINT32_MAX);
     pb->queries.resize(n);
@@ -143,7 +347,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             if (!reqs[i]) {
                 pb->queries[i].status = ERR_INVALID_ARGUMENT;
                 pb->queries[i].error = "null request";
-            } else pb->queries[i] = compile_query(idx, *reqs[i]);
+            } else pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy);
         }
     };
     if (n >= 256) {  // query compilation is independent per request: fan out over a few host threads
@@ -153,6 +357,34 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         compile_range(0, n / nt);
         for (auto& t : th) t.join();
     } else compile_range(0, n);
+    // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch, compile those queries again
+    UnionTable unions;
+    std::vector<size_t> again;
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == kStatusNeedsUnion) {
+            again.push_back(i);
+            for (auto& j : pb->queries[i].union_requests) unions.emplace(j.key, j);
+        }
+    if (!again.empty()) {
+        run_union_jobs(idx, ws, unions, st);
+        auto recompile = [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                CompiledQuery& q = pb->queries[again[k]];
+                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, &unions);
+                if (q.status == kStatusNeedsUnion) {
+                    q.status = ERR_UNSUPPORTED;
+                    q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
+                }
+            }
+        };
+        if (again.size() >= 64) {
+            const size_t nt = 4;
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; ++t) th.emplace_back(recompile, again.size() * t / nt, again.size() * (t + 1) / nt);
+            recompile(0, again.size() / nt);
+            for (auto& t : th) t.join();
+        } else recompile(0, again.size());
+    }
     const double t_compiled = now_ms();
     // ---- layout
     uint32_t nq = 0;

@@ -131,6 +131,27 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         d.terms = f.terms;
         d.lower_map.reserve(d.terms.size());
         for (uint32_t i = 0; i < d.terms.size(); ++i) d.lower_map[vqtext::to_lower_utf8(d.terms[i])].push_back(i);
+        {  // device image for k_dict_scan: code points as u16 (raw + lower-cased), CSR over the terms
+            std::vector<uint32_t> off(d.terms.size() + 1, 0u);
+            std::vector<uint16_t> raw, low;
+            for (uint32_t i = 0; i < d.terms.size(); ++i) {
+                for (uint32_t cp : vqtext::decode_utf8(d.terms[i])) {
+                    if (cp > 0xFFFFu) d.bmp_only = false;
+                    raw.push_back(uint16_t(cp));
+                    low.push_back(uint16_t(vqtext::lower_cp(cp)));
+                }
+                off[i + 1] = uint32_t(raw.size());
+            }
+            if (d.bmp_only) {
+                d.d_off.alloc(off.size() * 4 + 16);
+                d.d_off.upload(off.data(), off.size() * 4);
+                d.d_raw.alloc(raw.size() * 2 + 16);
+                d.d_raw.upload(raw.data(), raw.size() * 2);
+                d.d_low.alloc(low.size() * 2 + 16);
+                d.d_low.upload(low.data(), low.size() * 2);
+                idx->device_bytes += d.d_off.bytes + d.d_raw.bytes + d.d_low.bytes;
+            }
+        }
         idx->dict.emplace(path, std::move(d));
     }
 

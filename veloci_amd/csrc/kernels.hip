@@ -322,7 +322,8 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
                     if (c.lists[li].flags & LIST_HAS_SCORES) {
                         const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
                         const uint32_t idx = c.cur[li] + c.cnt_lo[li] + rank;
-                        v = posting_value(c.lists[li].term_score, as_global(c.lists[li].scores)[idx]);
+                        if (c.lists[li].flags & LIST_F32) v = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[idx];
+                        else v = posting_value(c.lists[li].term_score, as_global(c.lists[li].scores)[idx]);
                     }
                     if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
                     present = true;
@@ -1472,6 +1473,202 @@ void launch_scan_simple(hipStream_t st, bool dense, uint32_t total_spans, const 
         hipLaunchKernelGGL(k_scan_simple<true>, dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
     else
         hipLaunchKernelGGL(k_scan_simple<false>, dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+}
+
+}  // namespace vq
+
+// ====================================================================================================
+// k_dict_scan (K9) — fuzzy / prefix term expansion: one lane per dictionary term, Myers / Hyyrö bit-vector
+// edit distance of the query (pattern, <= 64 code points) against the term (text).  Decides exactly what the
+// reference's Levenshtein DFA accepts (search_field.rs:85-95): distance(term, query) <= max_d, with adjacent
+// transpositions at cost one when requested, or — for starts_with — the minimum over all prefixes of the term.
+// Code points are compared as stored (the host hands over the lower-cased image for case-insensitive scans).
+// ====================================================================================================
+namespace vq {
+
+__global__ __launch_bounds__(256) void k_dict_scan(const DictProbe* __restrict__ probes) {
+    const DictProbe& P = probes[blockIdx.y];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint16_t q[64];
+    if (threadIdx.x < 64) q[threadIdx.x] = P.query[threadIdx.x];
+    __syncthreads();
+    if (t >= P.num_terms) return;
+    const uint32_t m = P.m, max_d = P.max_d;
+    const bool transposition = P.flags & 1u, prefix = P.flags & 2u;
+    const uint32_t b = P.off[t], e = P.off[t + 1];
+    const uint32_t n = e - b;
+    if (!prefix && (n > m + max_d || n + max_d < m)) return;  // length filter
+    bool match;
+    if (m == 0) {
+        match = prefix || n <= max_d;
+    } else {
+        const unsigned long long top = 1ull << (m - 1);
+        unsigned long long Pv = m == 64 ? ~0ull : ((1ull << m) - 1ull), Mv = 0ull, prevEq = 0ull, prevD0 = ~0ull;
+        uint32_t score = m;
+        uint32_t best = m;  // distance of the empty prefix
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint16_t c = P.chars[b + i];
+            unsigned long long Eq = 0ull;
+            for (uint32_t j = 0; j < m; ++j) Eq |= (unsigned long long)(q[j] == c) << j;
+            unsigned long long D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
+            if (transposition) D0 |= (((~prevD0) & Eq) << 1) & prevEq;  // Hyyrö 2003: adjacent transposition, cost one
+            unsigned long long Ph = Mv | ~(D0 | Pv);
+            unsigned long long Mh = Pv & D0;
+            if (Ph & top) ++score;
+            else if (Mh & top) --score;
+            Ph = (Ph << 1) | 1ull;
+            Mh <<= 1;
+            Pv = Mh | ~(D0 | Ph);
+            Mv = Ph & D0;
+            prevEq = Eq;
+            prevD0 = D0;
+            best = score < best ? score : best;
+        }
+        match = (prefix ? best : score) <= max_d;
+    }
+    if (match) {
+        const uint32_t pos = atomicAdd(P.out_count, 1u);
+        if (pos < P.out_cap) P.out_ids[pos] = t;
+    }
+}
+
+void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t n_probes, uint32_t max_terms) {
+    if (!n_probes || !max_terms) return;
+    hipLaunchKernelGGL(k_dict_scan, dim3((max_terms + 255u) / 256u, n_probes), dim3(256), 0, st, d_probes);
+}
+
+}  // namespace vq
+
+// ====================================================================================================
+// k_union (K2) — multi-list union with per-doc max: materialises the hits of a leaf whose dictionary
+// expansion matched many terms (resolve_token_to_anchor, search_field.rs:419-464: every posting becomes
+// Hit(doc, term_score * (f16 / 100)), then sort by doc and dedup keeping the max).  One wave per span of the
+// job's doc space; lane l walks list l (<= 64 lists per task, wider leaves are merged in two levels) through a
+// 16-entry LDS window; each step takes the wave-wide minimum of the 64-bit heads (doc << 32 | ~order(score)),
+// which yields the next doc AND its maximal score in one reduction.  Run twice: count, then write.
+// ====================================================================================================
+namespace vq {
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long x) {
+#define VQ_MIN_STEP(ctrl, rm, bm)                                                                                       \
+    {                                                                                                                   \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)x, ctrl, rm, bm, false);           \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(x >> 32), ctrl, rm, bm, false);  \
+        const unsigned long long y = ((unsigned long long)hi << 32) | lo;                                               \
+        x = y < x ? y : x;                                                                                              \
+    }
+    VQ_MIN_STEP(0x111, 0xF, 0xF)  // row_shr:1
+    VQ_MIN_STEP(0x112, 0xF, 0xF)  // row_shr:2
+    VQ_MIN_STEP(0x114, 0xF, 0xE)  // row_shr:4
+    VQ_MIN_STEP(0x118, 0xF, 0xC)  // row_shr:8
+    VQ_MIN_STEP(0x142, 0xA, 0xF)  // row_bcast:15
+    VQ_MIN_STEP(0x143, 0xC, 0xF)  // row_bcast:31
+#undef VQ_MIN_STEP
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t lane_lower_bound(const VQ_GLOBAL uint32_t* a, uint32_t n, uint32_t target) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+constexpr uint32_t kUnionWindow = 16;
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_union(const UList* __restrict__ ulists, const UTask* __restrict__ tasks, const uint32_t* __restrict__ span_task,
+                                              uint32_t* __restrict__ span_cnt, const uint64_t* __restrict__ span_off, uint32_t* __restrict__ out_docs,
+                                              float* __restrict__ out_vals) {
+    __shared__ unsigned long long win[kUnionWindow][64];
+    const uint32_t span = blockIdx.x, lane = threadIdx.x;
+    const UTask task = tasks[span_task[span]];
+    const uint32_t s = span - task.span_begin;
+    // span bounds in doc space: quantiles of the task's longest list
+    uint32_t lo_doc = 0u, hi_doc = 0xFFFFFFFFu;
+    {
+        const UList piv = ulists[task.pivot];
+        const VQ_GLOBAL uint32_t* pd = as_global(piv.docs);
+        if (s > 0) lo_doc = pd[(unsigned long long)piv.len * s / task.n_spans];
+        if (s + 1 < task.n_spans) hi_doc = pd[(unsigned long long)piv.len * (s + 1) / task.n_spans];
+    }
+    UList L{};
+    uint32_t pos = 0, end = 0;
+    if (lane < task.n_lists) {
+        L = ulists[task.list_begin + lane];
+        const VQ_GLOBAL uint32_t* d = as_global(L.docs);
+        pos = lane_lower_bound(d, L.len, lo_doc);
+        end = hi_doc == 0xFFFFFFFFu ? L.len : lane_lower_bound(d, L.len, hi_doc);
+    }
+    const VQ_GLOBAL uint32_t* docs = as_global(L.docs);
+    const VQ_GLOBAL uint16_t* s16 = as_global(reinterpret_cast<const uint16_t*>(L.scores));
+    const VQ_GLOBAL float* s32 = as_global(reinterpret_cast<const float*>(L.scores));
+    const bool f32 = L.flags & 1u;
+    uint32_t wbase = pos;  // list index of window slot 0
+    auto refill = [&]() {
+        wbase = pos;
+#pragma unroll
+        for (uint32_t k = 0; k < kUnionWindow; ++k) {
+            const uint32_t i = pos + k;
+            if (i < end) {
+                const float v = f32 ? s32[i] : posting_value(L.term_score, s16[i]);
+                win[k][lane] = ((unsigned long long)docs[i] << 32) | (uint32_t)~order_f32(__float_as_uint(v));
+            }
+        }
+    };
+    unsigned long long head = ~0ull;
+    if (pos < end) {
+        refill();
+        head = win[0][lane];
+    }
+    const uint64_t base = WRITE ? span_off[span] : 0ull;
+    uint32_t n = 0;
+    unsigned long long pending = 0ull;
+    while (true) {
+        const unsigned long long m = wave_min_u64(head);
+        if (m == ~0ull) break;
+        if (WRITE) {
+            if ((n & 63u) == lane) pending = m;
+            if ((n & 63u) == 63u) {
+                out_docs[base + (n - 63u) + lane] = (uint32_t)(pending >> 32);
+                out_vals[base + (n - 63u) + lane] = __uint_as_float(unorder_f32(~(uint32_t)pending));
+            }
+        }
+        ++n;
+        if ((head >> 32) == (m >> 32)) {  // every list holding this doc moves on
+            ++pos;
+            if (pos >= end) head = ~0ull;
+            else {
+                if (pos - wbase >= kUnionWindow) refill();
+                head = win[pos - wbase][lane];
+            }
+        }
+    }
+    if (WRITE) {
+        const uint32_t done = n & ~63u;
+        if (lane < (n & 63u)) {
+            out_docs[base + done + lane] = (uint32_t)(pending >> 32);
+            out_vals[base + done + lane] = __uint_as_float(unorder_f32(~(uint32_t)pending));
+        }
+        if (s + 1 == task.n_spans && lane < 8u) {  // list padding: sentinel docs up to the vector width and beyond
+            out_docs[base + n + lane] = 0xFFFFFFFFu;
+            out_vals[base + n + lane] = 0.0f;
+        }
+    } else if (lane == 0) {
+        span_cnt[span] = n;
+    }
+}
+
+void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList* ulists, const UTask* tasks, const uint32_t* span_task, uint32_t* span_cnt,
+                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals) {
+    if (!total_spans) return;
+    if (write) hipLaunchKernelGGL(k_union<true>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals);
+    else hipLaunchKernelGGL(k_union<false>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals);
 }
 
 }  // namespace vq

@@ -8,6 +8,29 @@
 
 namespace vq {
 
+struct DictProbe {  // one fuzzy / prefix scan of a dictionary (k_dict_scan)
+    const uint32_t* off;    // u32 [num_terms + 1] into chars
+    const uint16_t* chars;  // code points (raw or lower-cased image)
+    uint32_t num_terms, m, max_d, flags;  // flags: 1 transposition costs one, 2 prefix (starts_with)
+    uint32_t out_cap, pad;
+    uint32_t* out_count;
+    uint32_t* out_ids;
+    uint16_t query[64];
+};
+
+struct UList {  // one input list of a union task (k_union)
+    const uint32_t* docs;
+    const void* scores;  // f16 anchor scores, or f32 values when flags & 1 (output of an earlier level)
+    uint32_t len;
+    float term_score;
+    uint32_t flags, pad;
+};
+struct UTask {  // <= 64 lists merged by one wave per span
+    uint32_t list_begin, n_lists;  // into the UList table
+    uint32_t span_begin, n_spans;  // global span index of span 0; spans split the doc space at quantiles of list `pivot`
+    uint32_t pivot, pad;           // absolute UList index of the longest list
+};
+
 struct FacetJob {
     uint32_t hist_off, num_values, top, out_off;
 };
@@ -27,6 +50,10 @@ void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const ui
 void launch_hist_reduce(hipStream_t st, const uint8_t* gathered, uint32_t num_shards, const PartialLayout& lay, uint32_t* out);
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n);
+
+void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList* ulists, const UTask* tasks, const uint32_t* span_task, uint32_t* span_cnt,
+                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals);
+void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t n_probes, uint32_t max_terms);
 
 #ifdef VQ_STAMP
 void debug_read_stamps(unsigned long long* out, int reset);
