@@ -354,3 +354,42 @@ def test_fuzzy_batch_and_clamp(words):
     got = veloci_amd.search_batch(reqs, idx)
     for r, g in zip(reqs, got):
         assert_same(r, g, ora.search_json(json.dumps(r)))
+
+
+# ------------------------------------------------------------------ the reference's integration tests, replayed (GPU half)
+import refcases  # noqa: E402
+
+REF_CASES = refcases.load()["cases"]
+# requests the MI355X path declines (VQ_ERR_UNSUPPORTED -> the caller keeps its CPU path)
+GPU_DECLINES = {
+    "search_and_boost_1_n": "1:n field boost",
+    "search_and_double_boost": "1:n field boost",
+    "or_connect_search_and_boost_anchor": "1:n field boost",
+    "boost_text_localitaet": "text_locality on a field that is not an anchor identity column",
+    "facet_without_facet_index": "n-step join",
+}
+_REF_IDX = {}
+
+
+@pytest.mark.parametrize("case", REF_CASES, ids=[c["name"] for c in REF_CASES])
+def test_reference_integration_case(case):
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    name = case["corpus"]
+    if name not in _REF_IDX:
+        data, docs, info = refcases.build(name)
+        ora = O.OracleIndex(data.num_anchors)
+        data.load_into(ora)
+        _REF_IDX[name] = (veloci_amd.Index(data, device=0), ora, docs, info)
+    idx, ora, docs, info = _REF_IDX[name]
+    run = lambda req: veloci_amd.search(req, idx)
+    if case["name"] in GPU_DECLINES:
+        with pytest.raises(veloci_amd.VelociError) as e:
+            run(case["request"])
+        assert e.value.kind == "Unsupported" and GPU_DECLINES[case["name"]] in str(e.value)
+        return
+    got = refcases.check_expectations(case, docs, info, run)
+    if got is not None:
+        exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in case["request"].get("boost", []))
+        assert_same(case["request"], got, ora.search_json(json.dumps(case["request"])), exact_scores=exact)
