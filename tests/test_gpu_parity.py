@@ -361,13 +361,7 @@ import refcases  # noqa: E402
 
 REF_CASES = refcases.load()["cases"]
 # requests the MI355X path declines (VQ_ERR_UNSUPPORTED -> the caller keeps its CPU path)
-GPU_DECLINES = {
-    "search_and_boost_1_n": "1:n field boost",
-    "search_and_double_boost": "1:n field boost",
-    "or_connect_search_and_boost_anchor": "1:n field boost",
-    "boost_text_localitaet": "text_locality on a field that is not an anchor identity column",
-    "facet_without_facet_index": "n-step join",
-}
+GPU_DECLINES = {}
 _REF_IDX = {}
 
 

@@ -376,35 +376,14 @@ struct Compiler {
         if (sp > uint32_t(kStackDepth)) unsupported("query tree deeper than the evaluation stack");
     }
 
-    NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
+    // score leaf: the posting lists of the matched terms (resolve_token_to_anchor, search_field.rs:400-504)
+    NodeInfo compile_leaf_scores(const SearchRequest& r, Leaf& l, std::vector<DOp>& ops, uint32_t& sp) {
         NodeInfo info;
-        if (r.kind == SearchRequest::Search) {
-            Leaf& l = field_result(r.part);
-            if (!is_filter) {  // 1:n boosts joined through a shared [] prefix (execution_plan.rs:422-509)
-                size_t pos = r.part.path.rfind("[]");
-                if (pos != std::string::npos) {
-                    std::string end_obj = r.part.path.substr(0, pos);
-                    for (auto& el : boost) {
-                        size_t p = el.path.rfind("[]");
-                        if (p != std::string::npos && el.path.substr(0, p) == end_obj) unsupported("1:n field boost (" + el.path + ")");
-                    }
-                }
-            }
-            DOp op{};
-            op.kind = OP_LEAF;
-            op.list_begin = uint16_t(cq.lists.size());
-            info.label = r.part.terms[0];
-            if (is_filter) {
-                auto lists = ids_to_anchor_lists(l, false);
-                op.list_count = uint16_t(lists.size());
-                for (uint32_t li : lists) {
-                    info.cover.push_back(li);
-                    info.cover_len += cq.lists[li].len;
-                    info.glen += cq.lists[li].global_len;
-                    cq.algorithmic_bytes += 4ull * cq.lists[li].len;
-                }
-                info.len_known = lists.size() <= 1;
-            } else {
+        DOp op{};
+        op.kind = OP_LEAF;
+        op.list_begin = uint16_t(cq.lists.size());
+        info.label = r.part.terms[0];
+        {
                 const PostingStore& ps = posting_store(l.path);
                 uint32_t count = 0;
                 uint32_t with_entries = 0;
@@ -484,6 +463,133 @@ struct Compiler {
                 info.glen = 0;
                 for (auto& [tid, score] : l.hits_scores)
                     if (tid < ps.num_tokens) info.glen += ps.global_len[tid];
+        }
+        push_op(ops, op, sp);
+        info.emitted = true;
+        return info;
+    }
+
+    void fill_boost_params(DColBoost& cb, const RequestBoostPart& b) {
+        cb.fun = b.boost_fun ? int32_t(*b.boost_fun) : BF_NONE;  // enum order matches BoostFun
+        cb.param = b.param.value_or(0.0f);
+        if (b.skip_when_score) {
+            if (b.skip_when_score->size() > size_t(kMaxSkipWhen)) unsupported("more than 4 skip_when_score values");
+            cb.nskip = uint32_t(b.skip_when_score->size());
+            for (size_t i = 0; i < b.skip_when_score->size(); ++i) cb.skip[i] = (*b.skip_when_score)[i];
+        }
+        cb.expr_op = EX_NONE;
+        if (b.expression) parse_expression(*b.expression, cb);
+    }
+
+    // BoostToAnchor + ApplyAnchorBoost (plan_steps.rs:174-219): matched terms -> text ids -> value ids of the 1:n object ->
+    // boost value and anchor of each value id (boost.rs:432-468), applied to the leaf's hits by anchor (boost.rs:255-281).
+    void emit_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b, std::vector<DOp>& ops, uint32_t& sp) {
+        std::vector<uint32_t> ids;
+        auto cit = idx.columns.find(part.path);
+        const bool tokenized = cit != idx.columns.end() && cit->second.tokenize;
+        if (tokenized) {  // search_field.rs:640-689
+            const KVStore& t2t = kv_store(l.path + TOKENS_TO_TEXT_ID);
+            for (auto& h : l.hits_scores) {
+                const uint32_t *rb, *re;
+                if (t2t.host_row(h.first, &rb, &re)) ids.insert(ids.end(), rb, re);
+                else ids.push_back(h.first);  // is a text id
+            }
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        } else ids = l.hits_ids;
+        std::vector<uint32_t> value_ids;  // join_to_parent_ids search.rs:281-315
+        const KVStore& to_parent = kv_store(l.path + VALUE_ID_TO_PARENT);
+        for (uint32_t id : ids) {
+            const uint32_t *rb, *re;
+            if (to_parent.host_row(id, &rb, &re)) value_ids.insert(value_ids.end(), rb, re);
+        }
+        std::sort(value_ids.begin(), value_ids.end());
+        value_ids.erase(std::unique(value_ids.begin(), value_ids.end()), value_ids.end());
+        auto bit = idx.boost.find(b.path + BOOST_VALID_TO_VALUE);
+        if (bit == idx.boost.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + b.path + BOOST_VALID_TO_VALUE);
+        const KVStore& to_anchor = kv_store(b.path + VALUE_ID_TO_ANCHOR);
+        std::vector<std::pair<uint32_t, float>> pairs;  // (anchor, boost value) in value-id order
+        for (uint32_t vid : value_ids) {
+            float v;
+            if (!bit->second.host_value(vid, &v)) continue;
+            const uint32_t *rb, *re;
+            if (to_anchor.host_row(vid, &rb, &re)) pairs.push_back({*rb, v});
+        }
+        for (size_t i = 1; i < pairs.size(); ++i) {
+            if (pairs[i].first < pairs[i - 1].first) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
+            // several boosted values on one anchor: how many of them the reference applies depends on the neighbouring hits (boost.rs:262-279)
+            if (pairs[i].first == pairs[i - 1].first) unsupported("1:n field boost with several boosted values on one anchor (" + b.path + ")");
+        }
+        std::vector<uint32_t> docs;
+        std::vector<float> vals;
+        for (auto& pr : pairs)
+            if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi) {
+                docs.push_back(pr.first);
+                vals.push_back(pr.second);
+            }
+        HList h;
+        h.len = uint32_t(docs.size());
+        h.global_len = pairs.size();
+        h.flags = LIST_HAS_SCORES | LIST_F32;
+        h.term_score = 1.0f;
+        h.inline_idx = int(cq.inline_lists.size());
+        h.inline_val_idx = int(cq.inline_vals.size());
+        cq.inline_lists.push_back(std::move(docs));
+        cq.inline_vals.push_back(std::move(vals));
+        const uint32_t li = add_list(h);
+        cq.algorithmic_bytes += 8ull * h.len;
+        DColBoost cb{};
+        fill_boost_params(cb, b);
+        cb.nskip = 0;  // apply_boost_values_anchor has no skip_when_score
+        cq.leaf_cols.push_back(cb);
+        DOp op{};
+        op.kind = OP_BOOST1N;
+        op.nchild = 1;
+        op.list_begin = uint16_t(li);
+        op.list_count = 1;
+        op.child_slot[0] = uint8_t(cq.leaf_cols.size() - 1);  // rebased behind the request-level boosts when the query is finished
+        push_op(ops, op, sp);
+    }
+
+    NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
+        NodeInfo info;
+        if (r.kind == SearchRequest::Search) {
+            Leaf& l = field_result(r.part);
+            const RequestBoostPart* boost_1n = nullptr;
+            if (!is_filter) {  // 1:n boosts joined through a shared [] prefix (execution_plan.rs:422-509)
+                size_t pos = r.part.path.rfind("[]");
+                if (pos != std::string::npos) {
+                    std::string end_obj = r.part.path.substr(0, pos);
+                    for (auto& el : boost) {
+                        size_t p = el.path.rfind("[]");
+                        if (p != std::string::npos && el.path.substr(0, p) == end_obj) {
+                            if (boost_1n) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"more than one boost matches the 1:n search path\" ");
+                            boost_1n = &el;
+                        }
+                    }
+                }
+            }
+            if (boost_1n) {  // the leaf, then a unary op that applies the per-anchor boost values
+                NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
+                emit_boost_1n(r.part, l, *boost_1n, ops, sp);
+                leaf_info.emitted = true;
+                return leaf_info;
+            }
+            if (!is_filter) return compile_leaf_scores(r, l, ops, sp);
+            DOp op{};
+            op.kind = OP_LEAF;
+            op.list_begin = uint16_t(cq.lists.size());
+            info.label = r.part.terms[0];
+            if (is_filter) {
+                auto lists = ids_to_anchor_lists(l, false);
+                op.list_count = uint16_t(lists.size());
+                for (uint32_t li : lists) {
+                    info.cover.push_back(li);
+                    info.cover_len += cq.lists[li].len;
+                    info.glen += cq.lists[li].global_len;
+                    cq.algorithmic_bytes += 4ull * cq.lists[li].len;
+                }
+                info.len_known = lists.size() <= 1;
             }
             push_op(ops, op, sp);
             info.emitted = true;
@@ -620,6 +726,7 @@ struct Compiler {
         auto run = [&](const std::vector<DOp>& ops) -> uint16_t {
             std::vector<uint16_t> st;
             for (const DOp& op : ops) {
+                if (op.kind == OP_BOOST1N) continue;  // changes scores only
                 if (op.kind == OP_LEAF) {
                     if (op.list_count == 1) {
                         st.push_back(op.list_begin);
@@ -701,18 +808,17 @@ struct Compiler {
                 cb.present = it->second.has_present ? it->second.present.as<uint32_t>() : nullptr;
                 cb.key_base = it->second.key_base;
                 cb.num_keys = it->second.num_keys;
-                cb.fun = b.boost_fun ? int32_t(*b.boost_fun) : BF_NONE;  // enum order matches BoostFun
-                cb.param = b.param.value_or(0.0f);
-                if (b.skip_when_score) {
-                    if (b.skip_when_score->size() > size_t(kMaxSkipWhen)) unsupported("more than 4 skip_when_score values");
-                    cb.nskip = uint32_t(b.skip_when_score->size());
-                    for (size_t i = 0; i < b.skip_when_score->size(); ++i) cb.skip[i] = (*b.skip_when_score)[i];
-                }
-                cb.expr_op = EX_NONE;
-                if (b.expression) parse_expression(*b.expression, cb);
+                fill_boost_params(cb, b);
                 cq.cols.push_back(cb);
                 cq.algorithmic_bytes += 0;  // 4 B gather per hit, unknown until run time
             }
+        cq.n_top_cols = uint32_t(cq.cols.size());
+        if (!cq.leaf_cols.empty()) {  // parameters of the OP_BOOST1N ops live behind the request-level boosts
+            if (cq.cols.size() + cq.leaf_cols.size() > 255) unsupported("more than 255 boosts in one query");
+            for (DOp& op : cq.ops)
+                if (op.kind == OP_BOOST1N) op.child_slot[0] = uint8_t(op.child_slot[0] + cq.n_top_cols);
+            cq.cols.insert(cq.cols.end(), cq.leaf_cols.begin(), cq.leaf_cols.end());
+        }
 
         // phrase boosts (execution_plan.rs:202-262, plan_steps.rs:235-293, search_field.rs:247-275)
         if (req.phrase_boosts) {
@@ -786,7 +892,55 @@ struct Compiler {
             for (auto& [path, terms] : term_id_hits) {
                 if (terms.size() <= 1) continue;  // boost.rs:36-39
                 const KVStore& t2t = kv_store(path + TOKENS_TO_TEXT_ID);
-                if (!idx.is_anchor_identity(path)) unsupported("text_locality on a field that is not an anchor identity column");
+                if (!idx.is_anchor_identity(path)) {
+                    // Text ids are not anchors (boost.rs:72-83): count the texts on the host copy of the small side tables,
+                    // hand the kernel one (anchor, 2*c*c) list per field.  Bounded: long token->text rows are declined.
+                    static const size_t cap = std::getenv("VQ_LOCALITY_HOST_MAX") ? size_t(std::atoll(std::getenv("VQ_LOCALITY_HOST_MAX"))) : (size_t(1) << 22);
+                    std::vector<uint32_t> all;
+                    for (auto& [term, ids] : terms)
+                        for (uint32_t id : ids) {
+                            const uint32_t *rb, *re;
+                            if (t2t.host_row(id, &rb, &re)) all.insert(all.end(), rb, re);
+                            if (all.size() > cap) unsupported("text_locality on a non-identity field with more than " + std::to_string(cap) + " token->text entries");
+                        }
+                    std::sort(all.begin(), all.end());
+                    const KVStore& t2a = kv_store(path + TEXT_ID_TO_ANCHOR);
+                    std::vector<std::pair<uint32_t, float>> pairs;
+                    for (size_t i = 0; i < all.size();) {
+                        size_t j = i;
+                        while (j < all.size() && all[j] == all[i]) ++j;
+                        const size_t c = j - i;  // counts list entries, not distinct terms (:51-56)
+                        if (c > 1) {
+                            const uint32_t *rb, *re;
+                            if (t2a.host_row(all[i], &rb, &re))
+                                for (const uint32_t* p = rb; p != re; ++p) pairs.push_back({*p, 2.0f * float(c) * float(c)});
+                        }
+                        i = j;
+                    }
+                    std::sort(pairs.begin(), pairs.end());  // by anchor, then value: the first entry of an anchor is its minimum (:25)
+                    std::vector<uint32_t> docs;
+                    std::vector<float> vals;
+                    for (auto& pr : pairs)
+                        if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi && (docs.empty() || docs.back() != pr.first)) {
+                            docs.push_back(pr.first);
+                            vals.push_back(pr.second);
+                        }
+                    HList h;
+                    h.len = uint32_t(docs.size());
+                    h.global_len = docs.size();
+                    h.flags = LIST_HAS_SCORES | LIST_F32;
+                    h.term_score = 1.0f;
+                    h.inline_idx = int(cq.inline_lists.size());
+                    h.inline_val_idx = int(cq.inline_vals.size());
+                    cq.inline_lists.push_back(std::move(docs));
+                    cq.inline_vals.push_back(std::move(vals));
+                    DLocField lf{};
+                    lf.list_begin = uint16_t(add_list(h));
+                    lf.list_count = kLocPrecomputed;
+                    cq.locf.push_back(lf);
+                    cq.algorithmic_bytes += 8ull * h.len;
+                    continue;
+                }
                 DLocField lf{};
                 lf.list_begin = uint16_t(cq.lists.size());
                 uint32_t count = 0;
@@ -814,8 +968,7 @@ struct Compiler {
                 std::string store_path;
                 if (steps.size() == 1) store_path = steps.front() + PARENT_TO_VALUE_ID;
                 else if (idx.kv.count(steps.back() + ANCHOR_TO_TEXT_ID)) store_path = steps.back() + ANCHOR_TO_TEXT_ID;
-                else unsupported("facet on " + fr.field + " without an anchor_to_text_id index (n-step join)");
-                const KVStore& kv = kv_store(store_path);
+                const KVStore& kv = store_path.empty() ? idx.composed_facet(steps) : kv_store(store_path);  // facet.rs:38-57 / :59-70
                 if (!kv.facet_csr) unsupported("facet source " + store_path + " is not staged as an anchor-keyed CSR");
                 auto dit = idx.dict.find(steps.back());
                 if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "fst not found loaded in indices " + steps.back() + " ");

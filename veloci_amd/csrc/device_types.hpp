@@ -43,7 +43,7 @@ struct DList {  // 48 B
     const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + 2048 * k
 };
 
-enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2 };
+enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2, OP_BOOST1N = 3 };  // OP_BOOST1N: unary, 1:n field boost of the leaf below (list_begin = anchors + f32 values, child_slot[0] = index into cols)
 
 struct DOp {  // 24 B
     uint8_t kind;
@@ -97,8 +97,10 @@ struct DColBoost {  // boost.rs:283-377, 470-504
     uint32_t pad;
 };
 
-struct DLocField {  // one text field with >= 2 query terms (boost.rs:34-87), identity column
-    uint16_t list_begin, list_count;
+constexpr uint16_t kLocPrecomputed = 0xFFFF;
+struct DLocField {  // one text field with >= 2 query terms (boost.rs:34-87)
+    uint16_t list_begin, list_count;  // identity column: the terms' token->text lists, counted per doc;
+                                      // list_count == kLocPrecomputed: list_begin is one (anchor, f32 2*c*c) list
 };
 
 struct DFacet {  // facet.rs:31-73 fast path: anchor -> value ids, counted into a histogram

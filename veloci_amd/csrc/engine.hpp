@@ -203,6 +203,15 @@ struct BoostColumn {
     bool has_present = false;
     DevBuf values;   // f32
     DevBuf present;  // bitmap u32
+    std::vector<uint32_t> host_bits;    // host copy, kept for 1:n boost columns (keys are value ids, resolved on the host)
+    std::vector<uint8_t> host_present;
+    bool host_value(uint64_t key, float* out) const {  // IndexIdToParent::get_value
+        if (key < key_base || key - key_base >= host_bits.size()) return false;
+        const size_t r = size_t(key - key_base);
+        if (!host_present.empty() && !host_present[r]) return false;
+        std::memcpy(out, &host_bits[r], 4);
+        return true;
+    }
 };
 
 struct PinnedBuf {  // page-locked host staging
@@ -251,6 +260,11 @@ struct Index {
     std::map<std::string, BoostColumn> boost;
     std::map<std::string, ColumnMeta> columns;
     uint64_t device_bytes = 0;
+    // facets on 1:n fields without an anchor_to_text_id index (facet.rs:59-70): the chain of parent_to_value_id joins is composed
+    // once per field, on first use, into one anchor-keyed CSR that the facet kernel reads like a direct index
+    mutable std::mutex composed_mu;
+    mutable std::map<std::string, std::unique_ptr<KVStore>> composed_facets;
+    const KVStore& composed_facet(const std::vector<std::string>& steps) const;
     hipStream_t own_stream = nullptr, own_fin_stream = nullptr;
     hipStream_t stream = nullptr;      // scans + span merges
     hipStream_t fin_stream = nullptr;  // shard merge, facet selection, result download (== stream when the caller set one)
@@ -275,6 +289,7 @@ struct HList {
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;
     int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
+    int inline_val_idx = -1;  // >= 0: f32 values come from inline_vals[inline_val_idx]
 };
 
 struct FacetOut {
@@ -290,6 +305,9 @@ struct CompiledQuery {
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
     std::vector<HList> lists;
     std::vector<std::vector<uint32_t>> inline_lists;
+    std::vector<std::vector<float>> inline_vals;
+    std::vector<DColBoost> leaf_cols;  // compile-time staging of the OP_BOOST1N parameters
+    uint32_t n_top_cols = 0;  // cols[0 .. n_top_cols) are the request-level boosts; the rest belong to OP_BOOST1N ops
     std::vector<DOp> ops, fops;
     std::vector<DPresOp> pres;
     std::vector<uint16_t> pres_in;

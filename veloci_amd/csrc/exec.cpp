@@ -46,7 +46,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.n_fops = uint32_t(cq.fops.size());
     h.n_groups = uint32_t(cq.groups.size());
     h.n_tboost = uint32_t(cq.tboosts.size());
-    h.n_col = uint32_t(cq.cols.size());
+    h.n_col = cq.n_top_cols;
     h.n_locf = uint32_t(cq.locf.size());
     h.n_facets = uint32_t(cq.facets.size());
     h.off_lists = uint32_t(section(cq.lists.size() * sizeof(DList)));
@@ -68,6 +68,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (desc_bytes_out) *desc_bytes_out = off;
     std::vector<size_t> inline_off(cq.inline_lists.size());
     for (size_t i = 0; i < cq.inline_lists.size(); ++i) inline_off[i] = section(align_up(cq.inline_lists[i].size(), 4) * 4);
+    std::vector<size_t> inline_val_off(cq.inline_vals.size());
+    for (size_t i = 0; i < cq.inline_vals.size(); ++i) inline_val_off[i] = section(align_up(cq.inline_vals[i].size(), 4) * 4);
     h.top_k = cq.top_k;
     h.tile_words = cq.tile_words;
     h.n_spans = cq.n_spans;
@@ -84,7 +86,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         const HList& l = cq.lists[i];
         DList d{};
         d.docs = l.inline_idx >= 0 ? reinterpret_cast<const uint32_t*>(dev + inline_off[l.inline_idx]) : l.d_docs;
-        d.scores = l.d_scores;
+        d.scores = l.inline_val_idx >= 0 ? reinterpret_cast<const uint16_t*>(dev + inline_val_off[l.inline_val_idx]) : l.d_scores;
         d.len = l.len;
         d.flags = l.flags;
         d.term_score = l.term_score;
@@ -107,6 +109,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         f.out_off = fac_out_off[i];
         df[i] = f;
     }
+    for (size_t i = 0; i < cq.inline_vals.size(); ++i)
+        if (!cq.inline_vals[i].empty()) std::memcpy(dst + inline_val_off[i], cq.inline_vals[i].data(), cq.inline_vals[i].size() * 4);
     for (size_t i = 0; i < cq.inline_lists.size(); ++i) {
         uint32_t* p = reinterpret_cast<uint32_t*>(dst + inline_off[i]);
         const auto& v = cq.inline_lists[i];

@@ -312,6 +312,10 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         c.values.alloc(bc.bits.size() * 4 + 16);
         c.values.upload(bc.bits.data(), bc.bits.size() * 4);
         idx->device_bytes += c.values.bytes;
+        if (path.find("[]") != std::string::npos) {
+            c.host_bits = bc.bits;
+            c.host_present.assign(bc.present.begin(), bc.present.end());
+        }
         if (!bc.present.empty()) {
             c.has_present = true;
             std::vector<uint32_t> bits((bc.bits.size() + 31) / 32, 0u);
@@ -325,6 +329,49 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     }
     VQ_HIP(hipDeviceSynchronize());
     return idx;
+}
+
+// join_anchor_to_leaf (facet.rs:75-93) for every anchor of the shard: anchor -> value ids of step 0 -> ... -> text ids of the last step
+const KVStore& Index::composed_facet(const std::vector<std::string>& steps) const {
+    std::string key;
+    for (auto& s : steps) key += s + "|";
+    std::lock_guard<std::mutex> g(composed_mu);
+    auto it = composed_facets.find(key);
+    if (it != composed_facets.end()) return *it->second;
+    std::vector<const KVStore*> chain;
+    for (auto& s : steps) {
+        auto kit = kv.find(s + PARENT_TO_VALUE_ID);
+        if (kit == kv.end()) throw VelociError(vqreq::ERR_INDEX_NOT_FOUND, "Did not found path in indices " + s + PARENT_TO_VALUE_ID);
+        chain.push_back(&kit->second);
+    }
+    VQ_HIP(hipSetDevice(device));
+    auto out = std::make_unique<KVStore>();
+    std::vector<uint64_t> off(size_t(doc_hi - doc_lo) + 1, 0);
+    std::vector<uint32_t> vals, level, next;
+    for (uint32_t a = doc_lo; a < doc_hi; ++a) {
+        level.assign(1, a);
+        for (const KVStore* st : chain) {
+            next.clear();
+            for (uint32_t id : level) {
+                const uint32_t *rb, *re;
+                if (st->host_row(id, &rb, &re)) next.insert(next.end(), rb, re);
+            }
+            level.swap(next);
+        }
+        vals.insert(vals.end(), level.begin(), level.end());
+        off[a - doc_lo + 1] = vals.size();
+    }
+    out->facet_csr = true;
+    out->csr_key_base = doc_lo;
+    out->csr_num_keys = doc_hi - doc_lo;
+    out->csr_off.alloc(off.size() * 8);
+    out->csr_off.upload(off.data(), off.size() * 8);
+    out->csr_values.alloc(vals.size() * 4 + 16);
+    out->csr_values.upload(vals.data(), vals.size() * 4);
+    VQ_HIP(hipDeviceSynchronize());
+    const KVStore& ref = *out;
+    composed_facets.emplace(key, std::move(out));
+    return ref;
 }
 
 }  // namespace vq

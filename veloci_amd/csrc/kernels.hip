@@ -183,15 +183,8 @@ uint32_t debug_div100_mismatches() {
 __device__ __forceinline__ float log10_f32(float x) { return (float)log10((double)x); }
 __device__ __forceinline__ float log2_f32(float x) { return (float)log2((double)x); }
 
-__device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc) {
-    // add_boost boost.rs:470-504 + apply_boost :283-377
-    for (uint32_t s = 0; s < cb.nskip; ++s)
-        if (fabsf(cb.skip[s] - score) < 0.00001f) return score;
-    if (doc < cb.key_base) return score;
-    uint32_t row = doc - cb.key_base;
-    if (row >= cb.num_keys) return score;
-    if (cb.present && !((as_global(cb.present)[row >> 5] >> (row & 31u)) & 1u)) return score;
-    float v = as_global(cb.values)[row];
+// apply_boost (boost.rs:283-377): boost function, then the optional expression
+__device__ float apply_boost_value(float score, const DColBoost& cb, float v) {
     float vp = v + cb.param;
     switch (cb.fun) {
         case BF_LOG10: score *= log10_f32(vp); break;
@@ -214,6 +207,17 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
         score += e;
     }
     return score;
+}
+
+__device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc) {
+    // add_boost boost.rs:470-504
+    for (uint32_t s = 0; s < cb.nskip; ++s)
+        if (fabsf(cb.skip[s] - score) < 0.00001f) return score;
+    if (doc < cb.key_base) return score;
+    uint32_t row = doc - cb.key_base;
+    if (row >= cb.num_keys) return score;
+    if (cb.present && !((as_global(cb.present)[row >> 5] >> (row & 31u)) & 1u)) return score;
+    return apply_boost_value(score, cb, as_global(cb.values)[row]);
 }
 
 // ------------------------------------------------------------------------------------ per-hit scoring
@@ -329,6 +333,18 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
                     present = true;
                 }
             }
+        } else if (op.kind == OP_BOOST1N) {  // apply_boost_values_anchor (boost.rs:255-281): one boost value per anchor of the leaf below
+            const uint32_t top = sp - 1u;
+            if ((pmask >> top) & 1u) {
+                const uint32_t li = op.list_begin;
+                const uint32_t word = c.bm[li * c.WW + w];
+                if ((word >> b) & 1u) {
+                    const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
+                    const float v = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
+                    c.fstack[top * kBlock] = apply_boost_value(c.fstack[top * kBlock], c.cols[op.child_slot[0]], v);
+                }
+            }
+            continue;
         } else if (op.kind == OP_AND) {
             const uint32_t base = sp - op.nchild;
             present = true;
@@ -377,6 +393,17 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint3
         float best = 0.0f;
         bool have = false;
         for (uint32_t f = 0; f < c.n_locf; ++f) {
+            if (c.locf[f].list_count == kLocPrecomputed) {  // field whose text ids are not anchors: (anchor, 2*c*c) resolved by the query compiler
+                const uint32_t li = c.locf[f].list_begin;
+                const uint32_t word = c.bm[li * c.WW + w];
+                if ((word >> b) & 1u) {
+                    const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & ((1u << b) - 1u));
+                    const float bv = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
+                    if (!have || bv < best) best = bv;
+                    have = true;
+                }
+                continue;
+            }
             uint32_t cnt = 0;
             for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += (c.bm[(c.locf[f].list_begin + j) * c.WW + w] >> b) & 1u;
             if (cnt > 1u) {
