@@ -256,6 +256,19 @@ def test_generic_kernel_also_matches_for_simple_queries():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}], ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple"])
+def test_alternative_kernel_routes_match(env):
+    """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "single_term or test_or or leaf_boost or batch_equals or two_shards or case_insensitive or (reference_integration and (or_connect or minimal or simple_search))"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_fast_div100_is_exact_for_every_f16():
     """The dense-tile path divides by 100 with a 3-instruction sequence; it must equal the correctly rounded
     f32 division for every finite f16 input (the only inputs it ever sees)."""

@@ -1004,6 +1004,18 @@ struct Compiler {
                 for (size_t i = 0; i + 1 < n; ++i) ok = ok && is_leaf1(cq.ops[i]);
                 if (ok) cq.simple_n = uint32_t(n - 1);
             }
+            // OR whose operands all have their own term slot: order the leaves by slot, so that the kernels' slot loop
+            // (set_op.rs:169-186) is the plain left-to-right sum over the operands
+            if (cq.simple_n > 1 && cq.ops[n - 1].kind == OP_OR && cq.ops[n - 1].nslots == cq.simple_n) {
+                DOp& root = cq.ops[n - 1];
+                std::vector<std::pair<uint8_t, DOp>> leaves;
+                for (uint32_t k = 0; k < cq.simple_n; ++k) leaves.push_back({root.child_slot[k], cq.ops[k]});
+                std::stable_sort(leaves.begin(), leaves.end(), [](auto& x, auto& y) { return x.first < y.first; });
+                for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                    cq.ops[k] = leaves[k].second;
+                    root.child_slot[k] = leaves[k].first;
+                }
+            }
         }
 
         {  // pure simple queries run on k_scan_simple (fixed 8192-doc tiles)

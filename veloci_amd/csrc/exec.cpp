@@ -485,9 +485,12 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         for (size_t i = 0; i < n; ++i) {
             const CompiledQuery& cq = pb->queries[i];
             if (cq.status != 0) continue;
-            // the LDS-staged dense-tile variant is opt-in (VQ_DENSE=1): at its current occupancy it is slower than the queue path
-            static const bool dense_enabled = std::getenv("VQ_DENSE") != nullptr;
-            const bool dense = dense_enabled && cq.simple_flags && (cq.simple_n == 1 || cq.ops.back().kind == OP_OR);
+            // every posting is a hit: k_scan_union streams the scores with the doc ids.  Single leaves always (VQ_NO_UNION=1 turns it
+            // off); its two-pass OR is correct but not yet faster than the survivor queue of k_scan_simple (50 vs 40 ms per 256
+            // 3-term ORs on 100 M docs), so ORs take it only with VQ_UNION_OR=1
+            static const bool union_enabled = std::getenv("VQ_NO_UNION") == nullptr;
+            static const bool union_or = std::getenv("VQ_UNION_OR") != nullptr;
+            const bool dense = union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
             if (dense) {
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
@@ -547,9 +550,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
-    launch_scan_simple(st, true, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
-                       reinterpret_cast<const uint32_t*>(dup + up_qmap_d), n_dense, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+    launch_scan_union(st, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
+                      reinterpret_cast<const uint32_t*>(dup + up_qmap_d), n_dense, cand_cap, ws.d_span_keys.as<unsigned long long>(),
+                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
     launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, reinterpret_cast<const uint32_t*>(dup + up_qmap_g), n_generic,
                      stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),

@@ -1699,3 +1699,339 @@ void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList*
 }
 
 }  // namespace vq
+
+// ====================================================================================================
+// k_scan_union — pure simple queries whose hits are dense: a single leaf (K1 streaming scan) or one OR over
+// 2..4 single-list posting leaves (K4).  Every posting is a hit, so the f16 scores are streamed with the doc
+// ids (coalesced 16 B + 8 B per lane) instead of being gathered per survivor:
+//   n == 1: the span's slice of the list is streamed once; score, key, threshold test per posting.
+//   OR:     tiles of 2048 docs.  Pass 1 scatters every list's in-tile postings into LDS (presence bit + raw f16 at the
+//           doc's offset).  Pass 2 streams the same postings again (L2 hits); a posting is evaluated by the FIRST list
+//           that holds its doc: lanes work on postings, not on bitmap bits, so there are no per-lane bit loops.
+// Same arithmetic as simple_flush (set_op.rs:169-186), bit-identical results.
+// ====================================================================================================
+namespace vq {
+
+#ifndef VQ_UT
+#define VQ_UT 2048
+#endif
+constexpr uint32_t kUT = VQ_UT;       // docs per tile
+constexpr uint32_t kUTW = kUT / 32;   // bitmap words per list and tile
+// LDS map (u32): misc[8] | cand[2*cand_cap] | bm[4][kUTW] | val u16 [4][kUT]
+size_t scan_union_lds_bytes(uint32_t cand_cap) { return (size_t)(8 + 2 * cand_cap + 4 * kUTW + 4 * kUT / 2) * 4 + 16; }
+
+__device__ __forceinline__ void union_push(bool pending, unsigned long long key, const CandState& cs, uint32_t top_k) {
+    while (true) {  // uniform
+        if (pending) {
+            if (key > *cs.thr) {
+                const uint32_t pos = atomicAdd(cs.n, 1u);
+                if (pos < cs.cap) {
+                    cs.cand[pos] = key;
+                    pending = false;
+                }
+            } else pending = false;
+        }
+        if (!__syncthreads_or(pending ? 1 : 0)) break;
+        cand_prune(cs, top_k);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                   const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
+                                                   unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t ql;
+    {
+        uint32_t lo = 0, hi = nq;
+        const uint32_t wg = blockIdx.x;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (span_base[mid] <= wg) lo = mid;
+            else hi = mid;
+        }
+        ql = lo;
+    }
+    const uint32_t span = blockIdx.x - span_base[ql];
+    const uint32_t q = qmap[ql];
+    const uint8_t* blob = blobs + blob_off[q];
+    const QHeader* H = reinterpret_cast<const QHeader*>(blob);
+    const uint32_t n = H->simple_n;
+    const uint32_t top_k = H->top_k;
+    const DList* gl = reinterpret_cast<const DList*>(blob + H->off_lists);
+    const DOp* gops = reinterpret_cast<const DOp*>(blob + H->off_ops);
+
+    const VQ_GLOBAL uint32_t* docs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const uint32_t* docs_flat[4] = {nullptr, nullptr, nullptr, nullptr};
+    const VQ_GLOBAL uint16_t* scs[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t len[4] = {0, 0, 0, 0};
+    float ts[4] = {0.f, 0.f, 0.f, 0.f};
+    uint8_t slot[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) {
+            const DList& d = gl[gops[k].list_begin];
+            docs[k] = as_global(d.docs);
+            docs_flat[k] = d.docs;
+            scs[k] = as_global(d.scores);
+            len[k] = d.len;
+            ts[k] = d.term_score;
+        }
+    uint32_t nslots = 1;
+    if (n > 1) {
+        nslots = gops[n].nslots;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) slot[k] = gops[n].child_slot[k];
+    }
+
+    unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t* cand_n = lds + 2;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + 8);
+    uint32_t* bm = lds + 8 + 2 * cand_cap;                                  // [4][kUTW]
+    uint16_t* val = reinterpret_cast<uint16_t*>(bm + 4 * kUTW);            // [4][kUT]
+    CandState cs{cand, cand_n, thr, cand_cap};
+
+    const uint32_t n_spans = H->n_spans;
+    const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(kSW - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(kSW - 1u));
+    const uint32_t keys_base = H->keys_base;
+
+    uint32_t cur[4] = {0, 0, 0, 0}, end[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) {
+            cur[k] = wave_lower_bound(docs_flat[k], len[k], span_lo);
+            end[k] = cur[k] + wave_lower_bound(docs_flat[k] + cur[k], len[k] - cur[k], span_hi);
+        }
+    if (lane == 0) {
+        *thr = 0ull;
+        *cand_n = 0;
+    }
+    __syncthreads();
+    unsigned long long hits = 0;
+    const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+
+    if (n == 1) {
+        // ---- K1: stream [cur, end) of the one list
+        hits = end[0] - cur[0];
+        const VQ_GLOBAL u32x4* dptr = reinterpret_cast<const VQ_GLOBAL u32x4*>(docs[0]);
+        const VQ_GLOBAL uint2* sptr = reinterpret_cast<const VQ_GLOBAL uint2*>(scs[0]);
+        const uint32_t v_end = (end[0] + 3u) >> 2;
+        uint32_t v = (cur[0] >> 2) + lane;
+        u32x4 d4 = kSent;
+        uint2 s4 = uint2{0u, 0u};
+        if (v < v_end) {
+            d4 = dptr[v];
+            s4 = uint2{sptr[v].x, sptr[v].y};
+        }
+        for (uint32_t v0 = cur[0] >> 2; v0 < v_end; v0 += 64u) {  // uniform
+            const uint32_t vn = v + 64u;
+            u32x4 nd4 = kSent;
+            uint2 ns4 = uint2{0u, 0u};
+            if (vn < v_end) {
+                nd4 = dptr[vn];
+                ns4 = uint2{sptr[vn].x, sptr[vn].y};
+            }
+            const uint32_t i0 = v << 2;
+            const unsigned long long thr_reg = *thr;
+            unsigned long long key[4];
+            bool pend[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t d = comp4(d4, j);
+                const uint32_t raw = j == 0 ? (s4.x & 0xFFFFu) : j == 1 ? (s4.x >> 16) : j == 2 ? (s4.y & 0xFFFFu) : (s4.y >> 16);
+                const float score = posting_value_fast(ts[0], (uint16_t)raw);
+                key[j] = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)d;
+                const uint32_t i = i0 + j;
+                pend[j] = v < v_end && i >= cur[0] && i < end[0] && key[j] > thr_reg;
+            }
+            if (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {  // uniform; rare once the threshold has risen
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) union_push(pend[j], key[j], cs, top_k);
+            }
+            d4 = nd4;
+            s4 = ns4;
+            v = vn;
+        }
+    } else {
+        // ---- K4: OR over n lists, tile by tile
+        bool ident = nslots == n;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n && slot[k] != k) ident = false;
+        uint32_t nxt[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n && cur[k] < end[k]) nxt[k] = docs[k][cur[k]];
+        while (true) {
+            uint32_t head = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < n) head = nxt[k] < head ? nxt[k] : head;
+            if (head >= span_hi) break;
+            const uint32_t tile_lo = head & ~(kUT - 1u);
+            const uint32_t tile_end = tile_lo + kUT;
+            const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
+            uint32_t c1[4] = {0, 0, 0, 0};
+            // pass 1: presence bits + raw scores of every list's in-tile postings
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < n) bm[k * kUTW + lane] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < n) {
+                    c1[k] = cur[k];
+                    if (nxt[k] < tile_hi) {  // uniform
+                        const VQ_GLOBAL u32x4* dptr = reinterpret_cast<const VQ_GLOBAL u32x4*>(docs[k]);
+                        const VQ_GLOBAL uint2* sptr = reinterpret_cast<const VQ_GLOBAL uint2*>(scs[k]);
+                        const uint32_t v_end = (end[k] + 3u) >> 2;
+                        uint32_t* bmk = bm + k * kUTW;
+                        uint16_t* valk = val + k * kUT;
+                        uint32_t total = 0, boundary = 0xFFFFFFFFu;
+                        for (uint32_t v0 = cur[k] >> 2;; v0 += 64u) {  // uniform
+                            const uint32_t v = v0 + lane;
+                            u32x4 d4 = kSent;
+                            uint2 s4 = uint2{0u, 0u};
+                            if (v < v_end) {
+                                d4 = dptr[v];
+                                s4 = uint2{sptr[v].x, sptr[v].y};
+                            }
+                            const uint32_t i0 = v << 2;
+                            uint32_t mine = 0, first_out = 0xFFFFFFFFu;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t d = comp4(d4, j);
+                                const uint32_t i = i0 + j;
+                                const bool live = v < v_end && i >= cur[k] && i < end[k];
+                                const bool in = live && d < tile_hi;
+                                if (in) {
+                                    const uint32_t o = d - tile_lo;
+                                    const uint32_t raw = j == 0 ? (s4.x & 0xFFFFu) : j == 1 ? (s4.x >> 16) : j == 2 ? (s4.y & 0xFFFFu) : (s4.y >> 16);
+                                    atomicOr(&bmk[o >> 5], 1u << (o & 31u));
+                                    valk[o] = (uint16_t)raw;
+                                    ++mine;
+                                } else if (live && first_out == 0xFFFFFFFFu) first_out = d;
+                            }
+                            uint32_t round_in;
+                            (void)wave_excl_scan_u32(mine, &round_in);
+                            total += round_in;
+                            // the first live posting outside the tile (sorted list: the minimum over the lanes)
+                            const unsigned long long outm = __ballot(first_out != 0xFFFFFFFFu);
+                            if (outm) {
+                                boundary = (uint32_t)__builtin_amdgcn_readlane((int)first_out, (int)(__ffsll((long long)outm) - 1));
+                                break;
+                            }
+                            if (v0 + 64u >= v_end) break;  // list exhausted inside the tile
+                        }
+                        c1[k] = cur[k] + total;
+                        nxt[k] = boundary;
+                    }
+                }
+            }
+            __syncthreads();
+            // pass 2: evaluate every posting whose doc no earlier list holds
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (k < n && c1[k] > cur[k]) {  // uniform
+                    const VQ_GLOBAL u32x4* dptr = reinterpret_cast<const VQ_GLOBAL u32x4*>(docs[k]);
+                    const VQ_GLOBAL uint2* sptr = reinterpret_cast<const VQ_GLOBAL uint2*>(scs[k]);
+                    const uint32_t v_end = (c1[k] + 3u) >> 2;
+                    for (uint32_t v0 = cur[k] >> 2; v0 < v_end; v0 += 64u) {  // uniform
+                        const uint32_t v = v0 + lane;
+                        u32x4 d4 = kSent;
+                        uint2 s4 = uint2{0u, 0u};
+                        if (v < v_end) {
+                            d4 = dptr[v];
+                            s4 = uint2{sptr[v].x, sptr[v].y};
+                        }
+                        const uint32_t i0 = v << 2;
+                        const unsigned long long thr_reg = *thr;
+                        unsigned long long key[4];
+                        bool pend[4];
+                        uint32_t fresh = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const uint32_t d = comp4(d4, j);
+                            const uint32_t i = i0 + j;
+                            bool live = v < v_end && i >= cur[k] && i < c1[k];
+                            const uint32_t o = live ? d - tile_lo : 0u;
+                            const uint32_t raw = j == 0 ? (s4.x & 0xFFFFu) : j == 1 ? (s4.x >> 16) : j == 2 ? (s4.y & 0xFFFFu) : (s4.y >> 16);
+                            float vals[4] = {0.f, 0.f, 0.f, 0.f};
+                            uint32_t pm = 1u << k;
+#pragma unroll
+                            for (uint32_t i2 = 0; i2 < 4; ++i2) {
+                                if (i2 < n && i2 != k) {
+                                    const bool bit = (bm[i2 * kUTW + (o >> 5)] >> (o & 31u)) & 1u;
+                                    if (bit) {
+                                        if (i2 < k) live = false;  // an earlier list evaluates this doc
+                                        else {
+                                            pm |= 1u << i2;
+                                            vals[i2] = posting_value_fast(ts[i2], val[i2 * kUT + o]);
+                                        }
+                                    }
+                                }
+                            }
+                            const float own = posting_value_fast(ts[k], (uint16_t)raw);
+                            if (k == 0) vals[0] = own;
+                            else if (k == 1) vals[1] = own;
+                            else if (k == 2) vals[2] = own;
+                            else vals[3] = own;
+                            float sum = 0.0f, nd = 0.0f;  // set_op.rs:169-186
+                            if (ident) {  // operand k is slot k: absent operands contribute max(0, -) = 0
+#pragma unroll
+                                for (uint32_t i2 = 0; i2 < 4; ++i2)
+                                    if (i2 < n) {
+                                        const float m = fmaxf(0.0f, vals[i2]);  // vals[i2] == 0 when absent
+                                        nd += m >= 0.00001f ? 1.0f : 0.0f;
+                                        sum += m;
+                                    }
+                            } else {
+                                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                    float m = 0.0f;
+#pragma unroll
+                                    for (uint32_t i2 = 0; i2 < 4; ++i2)
+                                        if (i2 < n && slot[i2] == sl && ((pm >> i2) & 1u)) m = fmaxf(m, vals[i2]);
+                                    if (m >= 0.00001f) nd += 1.0f;
+                                    sum += m;
+                                }
+                            }
+                            const float score = sum * nd * nd;
+                            key[j] = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)d;
+                            fresh += live ? 1u : 0u;
+                            pend[j] = live && key[j] > thr_reg;
+                        }
+                        uint32_t round_fresh;
+                        (void)wave_excl_scan_u32(fresh, &round_fresh);
+                        hits += round_fresh;
+                        if (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {  // uniform
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) union_push(pend[j], key[j], cs, top_k);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) cur[k] = c1[k];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    cand_prune(cs, top_k);
+    {
+        const uint32_t cn = *cand_n;
+        unsigned long long* out = span_keys + (size_t)keys_base + (size_t)span * top_k;
+        for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
+    }
+    if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
+}
+
+void launch_scan_union(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
+                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+    if (!total_spans) return;
+    hipLaunchKernelGGL(k_scan_union, dim3(total_spans), dim3(64), scan_union_lds_bytes(cand_cap), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys,
+                       num_hits);
+}
+
+}  // namespace vq
