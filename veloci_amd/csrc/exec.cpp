@@ -461,6 +461,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     ws.d_up.ensure(up_bytes);
     uint8_t* hup = ws.h_up.as<uint8_t>();
     uint8_t* dup = ws.d_up.as<uint8_t>();
+    bool union_has_or = false;
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0;
     {
         size_t off = 0;
@@ -492,6 +493,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             static const bool union_or = std::getenv("VQ_UNION_OR") != nullptr;
             const bool dense = union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
             if (dense) {
+                union_has_or = union_has_or || cq.simple_n > 1;
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
@@ -550,7 +552,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
-    launch_scan_union(st, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
+    launch_scan_union(st, union_has_or, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
                       reinterpret_cast<const uint32_t*>(dup + up_qmap_d), n_dense, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());

@@ -1718,7 +1718,7 @@ namespace vq {
 constexpr uint32_t kUT = VQ_UT;       // docs per tile
 constexpr uint32_t kUTW = kUT / 32;   // bitmap words per list and tile
 // LDS map (u32): misc[8] | cand[2*cand_cap] | bm[4][kUTW] | val u16 [4][kUT]
-size_t scan_union_lds_bytes(uint32_t cand_cap) { return (size_t)(8 + 2 * cand_cap + 4 * kUTW + 4 * kUT / 2) * 4 + 16; }
+size_t scan_union_lds_bytes(uint32_t cand_cap, bool with_or) { return (size_t)(8 + 2 * cand_cap + (with_or ? 4 * kUTW + 4 * kUT / 2 : 0)) * 4 + 16; }
 
 __device__ __forceinline__ void union_push(bool pending, unsigned long long key, const CandState& cs, uint32_t top_k) {
     while (true) {  // uniform
@@ -1813,46 +1813,99 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
     if (n == 1) {
-        // ---- K1: stream [cur, end) of the one list
+        // ---- K1: stream [cur, end) of the one list, kU1 vectors of 4 postings per lane and round, the next round in flight.
+        // With a positive term score the value is monotone in the raw f16 bits, so postings are pre-filtered by comparing the raw
+        // bits with `raw_min`, the smallest raw score that can still reach the threshold; only those build a key.
         hits = end[0] - cur[0];
         const VQ_GLOBAL u32x4* dptr = reinterpret_cast<const VQ_GLOBAL u32x4*>(docs[0]);
         const VQ_GLOBAL uint2* sptr = reinterpret_cast<const VQ_GLOBAL uint2*>(scs[0]);
         const uint32_t v_end = (end[0] + 3u) >> 2;
-        uint32_t v = (cur[0] >> 2) + lane;
-        u32x4 d4 = kSent;
-        uint2 s4 = uint2{0u, 0u};
-        if (v < v_end) {
-            d4 = dptr[v];
-            s4 = uint2{sptr[v].x, sptr[v].y};
+        constexpr uint32_t kU1 = 3;
+        u32x4 d4[kU1];
+        uint2 s4[kU1];
+        const uint32_t v_first = cur[0] >> 2;
+        // rounds run from the END of the slice to its start: under (score desc, id desc) a later posting wins every tie, so an
+        // ascending scan of a list with few distinct scores would push on every tie; descending, ties never beat the threshold
+        const uint32_t n_rounds = (v_end - v_first + kU1 * 64u - 1u) / (kU1 * 64u);
+#pragma unroll
+        for (uint32_t u = 0; u < kU1; ++u) {
+            const uint32_t v = v_first + (n_rounds ? (n_rounds - 1u) * kU1 * 64u : 0u) + u * 64u + lane;
+            d4[u] = kSent;
+            s4[u] = uint2{0u, 0u};
+            if (v < v_end) {
+                d4[u] = dptr[v];
+                s4[u] = uint2{sptr[v].x, sptr[v].y};
+            }
         }
-        for (uint32_t v0 = cur[0] >> 2; v0 < v_end; v0 += 64u) {  // uniform
-            const uint32_t vn = v + 64u;
-            u32x4 nd4 = kSent;
-            uint2 ns4 = uint2{0u, 0u};
-            if (vn < v_end) {
-                nd4 = dptr[vn];
-                ns4 = uint2{sptr[vn].x, sptr[vn].y};
+        const bool monotone = ts[0] > 0.0f;  // otherwise every posting takes the exact path (raw_min = 0)
+        unsigned long long thr_seen = ~0ull;
+        uint32_t raw_min = 0;
+        for (uint32_t r = n_rounds; r-- > 0;) {  // uniform
+            const uint32_t v0 = v_first + r * kU1 * 64u;
+            u32x4 nd4[kU1];
+            uint2 ns4[kU1];
+#pragma unroll
+            for (uint32_t u = 0; u < kU1; ++u) {
+                const uint32_t vn = v0 - kU1 * 64u + u * 64u + lane;  // the round before (only read when r > 0)
+                nd4[u] = kSent;
+                ns4[u] = uint2{0u, 0u};
+                if (r > 0 && vn < v_end) {
+                    nd4[u] = dptr[vn];
+                    ns4[u] = uint2{sptr[vn].x, sptr[vn].y};
+                }
             }
-            const uint32_t i0 = v << 2;
             const unsigned long long thr_reg = *thr;
-            unsigned long long key[4];
-            bool pend[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t d = comp4(d4, j);
-                const uint32_t raw = j == 0 ? (s4.x & 0xFFFFu) : j == 1 ? (s4.x >> 16) : j == 2 ? (s4.y & 0xFFFFu) : (s4.y >> 16);
-                const float score = posting_value_fast(ts[0], (uint16_t)raw);
-                key[j] = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)d;
-                const uint32_t i = i0 + j;
-                pend[j] = v < v_end && i >= cur[0] && i < end[0] && key[j] > thr_reg;
+            if (thr_reg != thr_seen) {  // uniform: the threshold rose — smallest positive-f16 bit pattern whose value reaches its score
+                thr_seen = thr_reg;
+                raw_min = 0;
+                if (monotone && thr_reg != 0ull) {
+                    const uint32_t tbits = (uint32_t)(thr_reg >> 32);
+                    uint32_t lo = 0, hi = 0x7C00u;  // [0, +inf): finite non-negative f16
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (order_f32(__float_as_uint(posting_value_fast(ts[0], (uint16_t)mid))) < tbits) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    raw_min = lo;
+                }
             }
-            if (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {  // uniform; rare once the threshold has risen
+            // interior rounds need no index checks
+            const bool interior = (v0 << 2) >= cur[0] && ((v0 + kU1 * 64u) << 2) <= end[0];
+            bool any = false;
+            bool pass[kU1 * 4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) union_push(pend[j], key[j], cs, top_k);
+            for (uint32_t u = 0; u < kU1; ++u) {
+                const uint32_t v = v0 + u * 64u + lane;
+                const uint32_t i0 = v << 2;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t raw = j == 0 ? (s4[u].x & 0xFFFFu) : j == 1 ? (s4[u].x >> 16) : j == 2 ? (s4[u].y & 0xFFFFu) : (s4[u].y >> 16);
+                    // raw >= raw_min as integers: true for every candidate (negative / NaN patterns compare high and take the exact path)
+                    bool p = raw >= raw_min;
+                    if (!interior) p = p && v < v_end && (i0 + j) >= cur[0] && (i0 + j) < end[0];
+                    pass[u * 4 + j] = p;
+                    any = any || p;
+                }
             }
-            d4 = nd4;
-            s4 = ns4;
-            v = vn;
+            if (__ballot(any)) {  // uniform; rare once the threshold has risen
+#pragma unroll
+                for (uint32_t u = 0; u < kU1; ++u) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        if (__ballot(pass[u * 4 + j])) {  // uniform
+                            const uint32_t raw = j == 0 ? (s4[u].x & 0xFFFFu) : j == 1 ? (s4[u].x >> 16) : j == 2 ? (s4[u].y & 0xFFFFu) : (s4[u].y >> 16);
+                            const float score = posting_value_fast(ts[0], (uint16_t)raw);
+                            const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)comp4(d4[u], j);
+                            union_push(pass[u * 4 + j] && key > *thr, key, cs, top_k);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kU1; ++u) {
+                d4[u] = nd4[u];
+                s4[u] = ns4[u];
+            }
         }
     } else {
         // ---- K4: OR over n lists, tile by tile
@@ -2027,10 +2080,11 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
 }
 
-void launch_scan_union(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
-                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+                       const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_scan_union, dim3(total_spans), dim3(64), scan_union_lds_bytes(cand_cap), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys,
+    // single-leaf queries need no tile arrays: with 2-3 KB of LDS the register file, not LDS, bounds the waves per CU
+    hipLaunchKernelGGL(k_scan_union, dim3(total_spans), dim3(64), scan_union_lds_bytes(cand_cap, with_or), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys,
                        num_hits);
 }
 
