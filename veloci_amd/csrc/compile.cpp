@@ -446,6 +446,7 @@ struct Compiler {
                     h.global_len = ps.global_len[tid];
                     h.flags = LIST_HAS_SCORES;
                     h.term_score = score;
+                    h.max_raw = ps.max_raw[tid];
                     if (!ps.bm_start.empty() && ps.bm_start[tid] >= 0) {
                         h.flags |= LIST_BITMAP;
                         h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[tid];

@@ -38,7 +38,8 @@ struct DList {  // 48 B
     uint32_t len;
     uint32_t flags;
     float term_score;        // s_t (search_field.rs:426), request.boost folded in (:359-364)
-    uint32_t pad;
+    uint16_t max_raw;        // largest f16 bit pattern among the list's scores (all non-negative): bounds every posting value of the list
+    uint16_t pad;
     const uint32_t* bitmap;    // LIST_BITMAP: bit (doc - bitmap_base) set for every doc of the list
     const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + 2048 * k
 };

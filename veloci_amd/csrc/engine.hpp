@@ -155,6 +155,7 @@ struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segment
     std::vector<uint64_t> start;        // start[t]: first entry of list t inside docs/scores (multiple of 4)
     std::vector<uint32_t> len;          // entries of list t inside this shard
     std::vector<uint64_t> global_len;   // entries of list t in the unsharded index
+    std::vector<uint16_t> max_raw;      // largest f16 score bits of list t (upper bound for OR pruning)
     DevBuf docs;                        // u32, lists padded to a multiple of 4 with 0xFFFFFFFF
     DevBuf scores;                      // f16 bits (u16), same indexing
     uint64_t total_padded = 0;
@@ -285,6 +286,7 @@ struct HList {
     uint32_t len = 0;
     uint32_t flags = 0;
     float term_score = 0.f;
+    uint16_t max_raw = 0x7C00;  // +inf: no bound known
     uint64_t global_len = 0;
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;

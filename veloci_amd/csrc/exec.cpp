@@ -90,6 +90,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         d.len = l.len;
         d.flags = l.flags;
         d.term_score = l.term_score;
+        d.max_raw = l.max_raw;
         d.bitmap = l.d_bitmap;
         d.rank_dir = l.d_rank_dir;
         dl[i] = d;

@@ -161,6 +161,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         ps.start.resize(ps.num_tokens);
         ps.len.resize(ps.num_tokens);
         ps.global_len.resize(ps.num_tokens);
+        ps.max_raw.assign(ps.num_tokens, 0);
         std::vector<uint32_t> docs;
         std::vector<uint16_t> scores;
         docs.reserve(p.anchors.size() + 4 * size_t(std::min<uint32_t>(ps.num_tokens, 1u << 20)));
@@ -174,7 +175,11 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             ps.global_len[t] = p.global_lens.empty() ? uint64_t(re - rb) : p.global_lens[t];
             append_padded(docs, sb, se);
             const uint32_t* sc = p.scores.data() + (sb - p.anchors.data());
-            for (uint32_t i = 0; i < ps.len[t]; ++i) scores.push_back(f32_to_f16_rne(float(sc[i])));
+            for (uint32_t i = 0; i < ps.len[t]; ++i) {
+                const uint16_t h = f32_to_f16_rne(float(sc[i]));  // non-negative: bit order == value order
+                scores.push_back(h);
+                ps.max_raw[t] = std::max(ps.max_raw[t], h);
+            }
             while (scores.size() < docs.size()) scores.push_back(0);
         }
         ps.total_padded = docs.size();

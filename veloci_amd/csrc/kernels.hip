@@ -1218,6 +1218,16 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
     __syncthreads();
     uint32_t qlen = 0;
     unsigned long long hits = 0;
+    // OR pruning state: largest posting value per operand (+inf when unknown), masks whose bound still reaches the threshold
+    float or_max[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) {
+            const uint16_t mr = gl[gops[k].list_begin].max_raw;
+            or_max[k] = (lf[k].ts > 0.0f && mr < 0x7C00u) ? posting_value(lf[k].ts, mr) : __uint_as_float(0x7F800000u);
+        }
+    unsigned long long or_thr_seen = ~0ull;
+    uint32_t or_live = 0xFFFFu;
     uint32_t pos = span_lo;  // sequential mode: next doc to cover
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const u32x4 kZero = u32x4{0u, 0u, 0u, 0u};
@@ -1326,6 +1336,54 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
         (void)wave_excl_scan_u32(popc4(r), &S);
         if (S) {  // uniform
             hits += S;
+            if (kind == OP_OR) {
+                // Upper-bound pruning (exact): a doc present in exactly the operands of mask m scores at most
+                // ub[m] = (sum over m's slots of the largest posting value of the slot's lists) * |slots|^2 — the score formula
+                // evaluated on per-list maxima, and f32 add / mul are monotone.  Once the threshold exceeds ub[m] such docs are
+                // counted as hits (above) but not scored.  Typical OR: after the first tiles only docs in ALL operands stay live.
+                const unsigned long long thr_now = *thr;
+                if (thr_now != or_thr_seen) {  // uniform, rare
+                    or_thr_seen = thr_now;
+                    or_live = 0xFFFFu;
+                    if (thr_now != 0ull) {
+                        const uint32_t tbits = (uint32_t)(thr_now >> 32);
+                        or_live = 0u;
+                        for (uint32_t m = 1; m < (1u << n); ++m) {
+                            float sum = 0.0f, nd = 0.0f;
+                            for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                float ms = 0.0f;
+                                bool any = false;
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k)
+                                    if (k < n && ((m >> k) & 1u) && slot[k] == sl) {
+                                        ms = fmaxf(ms, pick4(or_max[0], or_max[1], or_max[2], or_max[3], k));
+                                        any = true;
+                                    }
+                                if (any) nd += 1.0f;
+                                sum += ms;
+                            }
+                            const float ub = sum * nd * nd;
+                            if (!(order_f32(__float_as_uint(ub)) < tbits)) or_live |= 1u << m;  // NaN / inf bounds stay live
+                        }
+                    }
+                }
+                if (or_live != 0xFFFFu) {
+                    u32x4 ev = kZero;
+                    for (uint32_t m = 1; m < (1u << n); ++m) {
+                        if ((or_live >> m) & 1u) {  // uniform
+                            u32x4 t = ~kZero;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                if (k < n) t &= ((m >> k) & 1u) ? wk[k] : ~wk[k];
+                            ev |= t;
+                        }
+                    }
+                    r = ev;
+                    uint32_t S2;
+                    (void)wave_excl_scan_u32(popc4(r), &S2);
+                    if (!S2) continue;  // uniform: nothing in this tile can enter the top-k
+                }
+            }
             // rank of each list at this lane's first word, and the popcounts of the lane's words before word j
             uint32_t run[4] = {0, 0, 0, 0};
             uint32_t c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, c3[4] = {0, 0, 0, 0}, tot_k[4] = {0, 0, 0, 0};
