@@ -42,7 +42,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="and", choices=["and", "or", "single"], help="and = the headline metric; or / single = extra shapes")
+    ap.add_argument("--workload", default="and", choices=["and", "or", "single", "config3", "and_of_ors", "mix", "config4"],
+                    help="and = the headline metric; or / single = extra shapes; config3 = AND + 2 phrase pairs + text locality; "
+                         "and_of_ors = AND(OR,OR) + Log10 boost + phrase + locality; mix = 40%% and / 40%% or / 20%% and_of_ors (BASELINE configs #3 / #5); "
+                         "config4 = lev-2 fuzzy term + facets on cat and tags[] (use --docs 10000000 --terms 1000000)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -73,8 +76,10 @@ def main():
     # ---- synthetic index shard (deterministic; shard == slice of the unsharded index)
     t0 = time.time()
     lo, hi = vdist.shard_range(args.docs, rank, world)
-    spec = synth.SynthSpec(num_docs=args.docs, num_terms=args.terms, triples=args.triples, with_t2t=False, with_facets=False, with_boost=False,
-                           with_phrase=False, background_terms=0)
+    rich = args.workload in ("config3", "and_of_ors", "mix")  # these need the phrase pairs, token->text lists and the boost column
+    fuzzy = args.workload == "config4"
+    spec = synth.SynthSpec(num_docs=args.docs, num_terms=args.terms, triples=args.triples, with_t2t=rich, with_facets=fuzzy, with_boost=rich,
+                           with_phrase=rich, background_terms=2000 if fuzzy else 0)
     data, meta = synth.generate(spec, doc_lo=lo, doc_hi=hi, device=f"cuda:{local_rank}")
     t_gen = time.time() - t0
     if world > 1:
@@ -90,8 +95,40 @@ def main():
         reqs_json = [synth.req_and(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
     elif args.workload == "or":
         reqs_json = [synth.req_or(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
-    else:
+    elif args.workload == "config4":
+        # 100 distinct query terms: vocabulary terms with posting lists, 1-2 random edits each
+        rng = np.random.default_rng(4)
+        pool = [t for tri in meta.triples for t in tri] + list(meta.background)
+        alphabet = "abcdefghijklmnopqrstuvwxyz"
+        def edit(w):
+            w = list(w)
+            for _ in range(int(rng.integers(1, 3))):
+                op = int(rng.integers(0, 3))
+                pos = int(rng.integers(0, len(w)))
+                if op == 0 and len(w) > 3:
+                    del w[pos]
+                elif op == 1:
+                    w.insert(pos, alphabet[int(rng.integers(0, 26))])
+                else:
+                    w[pos] = alphabet[int(rng.integers(0, 26))]
+            return "".join(w)
+        qterms = [edit(pool[int(rng.integers(0, len(pool)))]) for _ in range(100)]
+        reqs_json = [{"search_req": {"search": {"path": "body", "terms": [qterms[i % len(qterms)]], "levenshtein_distance": 2}}, "top": 10,
+                      "facets": [{"field": "cat"}, {"field": "tags[]"}]} for i in range(args.batch)]
+    elif args.workload == "single":
         reqs_json = [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(args.batch)]
+    else:
+        tri = lambda i: list(meta.triples[i % len(meta.triples)])
+        def and_of_ors(i):
+            a, b = tri(i), tri(i + 1)
+            return synth.req_and_of_ors([a[0], a[1]], [a[2], b[2]], top=10)
+        if args.workload == "config3":
+            reqs_json = [synth.req_and_phrase_locality(tri(i), top=10) for i in range(args.batch)]
+        elif args.workload == "and_of_ors":
+            reqs_json = [and_of_ors(i) for i in range(args.batch)]
+        else:
+            reqs_json = [synth.req_and(tri(i), top=10) if i % 5 in (0, 1) else synth.req_or(tri(i), top=10) if i % 5 in (2, 3) else and_of_ors(i)
+                         for i in range(args.batch)]
     reqs = [veloci_amd.Request(r) for r in reqs_json]
     batch = veloci_amd.RequestBatch(reqs)
     searcher = vdist.ShardedSearcher(index) if world > 1 else None
@@ -164,7 +201,11 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 doc ids + f16->f32 scores", "data": "synthetic",
-            "config": {"workload": f"{args.docs}-doc synthetic index, " + {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan"}[args.workload] +
+            "config": {"workload": f"{args.docs}-doc synthetic index, " + {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan",
+                                                                              "config3": "3-term AND + 2 phrase pairs + text locality",
+                                                                              "and_of_ors": "AND(OR,OR) + Log10 boost + phrase + locality",
+                                                                              "mix": "40% AND / 40% OR / 20% AND(OR,OR)+boost+phrase+locality",
+                                                                              "config4": "lev-2 fuzzy term + facets (cat, tags[])"}[args.workload] +
                        f" (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},

@@ -5,10 +5,15 @@ import torch
 import veloci_amd
 from veloci_amd import synth
 docs = int(os.environ.get("DOCS", "100000000")); tri = int(os.environ.get("TRIPLES", "8"))
-spec = synth.SynthSpec(num_docs=docs, num_terms=10000, triples=tri, with_t2t=False, with_facets=False, with_boost=False, with_phrase=False)
+kind = os.environ.get("KIND", "and")  # and | config3 | and_of_ors
+rich = kind != "and"
+spec = synth.SynthSpec(num_docs=docs, num_terms=10000, triples=tri, with_t2t=rich, with_facets=False, with_boost=rich, with_phrase=rich)
 data, meta = synth.generate(spec)
 idx = veloci_amd.Index(data)
-reqs = [veloci_amd.Request(synth.req_and(list(meta.triples[i % tri]))) for i in range(int(os.environ.get("BATCH", "256")))]
+T = lambda i: list(meta.triples[i % tri])
+mk = {"and": lambda i: synth.req_and(T(i)), "config3": lambda i: synth.req_and_phrase_locality(T(i)),
+      "and_of_ors": lambda i: synth.req_and_of_ors(T(i)[:2], [T(i)[2], T(i + 1)[2]])}[kind]
+reqs = [veloci_amd.Request(mk(i)) for i in range(int(os.environ.get("BATCH", "256")))]
 L = veloci_amd.lib()
 buf = (C.c_ulonglong * 16)()
 veloci_amd.search_batch(reqs, idx)

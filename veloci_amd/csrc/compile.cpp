@@ -208,6 +208,7 @@ struct Compiler {
         const bool ci = p.ignore_case.value_or(true);  // search_field.rs:88
         const auto query_cps = vqtext::decode_utf8(p.terms[0]);
         std::vector<uint32_t> cand;
+        const FuzzyProbe* probe = nullptr;
         const bool scan = lev != 0 || p.starts_with;
         if (scan) {  // match set computed on the device before compilation (k_dict_scan), ascending == FST stream order
             const FuzzyProbe* fp = nullptr;
@@ -218,6 +219,7 @@ struct Compiler {
             if (!fp) unsupported("levenshtein_distance > 0 / starts_with without a dictionary scan (internal)");
             if (fp->status != 0) throw VelociError(fp->status, fp->error);
             cand = fp->matches;
+            probe = fp;
         } else if (ci) {
             auto it = dict.lower_map.find(lower_term);
             if (it != dict.lower_map.end()) cand = it->second;
@@ -229,7 +231,8 @@ struct Compiler {
         const size_t top_n_search = p.top.value_or(10) + p.skip.value_or(0);
         float worst_score = -std::numeric_limits<float>::max();
         const bool check_prefix = p.starts_with || lev != 0;  // :302
-        for (uint32_t id : cand) {  // ascending ids == FST stream order
+        for (size_t ci_ = 0; ci_ < cand.size(); ++ci_) {  // ascending ids == FST stream order
+            const uint32_t id = cand[ci_];
             if (!scan) {
                 const auto cps = vqtext::decode_utf8(dict.terms[id]);
                 if (cps.size() != query_cps.size()) continue;
@@ -239,9 +242,13 @@ struct Compiler {
             }
             if (get_ids) l.hits_ids.push_back(id);
             if (get_scores) {  // :304-354
-                const std::string lower_hit = vqtext::to_lower_utf8(dict.terms[id]);
-                const bool prefix_matches = check_prefix && lower_hit.compare(0, lower_term.size(), lower_term) == 0 && lower_hit.size() >= lower_term.size();
-                const float score = default_score_for_distance(scoring_distance(lower_hit, lower_term, lev), prefix_matches);
+                float score;
+                if (probe) score = probe->scores[ci_];
+                else {
+                    const std::string lower_hit = vqtext::to_lower_utf8(dict.terms[id]);
+                    const bool prefix_matches = check_prefix && lower_hit.compare(0, lower_term.size(), lower_term) == 0 && lower_hit.size() >= lower_term.size();
+                    score = default_score_for_distance(scoring_distance(lower_hit, lower_term, lev), prefix_matches);
+                }
                 if (limit_result) {
                     if (score < worst_score) continue;
                     if (!l.hits_scores.empty() && l.hits_scores.size() == top_n_search + 200) {  // sort.rs:24-34
@@ -1076,6 +1083,14 @@ struct Compiler {
         cq.stack_depth = std::max<uint32_t>(max_depth, 1);
         uint64_t spans = (cq.total_len + span_postings - 1) / span_postings;
         const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
+        {  // k_tile_scan pays a latency-bound round trip per visited tile (score gathers, facet rows): at most ~16 visited tiles per span
+            uint64_t cover_len = 0;
+            for (auto& l : cq.lists)
+                if (l.flags & LIST_COVER) cover_len += l.len;
+            const uint64_t visited = std::max<uint64_t>(std::min<uint64_t>(cover_len, tiles), 1);
+            // (k_scan_simple batches its gathers across tiles; tiles with a lot of postings are bandwidth-, not latency-bound)
+            if (!cq.simple_flags && cq.total_len / visited < 1024) spans = std::max<uint64_t>(spans, visited / 16);
+        }
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);
         cq.n_spans = uint32_t(spans);
@@ -1111,6 +1126,9 @@ static void probe_part(const Index& idx, const RequestSearchPart& p, FuzzyTable&
     fp.transposition = p.ignore_case.value_or(false);
     fp.ci = p.ignore_case.value_or(true);
     fp.prefix = p.starts_with;
+    fp.lower_term = vqtext::to_lower_utf8(p.terms[0]);
+    fp.lev = clamped_lev(p);
+    fp.check_prefix = p.starts_with || fp.lev != 0;  // :302
     const auto cps = vqtext::decode_utf8(p.terms[0]);
     if (!dit->second.bmp_only) {
         fp.status = ERR_UNSUPPORTED;
@@ -1133,6 +1151,18 @@ static void probe_tree(const Index& idx, const SearchRequest& r, FuzzyTable& tab
     else
         for (auto& q : r.tree.queries) probe_tree(idx, q, table);
 }
+// score of every match of a probe (search_field.rs:304-321), shared by all requests of the batch that contain the leaf
+void score_fuzzy_probe(const Index& idx, FuzzyProbe& fp) {
+    if (fp.status != 0) return;
+    const Dictionary& dict = idx.dict.at(fp.path);
+    fp.scores.resize(fp.matches.size());
+    for (size_t i = 0; i < fp.matches.size(); ++i) {
+        const std::string lower_hit = vqtext::to_lower_utf8(dict.terms[fp.matches[i]]);
+        const bool prefix_matches = fp.check_prefix && lower_hit.size() >= fp.lower_term.size() && lower_hit.compare(0, fp.lower_term.size(), fp.lower_term) == 0;
+        fp.scores[i] = default_score_for_distance(scoring_distance(lower_hit, fp.lower_term, fp.lev), prefix_matches);
+    }
+}
+
 void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& table) {
     if (req.search_req) probe_tree(idx, *req.search_req, table);
     if (req.filter) probe_tree(idx, *req.filter, table);

@@ -126,6 +126,10 @@ struct FuzzyProbe {  // one dictionary scan of a batch (get_text_lines_from_fst,
     uint32_t max_d = 0;
     bool transposition = false, prefix = false, ci = true;
     std::vector<uint32_t> matches;    // ascending term ids == FST stream order
+    std::vector<float> scores;        // default_score_for_distance of every match (search_field.rs:304-321), scored once per batch
+    std::string lower_term;           // scoring side: the lower-cased term, the clamped distance, the prefix rule (:284-302)
+    uint32_t lev = 0;
+    bool check_prefix = false;
     int status = 0;
     std::string error;
 };
@@ -134,6 +138,7 @@ std::string fuzzy_key(const vqreq::RequestSearchPart& p);
 bool needs_dictionary_scan(const vqreq::RequestSearchPart& p);
 void collect_fuzzy_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
 void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st);
+void score_fuzzy_probe(const Index& idx, FuzzyProbe& probe);
 
 // A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the
 // terms' posting lists with the per-doc maximum of term_score * (f16 / 100).

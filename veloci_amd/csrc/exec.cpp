@@ -184,6 +184,19 @@ void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
         }
         active.swap(overflow);
     }
+    // host side of the leaf: score every match once per distinct probe (a few threads when there is a lot to score)
+    size_t total = 0;
+    for (FuzzyProbe* fp : todo) total += fp->matches.size();
+    if (total >= 4096 && todo.size() >= 2) {
+        const size_t nt = std::min<size_t>(4, todo.size());
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (size_t i = t; i < todo.size(); i += nt) score_fuzzy_probe(idx, *todo[i]);
+            });
+        for (auto& t : th) t.join();
+    } else
+        for (FuzzyProbe* fp : todo) score_fuzzy_probe(idx, *fp);
 }
 
 // K2: run the union jobs of a batch.  Level 1 merges groups of <= 64 posting lists (one lane per list); a job with
@@ -214,7 +227,7 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
             ulists.push_back(tasks[t].lists[i]);
         }
         u.pivot = u.list_begin + piv;
-        uint64_t spans = std::min<uint64_t>(std::max<uint64_t>(total / 16384, 1), 256);
+        uint64_t spans = std::min<uint64_t>(std::max<uint64_t>(total / 2048, 1), 4096);
         spans = std::min<uint64_t>(spans, std::max<uint32_t>(tasks[t].lists[piv].len, 1u));
         u.span_begin = uint32_t(span_task.size());
         u.n_spans = uint32_t(spans);
@@ -344,6 +357,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     for (size_t i = 0; i < n; ++i)
         if (reqs[i]) collect_fuzzy_probes(idx, *reqs[i], fuzzy);
     if (!fuzzy.empty()) run_fuzzy_probes(idx, fuzzy, st);
+    const double t_probes = now_ms();
     pb->queries.reserve(n);
     pb->slot.assign(n, UINT32_MAX);
     pb->queries.resize(n);
@@ -362,6 +376,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         compile_range(0, n / nt);
         for (auto& t : th) t.join();
     } else compile_range(0, n);
+    const double t_pass1 = now_ms();
+    double t_unions = t_pass1;
     // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch, compile those queries again
     UnionTable unions;
     std::vector<size_t> again;
@@ -372,6 +388,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     if (!again.empty()) {
         run_union_jobs(idx, ws, unions, st);
+        t_unions = now_ms();
         auto recompile = [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
                 CompiledQuery& q = pb->queries[again[k]];
@@ -572,7 +589,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
-        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms, pack+launch %.3f ms\n", n, t_compiled - t_start, now_ms() - t_compiled);
+        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), pack+launch %.3f ms\n", n,
+                     t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_unions, now_ms() - t_compiled);
     return pb;
 }
 
