@@ -950,19 +950,43 @@ struct Compiler {
                     continue;
                 }
                 DLocField lf{};
-                lf.list_begin = uint16_t(cq.lists.size());
+                lf.list_begin = uint16_t(cq.loc_idx.size());
                 uint32_t count = 0;
+                const PostingStore* same_ps = nullptr;  // identity column: token->text row t == docs of posting list t (checked when staged)
+                if (t2t.rows_equal_postings) {
+                    auto pit = idx.postings.find(path + TO_ANCHOR_ID_SCORE);
+                    if (pit != idx.postings.end()) same_ps = &pit->second;
+                }
                 for (auto& [term, ids] : terms)
                     for (uint32_t id : ids) {
                         if (id < t2t.key_base || id - t2t.key_base >= t2t.num_keys) continue;
                         const uint32_t r = id - t2t.key_base;
                         if (t2t.host_off[r] == t2t.host_off[r + 1]) continue;
                         HList h;
-                        h.d_docs = t2t.values.as<uint32_t>() + t2t.start[r];
-                        h.len = t2t.len[r];
+                        if (same_ps && id < same_ps->num_tokens) {  // read the posting list's doc ids (and its bitmap image) instead of a second copy
+                            h.d_docs = same_ps->docs.as<uint32_t>() + same_ps->start[id];
+                            h.len = same_ps->len[id];
+                            if (!same_ps->bm_start.empty() && same_ps->bm_start[id] >= 0) {
+                                h.flags |= LIST_BITMAP;
+                                h.d_bitmap = same_ps->bitmaps.as<uint32_t>() + same_ps->bm_start[id];
+                                h.d_rank_dir = same_ps->rank_dir.as<uint32_t>() + same_ps->rd_start[id];
+                            }
+                        } else {
+                            h.d_docs = t2t.values.as<uint32_t>() + t2t.start[r];
+                            h.len = t2t.len[r];
+                        }
                         h.global_len = t2t.host_off[r + 1] - t2t.host_off[r];
-                        add_list(h);
-                        cq.algorithmic_bytes += 4ull * h.len;
+                        uint32_t li = UINT32_MAX;
+                        for (uint32_t e = 0; e < cq.lists.size(); ++e)  // already a list of this query (the term's own posting leaf): share its tile bitmap
+                            if (cq.lists[e].d_docs == h.d_docs && cq.lists[e].inline_idx < 0 && cq.lists[e].len == h.len) {
+                                li = e;
+                                break;
+                            }
+                        if (li == UINT32_MAX) {
+                            li = add_list(h);
+                            cq.algorithmic_bytes += 4ull * h.len;
+                        }
+                        cq.loc_idx.push_back(uint16_t(li));
                         ++count;
                     }
                 lf.list_count = uint16_t(count);

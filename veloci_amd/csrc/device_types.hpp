@@ -100,7 +100,8 @@ struct DColBoost {  // boost.rs:283-377, 470-504
 
 constexpr uint16_t kLocPrecomputed = 0xFFFF;
 struct DLocField {  // one text field with >= 2 query terms (boost.rs:34-87)
-    uint16_t list_begin, list_count;  // identity column: the terms' token->text lists, counted per doc;
+    uint16_t list_begin, list_count;  // identity column: loc_idx[list_begin .. + list_count) are the terms' token->text lists (any list of
+                                      // the query, possibly the posting lists themselves), counted per doc;
                                       // list_count == kLocPrecomputed: list_begin is one (anchor, f32 2*c*c) list
 };
 
@@ -126,6 +127,8 @@ struct QHeader {
     uint32_t blob_bytes;
     uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
+    uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
+    uint32_t pad0;
     uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are

@@ -178,6 +178,7 @@ struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device ima
     // list use: values are anchors -> every row is a padded, sorted, unique doc-id list in HBM
     bool list_rows = false;
     bool rows_sorted_unique = true;
+    bool rows_equal_postings = false;  // tokens_to_text_id of an identity column: row t holds exactly the docs of posting list t
     std::vector<uint64_t> start;  // first entry of row r inside `values` (multiple of 4)
     std::vector<uint32_t> len;    // entries of row r inside this shard
     DevBuf values;
@@ -325,6 +326,7 @@ struct CompiledQuery {
     std::vector<DTermBoost> tboosts;
     std::vector<DColBoost> cols;
     std::vector<DLocField> locf;
+    std::vector<uint16_t> loc_idx;
     std::vector<DFacet> facets;
     std::vector<FacetOut> facet_out;
     uint32_t top = 10, skip = 0, top_k = 10;

@@ -60,6 +60,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.n_pres = uint32_t(cq.pres.size());
     h.off_pres = uint32_t(section(cq.pres.size() * sizeof(DPresOp)));
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
+    h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
     h.n_temps = cq.n_temps;
     h.simple_n = cq.simple_n;
     h.bitmap_base = idx.bitmap_base;
@@ -101,6 +102,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!cq.tboosts.empty()) std::memcpy(dst + h.off_tboost, cq.tboosts.data(), cq.tboosts.size() * sizeof(DTermBoost));
     if (!cq.cols.empty()) std::memcpy(dst + h.off_col, cq.cols.data(), cq.cols.size() * sizeof(DColBoost));
     if (!cq.locf.empty()) std::memcpy(dst + h.off_locf, cq.locf.data(), cq.locf.size() * sizeof(DLocField));
+    if (!cq.loc_idx.empty()) std::memcpy(dst + h.off_loc_idx, cq.loc_idx.data(), cq.loc_idx.size() * sizeof(uint16_t));
     if (!cq.pres.empty()) std::memcpy(dst + h.off_pres, cq.pres.data(), cq.pres.size() * sizeof(DPresOp));
     if (!cq.pres_in.empty()) std::memcpy(dst + h.off_pres_in, cq.pres_in.data(), cq.pres_in.size() * sizeof(uint16_t));
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);

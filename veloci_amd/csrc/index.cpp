@@ -237,6 +237,16 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             identity_t2t = idx->is_anchor_identity(ti);
         }
         s.list_rows = ends_with(path, TEXT_ID_TO_ANCHOR) || identity_t2t;
+        if (identity_t2t) {  // text id == anchor: row t must then be the doc list of posting list t; verify instead of assuming
+            std::string pp = path.substr(0, path.size() - std::strlen(TOKENS_TO_TEXT_ID)) + TO_ANCHOR_ID_SCORE;
+            auto bit = b.postings.find(pp);
+            if (bit != b.postings.end() && bit->second.offsets.size() == k.offsets.size() && k.key_base == 0) {
+                const auto& po = bit->second;
+                bool same = po.offsets == k.offsets && po.anchors.size() == k.values.size() &&
+                            std::memcmp(po.anchors.data(), k.values.data(), k.values.size() * 4) == 0;
+                s.rows_equal_postings = same;
+            }
+        }
         if (s.list_rows) {
             s.start.resize(s.num_keys);
             s.len.resize(s.num_keys);

@@ -249,6 +249,7 @@ struct ScoreCtx {
     const DColBoost* cols;
     uint32_t n_col;
     const DLocField* locf;
+    const uint16_t* loc_idx;
     uint32_t n_locf;
     const DFacet* facets;
     uint32_t n_facets;
@@ -405,7 +406,7 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint3
                 continue;
             }
             uint32_t cnt = 0;
-            for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += (c.bm[(c.locf[f].list_begin + j) * c.WW + w] >> b) & 1u;
+            for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += (c.bm[(uint32_t)c.loc_idx[c.locf[f].list_begin + j] * c.WW + w] >> b) & 1u;
             if (cnt > 1u) {
                 float bv = 2.0f * (float)cnt * (float)cnt;
                 if (!have || bv < best) best = bv;
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     const DTermBoost* tboosts = reinterpret_cast<const DTermBoost*>(blob + H->off_tboost);
     const DColBoost* cols = reinterpret_cast<const DColBoost*>(blob + H->off_col);
     const DLocField* locf = reinterpret_cast<const DLocField*>(blob + H->off_locf);
+    const uint16_t* loc_idx = reinterpret_cast<const uint16_t*>(blob + H->off_loc_idx);
     const DFacet* facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
     const DPresOp* pres = reinterpret_cast<const DPresOp*>(blob + H->off_pres);
     const uint16_t* pres_in = reinterpret_cast<const uint16_t*>(blob + H->off_pres_in);
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             __syncthreads();  // one wave: orders the LDS writes above before the reads below
             VQ_STAMP_AT(4)
 
-            ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, n_locf, facets, n_facets,
+            ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
                         bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist};
             uint32_t it_a = compact ? lane : 0u;
             uint32_t it_r = compact ? 0u : rootw[w0];
