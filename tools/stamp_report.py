@@ -21,9 +21,8 @@ L.vq_debug_stamps(buf, 1)
 veloci_amd.search_batch(reqs, idx)
 L.vq_debug_stamps(buf, 1)
 v = list(buf)
-names = ["init", "P0+P1 clear", "P2 scatter", "P3 presence", "P4 prefix", "P5 eval", "final"]
-tot = sum(v[:7])
-for n, x in zip(names, v[:7]):
-    print(f"{n:14s} {x/tot*100:6.2f}%   {x/max(v[7],1):10.1f} ticks/tile")
-print("P2 detail: issue", v[9]/max(v[7],1), "process", v[10]/max(v[7],1), "barrier", v[2]/max(v[7],1))
+names = {0: "init", 1: "P0 next tile + P1 clear", 9: "P2 issue first loads", 10: "P2 scatter / copy", 2: "P2 barrier", 3: "P3 presence", 4: "P4 prefix", 5: "P5 eval", 6: "final"}
+tot = sum(v[k] for k in names)
+for k, n in names.items():
+    print(f"{n:26s} {v[k]/tot*100:6.2f}%   {v[k]/max(v[7],1):10.1f} ticks/tile")
 print("tiles", v[7], "wgs", v[8], "ticks/tile total", tot / max(v[7], 1))

@@ -568,7 +568,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
-    launch_scan_simple(st, false, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+    launch_scan_simple(st, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());

@@ -1066,8 +1066,7 @@ constexpr uint32_t kSLdsQDoc = 8;
 constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
 constexpr uint32_t kSLdsCand = kSLdsQIdx + 4 * kQCap;
 
-constexpr uint32_t kSliceU16 = 4096 + 64;  // u16 entries of staged f16 scores (dense tiles): 1 list x 2048 or 4 lists x 1024 (+ alignment slack)
-size_t scan_simple_lds_bytes(uint32_t cand_cap, bool dense) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW + (dense ? kSliceU16 / 2 : 0)) * 4 + 16; }
+size_t scan_simple_lds_bytes(uint32_t cand_cap) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW) * 4 + 16; }
 
 struct SimpleLeaf {
     const uint32_t* docs;
@@ -1139,7 +1138,6 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
     }
 }
 
-template <bool DENSE>
 __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                     uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
@@ -1398,95 +1396,6 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
                     run[k] = base_idx[k] + wave_excl_scan_u32(c3[k] + (uint32_t)__popc(wk[k].w), &tot_k[k]);
                 }
             }
-            // ---- dense tile (OR / single-term scans: most docs of the tile are hits).  The f16 scores of the tile's
-            //      entries are contiguous per list: stage them into LDS with coalesced 8-byte loads, then every lane
-            //      walks its own bits and reads scores from LDS — no global gathers, no queue traffic.  Optimistic:
-            //      if the candidate buffer overflows the tile's pushes are discarded and the queue path below redoes it.
-            bool dense_done = false;
-            const uint32_t scap = n == 1 ? 2048u : 1024u;
-            bool fits = DENSE && S >= 512u && *thr != 0ull;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (k < n && tot_k[k] + 4u > scap) fits = false;
-            if (DENSE && fits) {  // uniform
-                uint16_t* slices = reinterpret_cast<uint16_t*>(bml + 4 * kSWW);
-                uint32_t soff[4] = {0, 0, 0, 0};  // slice index of the entry with rank run[k] (this lane's first word)
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (k < n) {
-                        const uint32_t e0 = base_idx[k] & ~3u;
-                        const uint32_t n8 = ((base_idx[k] - e0) + tot_k[k] + 3u) >> 2;
-                        const VQ_GLOBAL uint2* src = as_global(reinterpret_cast<const uint2*>(lf[k].scores + e0));
-                        uint2* dst = reinterpret_cast<uint2*>(slices + k * (scap + 8u));
-                        for (uint32_t u = lane; u < n8; u += 64u) {
-                            const uint2 v = uint2{src[u].x, src[u].y};
-                            dst[u] = v;
-                        }
-                        soff[k] = k * (scap + 8u) + (run[k] - e0);
-                    }
-                }
-                if ((*cand_n) + 0u > cand_cap / 2u) cand_prune(cs, top_k);  // uniform: make room first
-                __syncthreads();
-                const uint32_t cand_n0 = *cand_n;
-                const unsigned long long thr_reg = *thr;
-                bool overflow = false;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    uint32_t rw = comp4(r, j);
-                    const uint32_t wdoc = tile_lo + (((lane << 2) + j) << 5);
-                    uint32_t wj[4], pj[4];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        wj[k] = k < n ? comp4(wk[k], j) : 0u;
-                        pj[k] = soff[k] + (j == 0 ? 0u : j == 1 ? c1[k] : j == 2 ? c2[k] : c3[k]);
-                    }
-                    while (rw) {
-                        const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
-                        rw &= rw - 1u;
-                        const uint32_t below = (1u << b) - 1u;
-                        float val[4] = {0.f, 0.f, 0.f, 0.f};
-                        uint32_t pm = 0;
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            if (k < n && ((wj[k] >> b) & 1u)) {
-                                pm |= 1u << k;
-                                val[k] = posting_value_fast(lf[k].ts, slices[pj[k] + (uint32_t)__popc(wj[k] & below)]);
-                            }
-                        }
-                        float score;
-                        if (n == 1) score = val[0];
-                        else if (kind == OP_AND) {
-                            score = 0.0f;
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k)
-                                if (k < n) score += pick4(val[0], val[1], val[2], val[3], order[k]);
-                        } else {
-                            float sum = 0.0f, nd = 0.0f;
-                            for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                float m = 0.0f;
-#pragma unroll
-                                for (uint32_t k = 0; k < 4; ++k)
-                                    if (k < n && slot[k] == sl && ((pm >> k) & 1u)) m = fmaxf(m, val[k]);
-                                if (m >= 0.00001f) nd += 1.0f;
-                                sum += m;
-                            }
-                            score = sum * nd * nd;
-                        }
-                        const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)(wdoc + b);
-                        if (key > thr_reg) {
-                            const uint32_t pos = atomicAdd(cand_n, 1u);
-                            if (pos < cand_cap) cand[pos] = key;
-                            else overflow = true;
-                        }
-                    }
-                }
-                if (__syncthreads_or(overflow ? 1 : 0)) {
-                    if (lane == 0) *cand_n = cand_n0;  // forget this tile's pushes; the queue path redoes the tile
-                    __syncthreads();
-                    cand_prune(cs, top_k);
-                } else dense_done = true;
-            }
-            if (dense_done) continue;  // next tile
             // every round each lane emits its next surviving doc (lowest word, lowest bit first): the number of
             // rounds is the largest survivor count of a lane (1-2 for an AND tile, up to 128 for a dense OR tile)
             u32x4 rr = r;
@@ -1552,14 +1461,10 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
 }
 
-void launch_scan_simple(hipStream_t st, bool dense, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+void launch_scan_simple(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
     if (!total_spans) return;
-    const size_t lds_bytes = scan_simple_lds_bytes(cand_cap, dense);
-    if (dense)
-        hipLaunchKernelGGL(k_scan_simple<true>, dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
-    else
-        hipLaunchKernelGGL(k_scan_simple<false>, dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+    hipLaunchKernelGGL(k_scan_simple, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
 }
 
 }  // namespace vq
