@@ -400,3 +400,90 @@ def test_reference_integration_case(case):
     if got is not None:
         exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in case["request"].get("boost", []))
         assert_same(case["request"], got, ora.search_json(json.dumps(case["request"])), exact_scores=exact)
+
+
+# ------------------------------------------------------------------ randomized differential test on the reference's own fixture corpus
+def _random_request(rng, info, depth=0):
+    """Random Request over the `test_all` corpus: trees of exact / fuzzy / prefix leaves, filters, boosts, phrase pairs, locality, facets."""
+    text_fields = ["meanings.ger[]", "meanings.eng[]", "tags[]", "title", "ent_seq", "kanji[].text", "field1[].text", "address[].line[]"]
+
+    def leaf():
+        path = text_fields[int(rng.integers(0, len(text_fields)))]
+        terms = info[path]["terms"]
+        words = [t for t in terms if t.strip() and len(t) <= 20]
+        t = words[int(rng.integers(0, len(words)))]
+        part = {"path": path, "terms": [t]}
+        r = rng.random()
+        if r < 0.25:
+            part["levenshtein_distance"] = int(rng.integers(1, 3))
+        elif r < 0.4:
+            part["terms"] = [t[:max(1, len(t) // 2)]]
+            part["starts_with"] = True
+        if rng.random() < 0.2:
+            part["ignore_case"] = bool(rng.integers(0, 2))
+        if rng.random() < 0.2:
+            part["boost"] = float(rng.choice([0.5, 2.0, 3.5]))
+        return {"search": part}
+
+    def tree(d):
+        if d >= 2 or rng.random() < 0.4:
+            return leaf()
+        kind = "and" if rng.random() < 0.4 else "or"
+        return {kind: {"queries": [tree(d + 1) for _ in range(int(rng.integers(2, 4)))]}}
+
+    req = {"search_req": tree(0), "top": int(rng.choice([1, 3, 10, 50]))}
+    if rng.random() < 0.2:
+        req["skip"] = int(rng.integers(0, 3))
+    if rng.random() < 0.25:
+        req["filter"] = tree(1)
+    if rng.random() < 0.3:
+        req["boost"] = [{"path": "commonness", "boost_fun": str(rng.choice(["Multiply", "Add", "Replace", "Log10", "Log2"])), "param": float(rng.choice([0.0, 1.0, 2.0]))}]
+    if rng.random() < 0.25:
+        a, b = leaf()["search"], leaf()["search"]
+        b["path"] = a["path"]
+        b["terms"] = [info[a["path"]]["terms"][int(rng.integers(0, len(info[a["path"]]["terms"])))]]
+        for p in (a, b):
+            for key in ("levenshtein_distance", "starts_with", "boost"):
+                p.pop(key, None)
+        req["phrase_boosts"] = [{"search1": a, "search2": b}]
+    if rng.random() < 0.2:
+        bt = leaf()["search"]
+        bt.pop("boost", None)
+        req["boost_term"] = [dict(bt, boost=float(rng.choice([2.0, 5.0])))]
+    if rng.random() < 0.3:
+        req["text_locality"] = True
+    if rng.random() < 0.3:
+        req["facets"] = [{"field": str(rng.choice(["tags[]", "commonness", "meanings.eng[]"]))}]
+    return req
+
+
+def test_random_requests_on_reference_corpus_match_the_oracle():
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    data, docs, info = refcases.build("test_all")
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    rng = np.random.default_rng(20241003)
+    ran = declined = 0
+    for i in range(600):
+        req = _random_request(rng, info)
+        js = json.dumps(req)
+        try:
+            want = ora.search_json(js)
+        except O.OracleError as e:
+            with pytest.raises(veloci_amd.VelociError) as g:
+                veloci_amd.search(req, idx)
+            assert str(g.value) == str(e), js
+            continue
+        try:
+            got = veloci_amd.search(req, idx)
+        except veloci_amd.VelociError as e:
+            assert e.kind == "Unsupported", (str(e), js)
+            declined += 1
+            continue
+        exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in req.get("boost", []))
+        assert_same(req, got, want, exact_scores=exact)
+        ran += 1
+    assert declined == 0 and ran >= 590, (ran, declined)

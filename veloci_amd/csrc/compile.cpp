@@ -140,6 +140,12 @@ struct NodeInfo {
     std::vector<uint32_t> cover; // lists that cover the node's result docs
     uint64_t cover_len = 0;      // shard-local entries of the cover
     bool emitted = false;        // false: node produced no op of its own (single child / passthrough)
+    uint32_t node_id = UINT32_MAX;  // preorder number inside search_req (stable between compilation passes)
+    int root_op = -1;               // index of the op whose presence is this node's result
+};
+struct CountReq {
+    uint32_t node_id;
+    int root_op;
 };
 
 struct Compiler {
@@ -152,6 +158,11 @@ struct Compiler {
 
     const FuzzyTable* fuzzy = nullptr;
     const UnionTable* unions = nullptr;
+    const QueryCounts* counts = nullptr;
+    uint32_t next_node = 0;
+    std::vector<CountReq> count_reqs;   // operands whose result sizes a count pre-pass must measure
+    std::vector<CountReq> maybe_reqs;   // ... only if some OR needs the label of a two-operand AND
+    bool label_wanted = false;
 
     Compiler(const Index& i, const Request& r, const FuzzyTable* f) : idx(i), req(r), fuzzy(f) {}
 
@@ -560,7 +571,22 @@ struct Compiler {
     }
 
     NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
+        NodeInfo info = compile_node_inner(r, is_filter, ops, sp, boost, is_filter ? UINT32_MAX : next_node++);
+        return info;
+    }
+    // result length of a node as the reference sees it: measured by the count pre-pass when it is not known statically
+    void apply_counts(NodeInfo& c) {
+        if (c.len_known || !counts) return;
+        auto it = counts->nodes.find(c.node_id);
+        if (it == counts->nodes.end()) return;
+        const bool filter_is_set = counts->has_filter && counts->filter_count <= 100000;  // FilterResult::Set: leaves drop ids outside it
+        c.glen = filter_is_set ? it->second.second : it->second.first;
+        c.len_known = true;
+    }
+    NodeInfo compile_node_inner(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost,
+                                uint32_t my_id) {
         NodeInfo info;
+        info.node_id = my_id;
         if (r.kind == SearchRequest::Search) {
             Leaf& l = field_result(r.part);
             const RequestBoostPart* boost_1n = nullptr;
@@ -579,11 +605,18 @@ struct Compiler {
             }
             if (boost_1n) {  // the leaf, then a unary op that applies the per-anchor boost values
                 NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
+                leaf_info.node_id = my_id;
+                leaf_info.root_op = int(ops.size()) - 1;
                 emit_boost_1n(r.part, l, *boost_1n, ops, sp);
                 leaf_info.emitted = true;
                 return leaf_info;
             }
-            if (!is_filter) return compile_leaf_scores(r, l, ops, sp);
+            if (!is_filter) {
+                NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
+                leaf_info.node_id = my_id;
+                leaf_info.root_op = int(ops.size()) - 1;
+                return leaf_info;
+            }
             DOp op{};
             op.kind = OP_LEAF;
             op.list_begin = uint16_t(cq.lists.size());
@@ -613,6 +646,7 @@ struct Compiler {
             info.len_known = true;
             info.label_known = false;
             info.emitted = true;
+            info.root_op = int(ops.size()) - 1;
             return info;
         }
         std::vector<NodeInfo> ch;
@@ -653,13 +687,26 @@ struct Compiler {
         if (r.kind == SearchRequest::And) {
             op.kind = OP_AND;
             bool all_known = true;
-            for (auto& c : ch) all_known = all_known && c.len_known;
+            for (auto& c : ch) {
+                apply_counts(c);
+                all_known = all_known && c.len_known;
+            }
             size_t shortest = 0;
             if (all_known) {  // get_shortest_result set_op.rs:9-17: first minimal length
                 for (size_t i = 1; i < n; ++i)
                     if (ch[i].glen < ch[shortest].glen) shortest = i;
-            } else if (n > 2 && !is_filter) {
-                unsupported("AND of 3+ operands whose result sizes are only known at run time (summation order, set_op.rs:388-416)");
+            } else {
+                // The summation order (set_op.rs:388-416) and the label of the result (:439) follow the operands' result sizes, which only
+                // exist at run time here: ask for a count pre-pass (presence only) and compile again with its numbers.
+                // (two operands: the sum of two floats does not depend on the order; only the label does, and an OR that needs it says so)
+                if (counts && n > 2) unsupported("AND whose operand sizes are still unknown after the count pre-pass (internal)");
+                if (!counts) {
+                    if (n > 2 && (idx.doc_lo != 0 || idx.doc_hi != idx.num_anchors))
+                        unsupported("AND of 3+ operands whose result sizes are only known at run time, on a sharded index (sizes are per shard)");
+                    auto& dst = n > 2 ? count_reqs : maybe_reqs;
+                    for (auto& c : ch)
+                        if (!c.len_known) dst.push_back({c.node_id, c.root_op});
+                }
             }
             // swap_remove(shortest): the last operand takes its slot; the shortest is added last (:393,:415-416)
             std::vector<uint8_t> order;
@@ -685,7 +732,10 @@ struct Compiler {
             if (!is_filter) {
                 std::vector<std::string> terms;  // set_op.rs:122-124
                 for (auto& c : ch) {
-                    if (!c.label_known) unsupported("OR over an operand whose term label is only known at run time (set_op.rs:143,439)");
+                    if (!c.label_known) {  // label of a nested AND: known once its operands' sizes are (count pre-pass)
+                        if (counts) unsupported("OR over an operand whose term label is only known at run time (set_op.rs:143,439)");
+                        label_wanted = true;
+                    }
                     terms.push_back(c.label);
                 }
                 std::sort(terms.begin(), terms.end());
@@ -703,6 +753,7 @@ struct Compiler {
         }
         push_op(ops, op, sp);
         info.emitted = true;
+        info.root_op = int(ops.size()) - 1;
         return info;
     }
 
@@ -731,9 +782,35 @@ struct Compiler {
             cq.pres_in.insert(cq.pres_in.end(), in.begin(), in.end());
             cq.pres.push_back(op);
         };
-        auto run = [&](const std::vector<DOp>& ops) -> uint16_t {
+        // count pre-pass: counter 2i = hits of node count_reqs[i], 2i+1 = hits inside the filter, last = ids of the filter
+        const bool counting = !count_reqs.empty();
+        uint16_t filter_root = 0;
+        bool have_filter_root = false;
+        auto count_slot = [&](uint16_t slot, size_t req_index) {
+            emit(PRES_COUNT, {slot}, uint16_t(2 * req_index));
+            if (have_filter_root) {
+                uint16_t t = alloc_temp();
+                emit(PRES_AND, {slot, filter_root}, t);
+                emit(PRES_COUNT, {t}, uint16_t(2 * req_index + 1));
+                release(t);
+            }
+        };
+        auto run = [&](const std::vector<DOp>& ops, bool count_here) -> uint16_t {
             std::vector<uint16_t> st;
-            for (const DOp& op : ops) {
+            for (size_t o = 0; o < ops.size(); ++o) {
+                const DOp& op = ops[o];
+                struct AfterOp {  // count the node results this op produces (its slot is on top of the stack)
+                    const std::vector<CountReq>& reqs;
+                    bool on;
+                    size_t o;
+                    std::vector<uint16_t>& st;
+                    decltype(count_slot)& count;
+                    ~AfterOp() {
+                        if (!on || st.empty()) return;
+                        for (size_t i = 0; i < reqs.size(); ++i)
+                            if (reqs[i].root_op == int(o)) count(st.back(), i);
+                    }
+                } after{count_reqs, count_here && counting, o, st, count_slot};
                 if (op.kind == OP_BOOST1N) continue;  // changes scores only
                 if (op.kind == OP_LEAF) {
                     if (op.list_count == 1) {
@@ -758,10 +835,19 @@ struct Compiler {
         };
         std::vector<uint16_t> roots;
         bool any = !cq.ops.empty();
-        if (any) roots.push_back(run(cq.ops));
-        if (!cq.fops.empty()) roots.push_back(run(cq.fops));
+        if (!cq.fops.empty()) {  // the filter first: the counts of the score tree's nodes look at its root
+            filter_root = run(cq.fops, false);
+            have_filter_root = true;
+            roots.push_back(filter_root);
+            if (counting) emit(PRES_COUNT, {filter_root}, uint16_t(2 * count_reqs.size()));
+        }
+        if (any) roots.push_back(run(cq.ops, true));
         if (!any) emit(PRES_ZERO, {}, kSlotRoot);
         else emit(PRES_AND, roots, kSlotRoot);
+        if (counting) {
+            for (auto& r : count_reqs) cq.count_nodes.push_back(r.node_id);
+            cq.n_counts = uint32_t(2 * count_reqs.size() + 1);
+        }
         cq.n_temps = next_temp;
         if (next_temp > 32) unsupported("presence program needs more than 32 temporary bitmaps");
     }
@@ -1011,7 +1097,8 @@ struct Compiler {
                 f.values = kv.csr_values.as<uint32_t>();
                 f.key_base = kv.csr_key_base;
                 f.num_keys = kv.csr_num_keys;
-                f.num_values = uint32_t(dit->second.terms.size());
+                // value ids beyond the dictionary (texts longer than do_not_store_text_longer_than) are counted too and render as ""
+                f.num_values = std::max<uint32_t>(uint32_t(dit->second.terms.size()), kv.csr_num_keys ? kv.csr_max_value + 1 : 0);
                 f.top = uint32_t(*fr.top);
                 cq.facets.push_back(f);
                 FacetOut fo;
@@ -1024,7 +1111,16 @@ struct Compiler {
             }
         cq.algorithmic_bytes += 8ull * cq.top_k;
 
+        if (label_wanted) {  // some OR needs the label of a nested AND: that takes the sizes of the two-operand ANDs as well
+            if (maybe_reqs.empty() && count_reqs.empty()) unsupported("OR over an operand whose term label is only known at run time (set_op.rs:143,439)");
+            if (idx.doc_lo != 0 || idx.doc_hi != idx.num_anchors)
+                unsupported("OR over an AND whose label follows run-time result sizes, on a sharded index (sizes are per shard)");
+            count_reqs.insert(count_reqs.end(), maybe_reqs.begin(), maybe_reqs.end());
+        }
+        if (2 * count_reqs.size() + 1 > 256) unsupported("more than 127 AND operands whose sizes must be measured first");
         build_presence_program();
+        if (!count_reqs.empty())  // count pre-pass: every tile that holds a doc of any list is visited
+            for (auto& l : cq.lists) l.flags |= LIST_COVER;
         {  // shape that the kernel scores without the interpreter: <= 4 single-list posting leaves under one AND/OR
             const size_t n = cq.ops.size();
             auto is_leaf1 = [&](const DOp& o) {
@@ -1052,7 +1148,7 @@ struct Compiler {
 
         {  // pure simple queries run on k_scan_simple (fixed 8192-doc tiles)
             static const bool force_generic = std::getenv("VQ_FORCE_GENERIC") != nullptr;
-            const bool pure = cq.simple_n && cq.fops.empty() && cq.groups.empty() && cq.tboosts.empty() && cq.cols.empty() && cq.locf.empty() &&
+            const bool pure = cq.simple_n && count_reqs.empty() && cq.fops.empty() && cq.groups.empty() && cq.tboosts.empty() && cq.cols.empty() && cq.locf.empty() &&
                               cq.facets.empty() && uint64_t(idx.doc_hi) - idx.doc_lo >= 65536;
             if (pure && !force_generic) {
                 uint32_t f = 1u << 17;
@@ -1199,14 +1295,18 @@ void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& tabl
         for (auto& p : *req.boost_term) probe_part(idx, p, table);
 }
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions) {
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts) {
     Compiler c(idx, req, fuzzy);
     c.unions = unions;
+    c.counts = counts;
     try {
         c.run();
         if (!c.cq.union_requests.empty()) {
             c.cq.status = kStatusNeedsUnion;
             c.cq.error = "internal: union jobs pending";
+        } else if (c.cq.n_counts) {
+            c.cq.status = kStatusNeedsCounts;
+            c.cq.error = "internal: count pre-pass pending";
         }
     } catch (const VelociError& e) {
         c.cq.status = e.code;

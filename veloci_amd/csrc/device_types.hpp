@@ -59,7 +59,7 @@ struct DOp {  // 24 B
 
 // Presence program: the AND/OR/filter trees as three-address code over tile bitmaps (k_tile_scan P3).
 // A slot reference is a list index, or (bit 15 set) a temporary bitmap; 0xFFFF = the root words.
-enum PresKind : uint8_t { PRES_AND = 0, PRES_OR = 1, PRES_ZERO = 2 };
+enum PresKind : uint8_t { PRES_AND = 0, PRES_OR = 1, PRES_ZERO = 2, PRES_COUNT = 3 };  // PRES_COUNT: add popcount(in[0]) to counter `out` (count pre-pass)
 constexpr uint16_t kSlotTemp = 0x8000;
 constexpr uint16_t kSlotRoot = 0xFFFF;
 struct DPresOp {  // 8 B
@@ -128,7 +128,8 @@ struct QHeader {
     uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
     uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
-    uint32_t pad0;
+    uint32_t n_counts;       // != 0: count pre-pass — only the presence program runs, PRES_COUNT counters are added to
+                             // counts[part_keys_off + c] (the buffer passed as `num_hits`); nothing is scored
     uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are

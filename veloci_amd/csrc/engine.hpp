@@ -154,6 +154,15 @@ struct UnionJob {
 };
 using UnionTable = std::map<std::string, UnionJob>;
 constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union jobs have run
+constexpr int kStatusNeedsCounts = -2; // internal: the compiled query IS a count pre-pass; compile again with its results
+
+// Result sizes of the operands of AND nodes, measured by a count pre-pass (the reference orders the score sum of an AND by
+// its operands' result lengths and labels an AND result by them, set_op.rs:388-393,439).
+struct QueryCounts {
+    bool has_filter = false;
+    uint64_t filter_count = 0;                                       // ids in the filter result (Set below 100 001 ids, filter_result.rs:5-22)
+    std::map<uint32_t, std::pair<uint64_t, uint64_t>> nodes;        // node id (preorder) -> (hits, hits inside the filter)
+};
 
 struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segmented arrays in HBM
     uint32_t num_tokens = 0;
@@ -185,6 +194,7 @@ struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device ima
     // facet use: keys are anchors -> CSR restricted to the shard's anchors
     bool facet_csr = false;
     uint32_t csr_key_base = 0, csr_num_keys = 0;
+    uint32_t csr_max_value = 0;  // largest value id of the CSR (text ids of texts too long for the dictionary lie beyond it)
     DevBuf csr_off;     // u64 [csr_num_keys + 1]
     DevBuf csr_values;  // u32
 
@@ -311,6 +321,8 @@ struct CompiledQuery {
     int status = 0;
     std::string error;
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
+    std::vector<uint32_t> count_nodes;     // status == kStatusNeedsCounts: node ids; counters 2i / 2i+1 = hits / hits inside the filter, then the filter
+    uint32_t n_counts = 0;
     std::vector<HList> lists;
     std::vector<std::vector<uint32_t>> inline_lists;
     std::vector<std::vector<float>> inline_vals;
@@ -335,7 +347,8 @@ struct CompiledQuery {
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
 };
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr);
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr,
+                            const QueryCounts* counts = nullptr);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 
 // ------------------------------------------------------------------ results

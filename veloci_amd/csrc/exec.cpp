@@ -62,6 +62,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
     h.n_temps = cq.n_temps;
+    h.n_counts = cq.n_counts;
     h.simple_n = cq.simple_n;
     h.bitmap_base = idx.bitmap_base;
     h.simple_flags = cq.simple_flags;
@@ -108,8 +109,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);
     for (size_t i = 0; i < cq.facets.size(); ++i) {
         DFacet f = cq.facets[i];
-        f.hist_off = hist_off[i];
-        f.out_off = fac_out_off[i];
+        f.hist_off = i < hist_off.size() ? hist_off[i] : 0u;  // (the count pre-pass packs queries without facet outputs)
+        f.out_off = i < fac_out_off.size() ? fac_out_off[i] : 0u;
         df[i] = f;
     }
     for (size_t i = 0; i < cq.inline_vals.size(); ++i)
@@ -336,6 +337,58 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
     }
 }
 
+// Count pre-pass: launches k_tile_scan in count mode for queries whose AND operands' result sizes the compiler needs
+// (set_op.rs:388-393,439) and returns them per query.  Presence only: no scores are read.
+static void run_count_queries(const Index& idx, Workspace& ws, const std::vector<CompiledQuery*>& cqs, std::vector<QueryCounts>& out, hipStream_t st) {
+    const size_t n = cqs.size();
+    out.assign(n, QueryCounts{});
+    if (!n) return;
+    std::vector<uint32_t> blob_off(n + 1, 0), span_base(n + 1, 0), qmap(n), counts_off(n + 1, 0);
+    size_t lds_bytes = 0, desc_cap = 0;
+    uint32_t stack_depth = 1;
+    for (size_t i = 0; i < n; ++i) {
+        const CompiledQuery& cq = *cqs[i];
+        size_t desc = 0;
+        const size_t bytes = pack_blob(cq, idx, nullptr, nullptr, 0, 0, {}, {}, &desc);
+        blob_off[i + 1] = uint32_t(blob_off[i] + align_up(bytes, 16));
+        span_base[i + 1] = span_base[i] + cq.n_spans;
+        counts_off[i + 1] = counts_off[i] + cq.n_counts;
+        qmap[i] = uint32_t(i);
+        desc_cap = std::max(desc_cap, desc);
+        stack_depth = std::max(stack_depth, cq.stack_depth);
+    }
+    desc_cap = align_up(desc_cap, 16);
+    const uint32_t cand_cap = 256;  // the candidate area doubles as the counter array (<= 256 counters)
+    for (size_t i = 0; i < n; ++i)
+        lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(cqs[i]->lists.size()) + cqs[i]->n_temps, uint32_t(cqs[i]->lists.size()), cqs[i]->tile_words,
+                                                            stack_depth, cand_cap, uint32_t(desc_cap)));
+    if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
+    const size_t o_off = align_up(blob_off[n], 256), o_span = o_off + align_up((n + 1) * 4, 256), o_qmap = o_span + align_up((n + 1) * 4, 256),
+                 o_cnt = o_qmap + align_up(n * 4, 256), total = o_cnt + align_up(size_t(counts_off[n]) * 8, 256);
+    std::vector<uint8_t> host(total, 0);
+    ws.d_union_meta.ensure(total);
+    uint8_t* dev = ws.d_union_meta.as<uint8_t>();
+    for (size_t i = 0; i < n; ++i) pack_blob(*cqs[i], idx, host.data() + blob_off[i], dev + blob_off[i], 0, counts_off[i], {}, {});
+    std::memcpy(host.data() + o_off, blob_off.data(), (n + 1) * 4);
+    std::memcpy(host.data() + o_span, span_base.data(), (n + 1) * 4);
+    std::memcpy(host.data() + o_qmap, qmap.data(), n * 4);
+    VQ_HIP(hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, st));
+    launch_tile_scan(st, span_base[n], lds_bytes, dev, reinterpret_cast<const uint32_t*>(dev + o_off), reinterpret_cast<const uint32_t*>(dev + o_span),
+                     reinterpret_cast<const uint32_t*>(dev + o_qmap), uint32_t(n), stack_depth, cand_cap, uint32_t(desc_cap), nullptr,
+                     reinterpret_cast<unsigned long long*>(dev + o_cnt), nullptr);
+    VQ_HIP(hipGetLastError());
+    std::vector<uint64_t> cnt(counts_off[n]);
+    VQ_HIP(hipMemcpyAsync(cnt.data(), dev + o_cnt, cnt.size() * 8, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) {
+        const CompiledQuery& cq = *cqs[i];
+        const uint64_t* c = cnt.data() + counts_off[i];
+        out[i].has_filter = !cq.fops.empty();
+        out[i].filter_count = c[cq.n_counts - 1];
+        for (size_t k = 0; k < cq.count_nodes.size(); ++k) out[i].nodes[cq.count_nodes[k]] = {c[2 * k], c[2 * k + 1]};
+    }
+}
+
 static bool timing_enabled() {
     static const bool on = std::getenv("VQ_TIMING") != nullptr;
     return on;
@@ -408,6 +461,28 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             recompile(0, again.size() / nt);
             for (auto& t : th) t.join();
         } else recompile(0, again.size());
+    }
+    // ---- ANDs whose summation order / label follow run-time operand sizes: count pre-pass, then the final compilation
+    {
+        std::vector<size_t> need;
+        std::vector<CompiledQuery*> cqs;
+        for (size_t i = 0; i < n; ++i)
+            if (pb->queries[i].status == kStatusNeedsCounts) {
+                need.push_back(i);
+                cqs.push_back(&pb->queries[i]);
+            }
+        if (!need.empty()) {
+            std::vector<QueryCounts> counts;
+            run_count_queries(idx, ws, cqs, counts, st);
+            for (size_t k = 0; k < need.size(); ++k) {
+                CompiledQuery& q = pb->queries[need[k]];
+                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k]);
+                if (q.status < 0) {
+                    q.status = ERR_UNSUPPORTED;
+                    q.error = "unsupported on the MI355X query path: query still needs a pre-pass after the count pre-pass (internal)";
+                }
+            }
+        }
     }
     const double t_compiled = now_ms();
     // ---- layout

@@ -292,6 +292,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             idx->device_bytes += s.csr_off.bytes + s.csr_values.bytes;
             s.csr_key_base = uint32_t(nb);
             s.csr_num_keys = uint32_t(ne - nb);
+            for (uint64_t e = first; e < first + nvals; ++e) s.csr_max_value = std::max(s.csr_max_value, k.values[e]);
         }
         idx->kv.emplace(path, std::move(s));
     }
@@ -379,6 +380,7 @@ const KVStore& Index::composed_facet(const std::vector<std::string>& steps) cons
     out->facet_csr = true;
     out->csr_key_base = doc_lo;
     out->csr_num_keys = doc_hi - doc_lo;
+    for (uint32_t v : vals) out->csr_max_value = std::max(out->csr_max_value, v);
     out->csr_off.alloc(off.size() * 8);
     out->csr_off.upload(off.data(), off.size() * 8);
     out->csr_values.alloc(vals.size() * 4 + 16);

@@ -566,6 +566,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         *cand_n = 0;
         *hits_acc = 0;
     }
+    const uint32_t n_counts = H->n_counts;
+    for (uint32_t c = tid; c < n_counts; c += kBlock) reinterpret_cast<uint32_t*>(cand)[c] = 0u;  // the candidate area holds the counters
     uint32_t my_hits = 0;
     uint32_t par = 0;  // parity of the cursor buffers
     __syncthreads();
@@ -741,6 +743,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             const uint32_t n_in = pres[o].n_in;
             const uint16_t* in = pres_in + pres[o].in_begin;
             const uint32_t out = pres[o].out;
+            if (kind == PRES_COUNT) {  // count pre-pass: hits of one node of the tree inside this tile
+                const uint32_t ref = in[0];
+                const uint32_t* src = bm + ((ref & kSlotTemp) ? L + (ref & 0x7FFFu) : ref) * WW + w0;
+                uint32_t pc = 0;
+                for (uint32_t k = 0; k < WPL; ++k) pc += (uint32_t)__popc(src[k]);
+                uint32_t tot;
+                (void)wave_excl_scan_u32(pc, &tot);
+                if (lane == 0) reinterpret_cast<uint32_t*>(cand)[out] += tot;
+                continue;
+            }
             uint32_t* dst = (out == kSlotRoot ? rootw : bm + (L + (out & 0x7FFFu)) * WW) + w0;
             if ((WPL & 3u) == 0) {
                 for (uint32_t k = 0; k < WPL; k += 4) {
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         const uint32_t my_excl = wave_excl_scan_u32(surv, &S);
         VQ_STAMP_AT(3)
 
-        if (S) {  // uniform
+        if (S && !n_counts) {  // uniform
             // ---- P4: rank support for the score gathers: exclusive prefix popcount per posting list
             for (uint32_t i = 0; i < L; ++i) {
                 if (lists[i].flags & LIST_HAS_SCORES) {
@@ -865,6 +877,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         par ^= 1u;
     }
 
+    if (n_counts) {  // count pre-pass: publish this span's counters, nothing else
+        __syncthreads();
+        for (uint32_t c = tid; c < n_counts; c += kBlock) {
+            const uint32_t v = reinterpret_cast<uint32_t*>(cand)[c];
+            if (v) atomicAdd(&num_hits[H->part_keys_off + c], (unsigned long long)v);
+        }
+        return;
+    }
     // ---- span done: publish the local top-k (as a set) and the hit count
     cand_prune(cs, top_k);
     {
