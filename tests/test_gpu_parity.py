@@ -423,6 +423,8 @@ def _random_request(rng, info, depth=0):
             part["ignore_case"] = bool(rng.integers(0, 2))
         if rng.random() < 0.2:
             part["boost"] = float(rng.choice([0.5, 2.0, 3.5]))
+        if rng.random() < 0.1:
+            part["top"] = int(rng.integers(1, 4))
         return {"search": part}
 
     def tree(d):
@@ -438,6 +440,12 @@ def _random_request(rng, info, depth=0):
         req["filter"] = tree(1)
     if rng.random() < 0.3:
         req["boost"] = [{"path": "commonness", "boost_fun": str(rng.choice(["Multiply", "Add", "Replace", "Log10", "Log2"])), "param": float(rng.choice([0.0, 1.0, 2.0]))}]
+        if rng.random() < 0.3:
+            req["boost"].append({"path": str(rng.choice(["kanji[].commonness", "field1[].rank", "kana[].commonness"])), "boost_fun": "Multiply", "param": 1.0})
+        if rng.random() < 0.2:
+            req["boost"][0]["skip_when_score"] = [0.0, 10.0]
+        if rng.random() < 0.2:
+            req["boost"][0]["expression"] = str(rng.choice(["$SCORE * 2", "10 / $SCORE", "$SCORE + 1.5", "3 - $SCORE"]))
     if rng.random() < 0.25:
         a, b = leaf()["search"], leaf()["search"]
         b["path"] = a["path"]
@@ -480,10 +488,38 @@ def test_random_requests_on_reference_corpus_match_the_oracle():
         try:
             got = veloci_amd.search(req, idx)
         except veloci_amd.VelociError as e:
-            assert e.kind == "Unsupported", (str(e), js)
+            # the one documented decline the generator can reach: the reference applies a hit-order-dependent subset then
+            assert e.kind == "Unsupported" and "several boosted values on one anchor" in str(e), (str(e), js)
             declined += 1
             continue
         exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in req.get("boost", []))
         assert_same(req, got, want, exact_scores=exact)
         ran += 1
-    assert declined == 0 and ran >= 590, (ran, declined)
+    assert declined <= 6 and ran >= 590, (ran, declined)
+
+
+def test_random_requests_in_batches_match_the_oracle():
+    """The same generator through vq_search_batch: dictionary scans, union jobs and count pre-passes of many requests share one batch."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    data, docs, info = refcases.build("test_all")
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    rng = np.random.default_rng(77)
+    for _ in range(4):
+        reqs = [_random_request(rng, info) for _ in range(300)]
+        got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
+        for req, g in zip(reqs, got):
+            js = json.dumps(req)
+            try:
+                want = ora.search_json(js)
+            except O.OracleError as e:
+                assert isinstance(g, veloci_amd.VelociError) and g.code == e.code, js  # (the batch entry point reports codes, not texts)
+                continue
+            if isinstance(g, veloci_amd.VelociError) and g.kind == "Unsupported" and any("[]" in b["path"] for b in req.get("boost", [])):
+                continue  # 1:n boost with several boosted values on one anchor (see the single-request test)
+            assert not isinstance(g, Exception), (str(g), js)
+            exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in req.get("boost", []))
+            assert_same(req, g, want, exact_scores=exact)
