@@ -523,3 +523,51 @@ def test_random_requests_in_batches_match_the_oracle():
             assert not isinstance(g, Exception), (str(g), js)
             exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in req.get("boost", []))
             assert_same(req, g, want, exact_scores=exact)
+
+
+def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
+    """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
+    import veloci_amd
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    rng = np.random.default_rng(991)
+    pool = [t for tri in meta.triples for t in tri] + list(meta.extra_probes) + list(meta.background[:25])
+
+    def leaf():
+        part = {"path": "body", "terms": [pool[int(rng.integers(0, len(pool)))]]}
+        r = rng.random()
+        if r < 0.08:
+            part["terms"] = [part["terms"][0][:3]]
+            part["starts_with"] = True
+        elif r < 0.16:
+            part["levenshtein_distance"] = 1
+        if rng.random() < 0.15:
+            part["boost"] = float(rng.choice([0.5, 2.0]))
+        return {"search": part}
+
+    def tree(d):
+        if d >= 2 or rng.random() < 0.35:
+            return leaf()
+        return {("and" if rng.random() < 0.5 else "or"): {"queries": [tree(d + 1) for _ in range(int(rng.integers(2, 5)))]}}
+
+    reqs = []
+    for _ in range(240):
+        req = {"search_req": tree(0), "top": int(rng.choice([1, 10, 40]))}
+        if rng.random() < 0.25:
+            req["filter"] = tree(1)
+        if rng.random() < 0.3:
+            req["boost"] = [{"path": "pop", "boost_fun": str(rng.choice(["Multiply", "Add", "Replace"])), "param": 1.0}]
+        if rng.random() < 0.3:
+            a, b = (meta.triples[int(rng.integers(0, len(meta.triples)))][i] for i in (0, 1))
+            req["phrase_boosts"] = [{"search1": {"path": "body", "terms": [a]}, "search2": {"path": "body", "terms": [b]}}]
+        if rng.random() < 0.3:
+            req["text_locality"] = True
+        if rng.random() < 0.25:
+            req["facets"] = [{"field": str(rng.choice(["cat", "tags[]"])), "top": int(rng.choice([3, 10]))}]
+        if rng.random() < 0.2:
+            req["boost_term"] = [{"path": "body", "terms": [meta.background[int(rng.integers(0, 30))]], "boost": 3.0}]
+        reqs.append(req)
+    got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
+    for req, g in zip(reqs, got):
+        assert not isinstance(g, Exception), (str(g), json.dumps(req))
+        assert_same(req, g, ora.search_json(json.dumps(req)))
