@@ -548,16 +548,18 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_g = up_span_base + tbl;
     const size_t up_span_s = up_qmap_g + tbl;
     const size_t up_qmap_s = up_span_s + tbl;
-    const size_t up_span_d = up_qmap_s + tbl;   // simple + dense survivors (OR / single-term): k_scan_simple<true>
+    const size_t up_span_d = up_qmap_s + tbl;   // every posting is a hit (single leaves): k_scan_union
     const size_t up_qmap_d = up_span_d + tbl;
-    const size_t up_jobs = up_qmap_d + tbl;
+    const size_t up_span_w = up_qmap_d + tbl;   // simple ANDs: k_scan_simple with 16384-doc tiles
+    const size_t up_qmap_w = up_span_w + tbl;
+    const size_t up_jobs = up_qmap_w + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
     uint8_t* hup = ws.h_up.as<uint8_t>();
     uint8_t* dup = ws.d_up.as<uint8_t>();
     bool union_has_or = false;
-    uint32_t n_simple = 0, n_generic = 0, n_dense = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0;
+    uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0;
     {
         size_t off = 0;
         uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
@@ -576,7 +578,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t* ms = reinterpret_cast<uint32_t*>(hup + up_qmap_s);
         uint32_t* sd = reinterpret_cast<uint32_t*>(hup + up_span_d);
         uint32_t* md = reinterpret_cast<uint32_t*>(hup + up_qmap_d);
-        uint32_t accg = 0, accs = 0, accd = 0;
+        uint32_t* sw = reinterpret_cast<uint32_t*>(hup + up_span_w);
+        uint32_t* mw = reinterpret_cast<uint32_t*>(hup + up_qmap_w);
+        uint32_t accg = 0, accs = 0, accd = 0, accw = 0;
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
             const CompiledQuery& cq = pb->queries[i];
@@ -592,6 +596,10 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
+            } else if (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND) {
+                sw[n_wide] = accw;
+                mw[n_wide++] = qi;
+                accw += cq.n_spans;
             } else if (cq.simple_flags) {
                 ss[n_simple] = accs;
                 ms[n_simple++] = qi;
@@ -605,6 +613,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
         sg[n_generic] = accg;
         ss[n_simple] = accs;
+        sw[n_wide] = accw;
+        spans_wide = accw;
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -643,7 +653,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
-    launch_scan_simple(st, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+    launch_scan_simple(st, true, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
+                       reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+    VQ_HIP(hipGetLastError());
+    launch_scan_simple(st, false, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());

@@ -1086,7 +1086,7 @@ constexpr uint32_t kSLdsQDoc = 8;
 constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
 constexpr uint32_t kSLdsCand = kSLdsQIdx + 4 * kQCap;
 
-size_t scan_simple_lds_bytes(uint32_t cand_cap) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW) * 4 + 16; }
+size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW * nv) * 4 + 16; }
 
 struct SimpleLeaf {
     const uint32_t* docs;
@@ -1158,11 +1158,12 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
     }
 }
 
-__global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                    const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
-                                                    uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
-                                                    unsigned long long* __restrict__ num_hits) {
+template <uint32_t NV>  // u32x4 bitmap vectors per lane: the tile is NV * 8192 docs
+__device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                 const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
+                                                 unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t SW = kSW * NV, SWW = kSWW * NV, NW = 4u * NV;  // docs / words per tile, words per lane
     const uint32_t lane = threadIdx.x;
     uint32_t ql;
     {
@@ -1212,13 +1213,13 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
     uint32_t* qdoc = lds + kSLdsQDoc;
     uint32_t* qidx = lds + kSLdsQIdx;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kSLdsCand);
-    uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [4][kSWW]
+    uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [4][SWW]
     CandState cs{cand, cand_n, thr, cand_cap};
 
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
-    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(kSW - 1u));
-    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(kSW - 1u));
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(SW - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(SW - 1u));
     const uint32_t bitmap_base = H->bitmap_base;
     const uint32_t keys_base = H->keys_base;
 
@@ -1261,28 +1262,32 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
                 if (k < n && ((sflags >> (8 + k)) & 1u)) head = nxt[k] < head ? nxt[k] : head;
         }
         if (head >= span_hi) break;
-        const uint32_t tile_lo = head & ~(kSW - 1u);
-        const uint32_t tile_end = tile_lo + kSW;
+        const uint32_t tile_lo = head & ~(SW - 1u);
+        const uint32_t tile_end = tile_lo + SW;
         const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
         const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
         pos = tile_end > tile_lo ? tile_end : 0xFFFFFFFFu;
 
         // issue every first load of the tile: bitmap words (+ rank directory entry) or the first id vector
-        u32x4 wk[4];
+        u32x4 wk[4][NV];  // lane owns the NW consecutive words [lane * NW, lane * NW + NW) of every list's tile bitmap
         uint32_t base_idx[4] = {0, 0, 0, 0};
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            wk[k] = kZero;
+#pragma unroll
+            for (uint32_t h = 0; h < NV; ++h) wk[k][h] = kZero;
             if (k < n) {
                 if ((sflags >> k) & 1u) {
-                    wk[k] = as_global(reinterpret_cast<const u32x4*>(lf[k].bitmap + ((tile_lo - bitmap_base) >> 5)))[lane];
+                    const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(lf[k].bitmap + ((tile_lo - bitmap_base) >> 5)));
+#pragma unroll
+                    for (uint32_t h = 0; h < NV; ++h) wk[k][h] = gb[lane * NV + h];
                     base_idx[k] = as_global(lf[k].rank_dir)[(tile_lo - bitmap_base) >> 11];
                 } else {
                     // a list outside the cover that fell more than a tile behind skips ahead first
-                    if (nxt[k] < tile_lo && tile_lo - nxt[k] >= kSW) cur[k] += wave_lower_bound(lf[k].docs + cur[k], lf[k].len - cur[k], tile_lo);
+                    if (nxt[k] < tile_lo && tile_lo - nxt[k] >= SW) cur[k] += wave_lower_bound(lf[k].docs + cur[k], lf[k].len - cur[k], tile_lo);
                     const uint32_t v = (cur[k] >> 2) + lane;
-                    wk[k] = v < ((lf[k].len + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(lf[k].docs))[v] : kSent;
-                    reinterpret_cast<u32x4*>(bml + k * kSWW)[lane] = kZero;
+                    wk[k][0] = v < ((lf[k].len + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(lf[k].docs))[v] : kSent;
+#pragma unroll
+                    for (uint32_t h = 0; h < NV; ++h) reinterpret_cast<u32x4*>(bml + k * SWW)[lane * NV + h] = kZero;
                 }
             }
         }
@@ -1293,9 +1298,9 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
                 const uint32_t c0v = cur[k] & ~3u;
                 const uint32_t nvec = (lf[k].len + 3u) >> 2;
                 const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lf[k].docs));
-                uint32_t* bmi = bml + k * kSWW;
+                uint32_t* bmi = bml + k * SWW;
                 uint32_t v = (c0v >> 2) + lane;
-                u32x4 d4 = wk[k];
+                u32x4 d4 = wk[k][0];
                 uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
                 while (true) {
                     const uint32_t vn = v + 64u;
@@ -1339,21 +1344,30 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
         __syncthreads();  // one wave: LDS atomics above are ordered before the reads below
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
-            if (k < n && !((sflags >> k) & 1u)) wk[k] = reinterpret_cast<const u32x4*>(bml + k * kSWW)[lane];
+            if (k < n && !((sflags >> k) & 1u)) {
+#pragma unroll
+                for (uint32_t h = 0; h < NV; ++h) wk[k][h] = reinterpret_cast<const u32x4*>(bml + k * SWW)[lane * NV + h];
+            }
 
         // presence of the root
-        u32x4 r = wk[0];
-        if (kind == OP_AND) {
+        u32x4 r[NV];
+        uint32_t rpop = 0;
 #pragma unroll
-            for (uint32_t k = 1; k < 4; ++k)
-                if (k < n) r &= wk[k];
-        } else if (kind == OP_OR) {
+        for (uint32_t h = 0; h < NV; ++h) {
+            r[h] = wk[0][h];
+            if (kind == OP_AND) {
 #pragma unroll
-            for (uint32_t k = 1; k < 4; ++k)
-                if (k < n) r |= wk[k];
+                for (uint32_t k = 1; k < 4; ++k)
+                    if (k < n) r[h] &= wk[k][h];
+            } else if (kind == OP_OR) {
+#pragma unroll
+                for (uint32_t k = 1; k < 4; ++k)
+                    if (k < n) r[h] |= wk[k][h];
+            }
+            rpop += popc4(r[h]);
         }
         uint32_t S;
-        (void)wave_excl_scan_u32(popc4(r), &S);
+        (void)wave_excl_scan_u32(rpop, &S);
         if (S) {  // uniform
             hits += S;
             if (kind == OP_OR) {
@@ -1388,58 +1402,85 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
                     }
                 }
                 if (or_live != 0xFFFFu) {
-                    u32x4 ev = kZero;
+                    u32x4 ev[NV];
+#pragma unroll
+                    for (uint32_t h = 0; h < NV; ++h) ev[h] = kZero;
                     for (uint32_t m = 1; m < (1u << n); ++m) {
                         if ((or_live >> m) & 1u) {  // uniform
-                            u32x4 t = ~kZero;
 #pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k)
-                                if (k < n) t &= ((m >> k) & 1u) ? wk[k] : ~wk[k];
-                            ev |= t;
+                            for (uint32_t h = 0; h < NV; ++h) {
+                                u32x4 t = ~kZero;
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k)
+                                    if (k < n) t &= ((m >> k) & 1u) ? wk[k][h] : ~wk[k][h];
+                                ev[h] |= t;
+                            }
                         }
                     }
-                    r = ev;
+                    uint32_t epop = 0;
+#pragma unroll
+                    for (uint32_t h = 0; h < NV; ++h) {
+                        r[h] = ev[h];
+                        epop += popc4(ev[h]);
+                    }
                     uint32_t S2;
-                    (void)wave_excl_scan_u32(popc4(r), &S2);
+                    (void)wave_excl_scan_u32(epop, &S2);
                     if (!S2) continue;  // uniform: nothing in this tile can enter the top-k
                 }
             }
-            // rank of each list at this lane's first word, and the popcounts of the lane's words before word j
+            // rank of each list at this lane's first word (one DPP scan per list), and — packed one byte per word — the popcounts
+            // of the lane's words before word j: bytes of (pk * 0x0101..01) << 8 are the exclusive prefix sums of the bytes of pk
             uint32_t run[4] = {0, 0, 0, 0};
-            uint32_t c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, c3[4] = {0, 0, 0, 0}, tot_k[4] = {0, 0, 0, 0};
+            unsigned long long excl[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 if (k < n) {
-                    c1[k] = (uint32_t)__popc(wk[k].x);
-                    c2[k] = c1[k] + (uint32_t)__popc(wk[k].y);
-                    c3[k] = c2[k] + (uint32_t)__popc(wk[k].z);
-                    run[k] = base_idx[k] + wave_excl_scan_u32(c3[k] + (uint32_t)__popc(wk[k].w), &tot_k[k]);
+                    unsigned long long pk = 0ull;
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < NW; ++t) {
+                        const uint32_t pc = (uint32_t)__popc(comp4(wk[k][t >> 2], t & 3u));
+                        pk |= (unsigned long long)pc << (8u * t);
+                        tot += pc;
+                    }
+                    excl[k] = (pk * 0x0101010101010101ull) << 8;
+                    uint32_t dummy;
+                    run[k] = base_idx[k] + wave_excl_scan_u32(tot, &dummy);
                 }
             }
             // every round each lane emits its next surviving doc (lowest word, lowest bit first): the number of
             // rounds is the largest survivor count of a lane (1-2 for an AND tile, up to 128 for a dense OR tile)
-            u32x4 rr = r;
+            uint32_t rr[NW];
+#pragma unroll
+            for (uint32_t t = 0; t < NW; ++t) rr[t] = comp4(r[t >> 2], t & 3u);
             while (true) {  // uniform
-                const uint32_t j = rr.x ? 0u : rr.y ? 1u : rr.z ? 2u : 3u;
-                const uint32_t rw = comp4(rr, j);
+                uint32_t j = 0u, rw = 0u;  // this lane's first word that still has a surviving doc
+#pragma unroll
+                for (uint32_t t = NW; t-- > 0u;)
+                    if (rr[t]) {
+                        j = t;
+                        rw = rr[t];
+                    }
                 const bool has = rw != 0u;
                 const unsigned long long mask = __ballot(has);
                 if (!mask) break;
                 if (has) {
                     const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
                     const uint32_t cleared = rw & (rw - 1u);
-                    if (j == 0) rr.x = cleared;
-                    else if (j == 1) rr.y = cleared;
-                    else if (j == 2) rr.z = cleared;
-                    else rr.w = cleared;
+#pragma unroll
+                    for (uint32_t t = 0; t < NW; ++t)
+                        if (t == j) rr[t] = cleared;
                     const uint32_t below = (1u << b) - 1u;
                     const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    qdoc[p] = tile_lo + (((lane << 2) + j) << 5) + b;
+                    qdoc[p] = tile_lo + ((lane * NW + j) << 5) + b;
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
                         if (k < n) {
-                            const uint32_t word = comp4(wk[k], j);
-                            const uint32_t before = j == 0 ? 0u : j == 1 ? c1[k] : j == 2 ? c2[k] : c3[k];
+                            uint32_t word = 0u;
+#pragma unroll
+                            for (uint32_t t = 0; t < NW; ++t)
+                                if (t == j) word = comp4(wk[k][t >> 2], t & 3u);
+                            const uint32_t before = (uint32_t)(excl[k] >> (8u * j)) & 0xFFu;
                             qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + before + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
                         }
                     }
@@ -1481,10 +1522,27 @@ __global__ __launch_bounds__(64) void k_scan_simple(const uint8_t* __restrict__ 
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
 }
 
-void launch_scan_simple(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+// AND (few survivors): 16384-doc tiles halve the per-tile instruction overhead — the kernel is VALU-issue bound, not bandwidth bound
+// (rocprofv3 SQ_INSTS_VALU: 60 % of the issue slots at 8192 docs per tile).  OR: 8192-doc tiles (more survivors per lane make the
+// longer tiles slower there).  VQ_SIMPLE_NV=1 / 2 forces one width.
+template <uint32_t NV>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                    const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                    uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
+                                                    unsigned long long* __restrict__ num_hits) {
+    scan_simple_body<NV>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+}
+
+void launch_scan_simple(hipStream_t st, bool wide, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_scan_simple, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+    static const uint32_t force_nv = std::getenv("VQ_SIMPLE_NV") ? uint32_t(std::atoi(std::getenv("VQ_SIMPLE_NV"))) : 0u;
+    if (force_nv ? force_nv == 2u : wide)
+        hipLaunchKernelGGL(k_scan_simple<2>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
+                           span_keys, num_hits);
+    else
+        hipLaunchKernelGGL(k_scan_simple<1>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
+                           span_keys, num_hits);
 }
 
 }  // namespace vq
