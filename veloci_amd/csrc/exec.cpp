@@ -559,6 +559,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint8_t* hup = ws.h_up.as<uint8_t>();
     uint8_t* dup = ws.d_up.as<uint8_t>();
     bool union_has_or = false;
+    uint32_t scatter_wide = 0, scatter_simple = 0;  // id (scattered) lists per query: they alone need an LDS tile in k_scan_simple
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0;
     {
         size_t off = 0;
@@ -597,10 +598,12 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
             } else if (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND) {
+                scatter_wide = std::max<uint32_t>(scatter_wide, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)));
                 sw[n_wide] = accw;
                 mw[n_wide++] = qi;
                 accw += cq.n_spans;
             } else if (cq.simple_flags) {
+                scatter_simple = std::max<uint32_t>(scatter_simple, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)));
                 ss[n_simple] = accs;
                 ms[n_simple++] = qi;
                 accs += cq.n_spans;
@@ -653,11 +656,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
-    launch_scan_simple(st, true, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
+    launch_scan_simple(st, true, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
-    launch_scan_simple(st, false, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+    launch_scan_simple(st, false, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());

@@ -1086,7 +1086,7 @@ constexpr uint32_t kSLdsQDoc = 8;
 constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
 constexpr uint32_t kSLdsCand = kSLdsQIdx + 4 * kQCap;
 
-size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv) { return (size_t)(kSLdsCand + 2 * cand_cap + 4 * kSWW * nv) * 4 + 16; }
+size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter) { return (size_t)(kSLdsCand + 2 * cand_cap + n_scatter * kSWW * nv) * 4 + 16; }
 
 struct SimpleLeaf {
     const uint32_t* docs;
@@ -1213,7 +1213,10 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     uint32_t* qdoc = lds + kSLdsQDoc;
     uint32_t* qidx = lds + kSLdsQIdx;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kSLdsCand);
-    uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [4][SWW]
+    uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [number of scattered (id) lists][SWW]: lists read as bitmap images need no LDS tile
+    uint32_t bslot[4];                                // LDS tile of list k
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) bslot[k] = (uint32_t)__popc(~sflags & ((1u << k) - 1u) & 0xFu) * SWW;
     CandState cs{cand, cand_n, thr, cand_cap};
 
     const uint32_t n_spans = H->n_spans;
@@ -1287,7 +1290,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                     const uint32_t v = (cur[k] >> 2) + lane;
                     wk[k][0] = v < ((lf[k].len + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(lf[k].docs))[v] : kSent;
 #pragma unroll
-                    for (uint32_t h = 0; h < NV; ++h) reinterpret_cast<u32x4*>(bml + k * SWW)[lane * NV + h] = kZero;
+                    for (uint32_t h = 0; h < NV; ++h) reinterpret_cast<u32x4*>(bml + bslot[k])[lane * NV + h] = kZero;
                 }
             }
         }
@@ -1298,7 +1301,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 const uint32_t c0v = cur[k] & ~3u;
                 const uint32_t nvec = (lf[k].len + 3u) >> 2;
                 const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lf[k].docs));
-                uint32_t* bmi = bml + k * SWW;
+                uint32_t* bmi = bml + bslot[k];
                 uint32_t v = (c0v >> 2) + lane;
                 u32x4 d4 = wk[k][0];
                 uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
@@ -1346,7 +1349,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         for (uint32_t k = 0; k < 4; ++k)
             if (k < n && !((sflags >> k) & 1u)) {
 #pragma unroll
-                for (uint32_t h = 0; h < NV; ++h) wk[k][h] = reinterpret_cast<const u32x4*>(bml + k * SWW)[lane * NV + h];
+                for (uint32_t h = 0; h < NV; ++h) wk[k][h] = reinterpret_cast<const u32x4*>(bml + bslot[k])[lane * NV + h];
             }
 
         // presence of the root
@@ -1533,15 +1536,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     scan_simple_body<NV>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
 }
 
-void launch_scan_simple(hipStream_t st, bool wide, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
     if (!total_spans) return;
     static const uint32_t force_nv = std::getenv("VQ_SIMPLE_NV") ? uint32_t(std::atoi(std::getenv("VQ_SIMPLE_NV"))) : 0u;
     if (force_nv ? force_nv == 2u : wide)
-        hipLaunchKernelGGL(k_scan_simple<2>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
+        hipLaunchKernelGGL(k_scan_simple<2>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
                            span_keys, num_hits);
     else
-        hipLaunchKernelGGL(k_scan_simple<1>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
+        hipLaunchKernelGGL(k_scan_simple<1>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
                            span_keys, num_hits);
 }
 
