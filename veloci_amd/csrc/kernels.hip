@@ -1525,9 +1525,8 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
 }
 
-// AND (few survivors): 16384-doc tiles halve the per-tile instruction overhead — the kernel is VALU-issue bound, not bandwidth bound
-// (rocprofv3 SQ_INSTS_VALU: 60 % of the issue slots at 8192 docs per tile).  OR: 8192-doc tiles (more survivors per lane make the
-// longer tiles slower there).  VQ_SIMPLE_NV=1 / 2 forces one width.
+// 16384-doc tiles (NV = 2) cut the per-tile instruction overhead — with LDS sized by need the kernel is VALU-issue bound, not
+// bandwidth bound (rocprofv3 SQ_INSTS_VALU: 60 % of the issue slots at 8192 docs per tile).  VQ_SIMPLE_NV=1 / 2 forces one width.
 template <uint32_t NV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
