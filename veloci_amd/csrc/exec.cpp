@@ -660,7 +660,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
-    launch_scan_simple(st, true, scatter_simple, spans_simple,  // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy) pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+    // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy)
+    launch_scan_simple(st, true, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
