@@ -210,9 +210,11 @@ def main():
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},
             "p50_latency_ms_single_query": (round(p50, 3) if p50 == p50 else None),
-            "roofline": {"bound": "hbm", "kernel": "k_scan_simple", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": {"and": "k_scan_simple", "or": "k_scan_simple", "single": "k_scan_union"}.get(args.workload, "k_tile_scan"), "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches)},
+                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches),
+                         "note": "achieved = algorithmic bytes (6 B per posting + 8 B per returned hit, SURVEY.md 8d) / mean launch time; the kernel reads dense "
+                                 "lists as bitmap images, so it moves fewer HBM bytes than that (see traffic) and frac can exceed 1"},
         }
         # HBM traffic per launch from the committed PMC passes (profiles/r01_traffic.json), when they were taken on this configuration
         try:

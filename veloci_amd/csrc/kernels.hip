@@ -1068,7 +1068,7 @@ void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, 
 // (or a single leaf), no filter and no sink stages.  This is the shape of the headline workloads
 // (single-term scan, 3-term AND, 3-term OR), so it gets its own kernel with everything that does not
 // change from tile to tile in registers:
-//   * fixed tile of 8192 docs: every lane owns 4 consecutive bitmap words (one 16-byte vector)
+//   * tile of NV * 8192 docs (NV = 2): every lane owns NV * 4 consecutive bitmap words (NV 16-byte vectors)
 //   * dense lists are read as bitmap words straight from HBM into registers (no LDS round trip);
 //     sparse lists are scattered into an LDS bitmap with the ballot-counted cursor logic
 //   * presence = register AND/OR of the word vectors; ranks = lane-local popcounts + one DPP scan per list
