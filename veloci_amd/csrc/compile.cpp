@@ -852,6 +852,154 @@ struct Compiler {
         if (next_temp > 32) unsupported("presence program needs more than 32 temporary bitmaps");
     }
 
+    // Rich simple queries (DSimple2, k_scan_simple<2, true>): <= 4 single-list posting leaves in a tree of depth <= 2, no filter, no facets,
+    // sink stages that need membership in <= 4 id lists, the leaves' own presence, or a gather by doc id.
+    void detect_rich_simple() {
+        static const bool off = std::getenv("VQ_FORCE_GENERIC") != nullptr || std::getenv("VQ_NO_RICH") != nullptr;
+        if (off || !count_reqs.empty() || !cq.fops.empty() || !cq.facets.empty() || cq.ops.empty()) return;
+        if (uint64_t(idx.doc_hi) - idx.doc_lo < 65536 || cq.n_top_cols != cq.cols.size() || cq.cols.size() > 4) return;
+        DSimple2 S{};
+        std::vector<uint16_t> leaves;  // list index of leaf k
+        struct Node {
+            bool is_leaf;
+            uint32_t leaf;      // leaf index
+            DOp op;             // group op
+            std::vector<uint32_t> kids;  // leaf indices of a group
+        };
+        std::vector<Node> st;
+        bool have_root = false;
+        for (size_t o = 0; o < cq.ops.size(); ++o) {
+            const DOp& op = cq.ops[o];
+            if (op.kind == OP_LEAF) {
+                if (op.list_count != 1) return;
+                const HList& l = cq.lists[op.list_begin];
+                if (!(l.flags & LIST_HAS_SCORES) || (l.flags & LIST_F32) || l.inline_idx >= 0) return;
+                if (leaves.size() >= 4) return;
+                st.push_back(Node{true, uint32_t(leaves.size()), op, {}});
+                leaves.push_back(op.list_begin);
+            } else if (op.kind == OP_AND || op.kind == OP_OR) {
+                if (op.nchild > st.size() || op.nchild > 4) return;
+                std::vector<Node> kids(st.end() - op.nchild, st.end());
+                st.resize(st.size() - op.nchild);
+                bool all_leaves = true;
+                for (auto& k : kids) all_leaves = all_leaves && k.is_leaf;
+                const bool last = o + 1 == cq.ops.size();
+                if (all_leaves && !last) {  // a group of leaves
+                    Node g{false, 0, op, {}};
+                    for (auto& k : kids) g.kids.push_back(k.leaf);
+                    st.push_back(g);
+                } else if (last && st.empty()) {  // the root over leaves and groups
+                    if (kids.size() > 4) return;
+                    S.ngroups = uint8_t(kids.size());
+                    S.root_kind = op.kind;
+                    S.root_nslots = op.nslots;
+                    for (size_t g = 0; g < kids.size(); ++g) {
+                        S.r_order[g] = op.and_order[g];
+                        S.r_slot[g] = op.child_slot[g];
+                        if (kids[g].is_leaf) {
+                            S.g_kind[g] = OP_LEAF;
+                            S.g_mask[g] = uint8_t(1u << kids[g].leaf);
+                        } else {
+                            const DOp& gop = kids[g].op;
+                            S.g_kind[g] = gop.kind;
+                            S.g_nslots[g] = gop.nslots;
+                            for (size_t c = 0; c < kids[g].kids.size(); ++c) {
+                                const uint32_t leaf = kids[g].kids[c];
+                                S.g_mask[g] |= uint8_t(1u << leaf);
+                                S.g_order[g][c] = uint8_t(kids[g].kids[gop.and_order[c]]);  // and_order holds child positions
+                                S.g_slot[g][leaf] = gop.child_slot[c];
+                            }
+                        }
+                    }
+                    have_root = true;
+                } else return;  // deeper than two levels
+            } else return;  // OP_BOOST1N ...
+        }
+        if (!have_root) {
+            if (st.size() != 1 || !st[0].is_leaf) return;  // a single leaf
+            S.ngroups = 1;
+            S.root_kind = OP_LEAF;
+            S.root_nslots = 1;
+            S.g_kind[0] = OP_LEAF;
+            S.g_mask[0] = 1;
+        }
+        const uint32_t n = uint32_t(leaves.size());
+        for (uint32_t k = 0; k < n; ++k) S.leaf_list[k] = leaves[k];
+        // side lists of the sink stages
+        std::vector<uint16_t> sides;
+        auto leaf_of = [&](uint32_t li) -> int {
+            for (uint32_t k = 0; k < n; ++k)
+                if (leaves[k] == li) return int(k);
+            return -1;
+        };
+        auto side_of = [&](uint32_t li) -> int {
+            if (cq.lists[li].flags & LIST_HAS_SCORES) return -1;  // value lists (1:n boosts, precomputed locality) need the interpreter
+            for (size_t s2 = 0; s2 < sides.size(); ++s2)
+                if (sides[s2] == li) return int(s2);
+            if (sides.size() >= 4) return -1;
+            sides.push_back(uint16_t(li));
+            return int(sides.size() - 1);
+        };
+        if (cq.groups.size() > 4 || cq.tboosts.size() > 4 || cq.locf.size() > 2) return;
+        for (size_t g = 0; g < cq.groups.size(); ++g) {
+            for (uint32_t j = 0; j < cq.groups[g].list_count; ++j) {
+                const int s2 = side_of(cq.groups[g].list_begin + j);
+                if (s2 < 0) return;
+                S.grp_mask[g] |= uint8_t(1u << s2);
+            }
+            S.grp_mult[g] = cq.groups[g].mult;
+        }
+        S.n_grp = uint8_t(cq.groups.size());
+        for (size_t t = 0; t < cq.tboosts.size(); ++t) {
+            const int s2 = side_of(cq.tboosts[t].list);
+            if (s2 < 0) return;
+            S.tb_side[t] = uint8_t(s2);
+            S.tb_mult[t] = cq.tboosts[t].mult;
+        }
+        S.n_tb = uint8_t(cq.tboosts.size());
+        for (size_t f = 0; f < cq.locf.size(); ++f) {
+            if (cq.locf[f].list_count == kLocPrecomputed) return;
+            for (uint32_t j = 0; j < cq.locf[f].list_count; ++j) {
+                const uint32_t li = cq.loc_idx[cq.locf[f].list_begin + j];
+                const int k = leaf_of(li);
+                if (k >= 0) {
+                    if (S.loc_leaf[f] & (1u << k)) return;  // the same list twice: counted twice by the reference, not representable as a mask
+                    S.loc_leaf[f] |= uint8_t(1u << k);
+                } else {
+                    const int s2 = side_of(li);
+                    if (s2 < 0 || (S.loc_side[f] & (1u << s2))) return;
+                    S.loc_side[f] |= uint8_t(1u << s2);
+                }
+            }
+        }
+        S.n_loc = uint8_t(cq.locf.size());
+        S.n_side = uint8_t(sides.size());
+        for (size_t s2 = 0; s2 < sides.size(); ++s2) S.side_list[s2] = sides[s2];
+        for (uint32_t li = 0; li < cq.lists.size(); ++li)  // every list must be a leaf or a side list
+            if (leaf_of(li) < 0 && std::find(sides.begin(), sides.end(), uint16_t(li)) == sides.end()) return;
+        // flags as for the flat simple queries, per leaf
+        uint32_t f = (1u << 17) | (1u << 18);
+        bool seq = false;
+        for (uint32_t k = 0; k < n; ++k) {
+            const HList& l = cq.lists[leaves[k]];
+            if ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP)) seq = true;
+        }
+        if (seq) f |= 1u << 16;
+        bool any_cover = false;
+        for (uint32_t k = 0; k < n; ++k) {
+            const HList& l = cq.lists[leaves[k]];
+            const bool cover = l.flags & LIST_COVER;
+            any_cover = any_cover || cover;
+            if (cover) f |= 1u << (8 + k);
+            if ((l.flags & LIST_BITMAP) && (seq || !cover)) f |= 1u << k;
+            if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);
+        }
+        if (!any_cover) return;
+        cq.simple2 = S;
+        cq.simple_n = n;
+        cq.simple_flags = f;
+    }
+
     // ------------------------------------------------------------ the whole request (search.rs:143-228)
     void run() {
         if (req.has_select) unsupported("select");
@@ -1168,6 +1316,8 @@ struct Compiler {
                 cq.simple_flags = f;
             }
         }
+
+        if (!cq.simple_flags) detect_rich_simple();
 
         // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
         const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);

@@ -115,6 +115,26 @@ struct DFacet {  // facet.rs:31-73 fast path: anchor -> value ids, counted into 
     uint32_t out_off;     // index into the facet output arrays
 };
 
+// "Rich simple" queries (k_scan_simple<NV, true>): <= 4 single-list posting leaves in a tree of depth <= 2 (root over leaves or over
+// AND / OR groups of leaves), plus the sink stages that only need membership in a few id lists ("side" lists: phrase groups,
+// boost_term), the presence of the leaves themselves (text locality on shared lists) or a gather by doc id (column boosts).
+struct DSimple2 {
+    uint8_t ngroups, root_kind, root_nslots, n_side;
+    uint8_t g_kind[4], g_mask[4], g_nslots[4];  // group g: OP_LEAF / OP_AND / OP_OR over the leaves in g_mask
+    uint8_t g_order[4][4];                      // AND group: its leaves in summation order (set_op.rs:393,415-416)
+    uint8_t g_slot[4][4];                       // OR group: term slot of leaf k
+    uint8_t r_order[4];                         // root AND: groups in summation order
+    uint8_t r_slot[4];                          // root OR: term slot of group g
+    uint8_t n_grp, n_tb, n_loc, pad0;
+    uint8_t grp_mask[4];                        // phrase group g: its side lists (bit s)
+    uint8_t tb_side[4];                         // boost_term t: its side list
+    uint8_t loc_leaf[2], loc_side[2];           // locality field f: leaves / side lists that are the terms' token->text lists
+    uint16_t leaf_list[4];                      // list index of leaf k
+    uint16_t side_list[4];                      // list index of side list s
+    float grp_mult[4];
+    float tb_mult[4];
+};
+
 struct QHeader {
     uint32_t n_lists, n_ops, n_fops, n_groups, n_tboost, n_col, n_locf, n_facets;
     uint32_t off_lists, off_ops, off_fops, off_groups, off_tboost, off_col, off_locf, off_facets;
@@ -128,13 +148,15 @@ struct QHeader {
     uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
     uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
+    uint32_t off_simple2;    // DSimple2 (simple_flags bit 18)
+    uint32_t pad1;
     uint32_t n_counts;       // != 0: count pre-pass — only the presence program runs, PRES_COUNT counters are added to
                              // counts[part_keys_off + c] (the buffer passed as `num_hits`); nothing is scored
     uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are
                              // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
-                             // bits 20-23: leaf k has enough entries per tile to prefetch its next 1 KiB round
+                             // bit 18: rich simple query (DSimple2); bits 20-23: leaf k has enough entries per tile to prefetch its next 1 KiB round
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

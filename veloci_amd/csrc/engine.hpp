@@ -339,6 +339,7 @@ struct CompiledQuery {
     std::vector<DColBoost> cols;
     std::vector<DLocField> locf;
     std::vector<uint16_t> loc_idx;
+    DSimple2 simple2{};  // simple_flags bit 18
     std::vector<DFacet> facets;
     std::vector<FacetOut> facet_out;
     uint32_t top = 10, skip = 0, top_k = 10;

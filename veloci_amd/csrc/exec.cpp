@@ -61,6 +61,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres = uint32_t(section(cq.pres.size() * sizeof(DPresOp)));
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
+    h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : 0));
     h.n_temps = cq.n_temps;
     h.n_counts = cq.n_counts;
     h.simple_n = cq.simple_n;
@@ -104,6 +105,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!cq.cols.empty()) std::memcpy(dst + h.off_col, cq.cols.data(), cq.cols.size() * sizeof(DColBoost));
     if (!cq.locf.empty()) std::memcpy(dst + h.off_locf, cq.locf.data(), cq.locf.size() * sizeof(DLocField));
     if (!cq.loc_idx.empty()) std::memcpy(dst + h.off_loc_idx, cq.loc_idx.data(), cq.loc_idx.size() * sizeof(uint16_t));
+    if ((cq.simple_flags >> 18) & 1u) std::memcpy(dst + h.off_simple2, &cq.simple2, sizeof(DSimple2));
     if (!cq.pres.empty()) std::memcpy(dst + h.off_pres, cq.pres.data(), cq.pres.size() * sizeof(DPresOp));
     if (!cq.pres_in.empty()) std::memcpy(dst + h.off_pres_in, cq.pres_in.data(), cq.pres_in.size() * sizeof(uint16_t));
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);
@@ -552,7 +554,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_d = up_span_d + tbl;
     const size_t up_span_w = up_qmap_d + tbl;   // simple ANDs: k_scan_simple with 16384-doc tiles
     const size_t up_qmap_w = up_span_w + tbl;
-    const size_t up_jobs = up_qmap_w + tbl;
+    const size_t up_span_r = up_qmap_w + tbl;   // rich simple queries (DSimple2): k_scan_simple<2, true>
+    const size_t up_qmap_r = up_span_r + tbl;
+    const size_t up_jobs = up_qmap_r + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
@@ -560,7 +564,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint8_t* dup = ws.d_up.as<uint8_t>();
     bool union_has_or = false;
     uint32_t scatter_wide = 0, scatter_simple = 0;  // id (scattered) lists per query: they alone need an LDS tile in k_scan_simple
-    uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0;
+    uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, n_rich = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0, spans_rich = 0;
+    uint32_t scatter_rich = 0;
     {
         size_t off = 0;
         uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
@@ -581,7 +586,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t* md = reinterpret_cast<uint32_t*>(hup + up_qmap_d);
         uint32_t* sw = reinterpret_cast<uint32_t*>(hup + up_span_w);
         uint32_t* mw = reinterpret_cast<uint32_t*>(hup + up_qmap_w);
-        uint32_t accg = 0, accs = 0, accd = 0, accw = 0;
+        uint32_t* sr = reinterpret_cast<uint32_t*>(hup + up_span_r);
+        uint32_t* mr = reinterpret_cast<uint32_t*>(hup + up_qmap_r);
+        uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0;
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
             const CompiledQuery& cq = pb->queries[i];
@@ -591,8 +598,14 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             // 3-term ORs on 100 M docs), so ORs take it only with VQ_UNION_OR=1
             static const bool union_enabled = std::getenv("VQ_NO_UNION") == nullptr;
             static const bool union_or = std::getenv("VQ_UNION_OR") != nullptr;
-            const bool dense = union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
-            if (dense) {
+            const bool rich = (cq.simple_flags >> 18) & 1u;
+            const bool dense = !rich && union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
+            if (rich) {
+                scatter_rich = std::max<uint32_t>(scatter_rich, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)) + cq.simple2.n_side);
+                sr[n_rich] = accr;
+                mr[n_rich++] = qi;
+                accr += cq.n_spans;
+            } else if (dense) {
                 union_has_or = union_has_or || cq.simple_n > 1;
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
@@ -618,6 +631,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         ss[n_simple] = accs;
         sw[n_wide] = accw;
         spans_wide = accw;
+        sr[n_rich] = accr;
+        spans_rich = accr;
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -656,12 +671,16 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
-    launch_scan_simple(st, true, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
+    launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_r),
+                       reinterpret_cast<const uint32_t*>(dup + up_qmap_r), n_rich, cand_cap, ws.d_span_keys.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+    VQ_HIP(hipGetLastError());
+    launch_scan_simple(st, false, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());
     // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy)
-    launch_scan_simple(st, true, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
+    launch_scan_simple(st, false, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
     VQ_HIP(hipGetLastError());

@@ -1081,10 +1081,11 @@ namespace vq {
 constexpr uint32_t kSW = 8192;   // docs per tile
 constexpr uint32_t kSWW = 256;   // bitmap words per tile
 constexpr uint32_t kQCap = 128;  // survivor queue entries
-// LDS map (u32): misc[8] | qdoc[kQCap] | qidx[4][kQCap] | cand[2*cand_cap] | bm[4][kSWW]
+// LDS map (u32): misc[8] | qdoc[kQCap] | qidx[4][kQCap] | qmask[kQCap] | cand[2*cand_cap] | bm[scattered lists][SWW]
 constexpr uint32_t kSLdsQDoc = 8;
 constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
-constexpr uint32_t kSLdsCand = kSLdsQIdx + 4 * kQCap;
+constexpr uint32_t kSLdsQMask = kSLdsQIdx + 4 * kQCap;  // rich queries: side-list membership bits of the queued doc
+constexpr uint32_t kSLdsCand = kSLdsQMask + kQCap;
 
 size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter) { return (size_t)(kSLdsCand + 2 * cand_cap + n_scatter * kSWW * nv) * 4 + 16; }
 
@@ -1158,7 +1159,215 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
     }
 }
 
-template <uint32_t NV>  // u32x4 bitmap vectors per lane: the tile is NV * 8192 docs
+// ---- rich simple queries: shape of the tree and of the sink stages, all wave-uniform
+struct RichShape {
+    uint32_t ngroups, root_kind, root_nslots, n_side;
+    uint32_t g_kind4, g_mask4, g_nslots4, r_order4, r_slot4;
+    uint32_t g_order4[4], g_slot4[4];
+    uint32_t n_grp, n_tb, n_loc, grp_mask4, tb_side4, loc_leaf2, loc_side2;
+    float grp_mult[4], tb_mult[4];
+    const DColBoost* cols;
+    uint32_t n_col;
+};
+__device__ __forceinline__ uint32_t b8(uint32_t x, uint32_t i) { return (x >> (8u * i)) & 0xFFu; }
+
+__device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const DColBoost* cols, uint32_t n_col) {
+    RichShape R;
+    R.ngroups = S2->ngroups; R.root_kind = S2->root_kind; R.root_nslots = S2->root_nslots; R.n_side = S2->n_side;
+    R.g_kind4 = *reinterpret_cast<const uint32_t*>(S2->g_kind);
+    R.g_mask4 = *reinterpret_cast<const uint32_t*>(S2->g_mask);
+    R.g_nslots4 = *reinterpret_cast<const uint32_t*>(S2->g_nslots);
+    R.r_order4 = *reinterpret_cast<const uint32_t*>(S2->r_order);
+    R.r_slot4 = *reinterpret_cast<const uint32_t*>(S2->r_slot);
+#pragma unroll
+    for (uint32_t g = 0; g < 4; ++g) {
+        R.g_order4[g] = *reinterpret_cast<const uint32_t*>(S2->g_order[g]);
+        R.g_slot4[g] = *reinterpret_cast<const uint32_t*>(S2->g_slot[g]);
+        R.grp_mult[g] = S2->grp_mult[g];
+        R.tb_mult[g] = S2->tb_mult[g];
+    }
+    R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc;
+    R.grp_mask4 = *reinterpret_cast<const uint32_t*>(S2->grp_mask);
+    R.tb_side4 = *reinterpret_cast<const uint32_t*>(S2->tb_side);
+    R.loc_leaf2 = (uint32_t)S2->loc_leaf[0] | ((uint32_t)S2->loc_leaf[1] << 8);
+    R.loc_side2 = (uint32_t)S2->loc_side[0] | ((uint32_t)S2->loc_side[1] << 8);
+    R.cols = cols;
+    R.n_col = n_col;
+    return R;
+}
+
+// Score queue entries [0, count) of a rich simple query: leaves -> groups -> root (same arithmetic and order as tree_score_generic),
+// then the sink stages in the reference's order (column boosts, phrase groups, term boosts, text locality).
+__device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4], const RichShape& R, const uint32_t* qdoc, const uint32_t* qidx,
+                           const uint32_t* qmask, const CandState& cs, uint32_t top_k) {
+    const uint32_t lane = threadIdx.x;
+    const bool have = lane < count;
+    uint32_t doc = 0, qm = 0, pm = 0;
+    uint32_t idx[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (have) {
+        doc = qdoc[lane];
+        qm = qmask[lane];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n) idx[k] = qidx[k * kQCap + lane];
+    }
+    uint16_t raw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n && idx[k] != 0xFFFFFFFFu) {
+            raw[k] = as_global(lf[k].scores)[idx[k]];
+            pm |= 1u << k;
+        }
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < n) val[k] = posting_value(lf[k].ts, raw[k]);
+    // groups
+    float gv[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t gp = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 4; ++g) {
+        if (g < R.ngroups) {  // uniform
+            const uint32_t gk = b8(R.g_kind4, g), gm = b8(R.g_mask4, g);
+            if (gk == OP_AND) {  // set_op.rs:415-416
+                float sacc = 0.0f;
+                const uint32_t cnt = (uint32_t)__popc(gm);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    if (i < cnt) sacc += pick4(val[0], val[1], val[2], val[3], b8(R.g_order4[g], i));
+                gv[g] = sacc;
+                if ((pm & gm) == gm) gp |= 1u << g;
+            } else if (gk == OP_OR) {  // set_op.rs:169-186
+                float sum = 0.0f, nd = 0.0f;
+                const uint32_t ns = b8(R.g_nslots4, g);
+                for (uint32_t sl = 0; sl < ns; ++sl) {
+                    float m = 0.0f;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (((gm >> k) & 1u) && b8(R.g_slot4[g], k) == sl && ((pm >> k) & 1u)) m = fmaxf(m, val[k]);
+                    if (m >= 0.00001f) nd += 1.0f;
+                    sum += m;
+                }
+                gv[g] = sum * nd * nd;
+                if (pm & gm) gp |= 1u << g;
+            } else {  // a leaf
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if ((gm >> k) & 1u) gv[g] = val[k];
+                if (pm & gm) gp |= 1u << g;
+            }
+        }
+    }
+    float score;
+    if (R.root_kind == OP_AND) {
+        score = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < R.ngroups) score += pick4(gv[0], gv[1], gv[2], gv[3], b8(R.r_order4, i));
+    } else if (R.root_kind == OP_OR) {
+        float sum = 0.0f, nd = 0.0f;
+        for (uint32_t sl = 0; sl < R.root_nslots; ++sl) {
+            float m = 0.0f;
+#pragma unroll
+            for (uint32_t g = 0; g < 4; ++g)
+                if (g < R.ngroups && b8(R.r_slot4, g) == sl && ((gp >> g) & 1u)) m = fmaxf(m, gv[g]);
+            if (m >= 0.00001f) nd += 1.0f;
+            sum += m;
+        }
+        score = sum * nd * nd;
+    } else score = gv[0];
+    // sink stages
+    for (uint32_t k = 0; k < R.n_col; ++k) score = apply_col_boost(score, R.cols[k], doc);
+#pragma unroll
+    for (uint32_t g = 0; g < 4; ++g)
+        if (g < R.n_grp && (qm & b8(R.grp_mask4, g))) score *= R.grp_mult[g];
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+        if (t < R.n_tb && ((qm >> b8(R.tb_side4, t)) & 1u)) score *= R.tb_mult[t];
+    if (R.n_loc) {  // boost.rs:11-87: 2*c*c per field with c > 1, the MINIMUM over fields (:25)
+        float best = 0.0f;
+        bool hav = false;
+#pragma unroll
+        for (uint32_t f = 0; f < 2; ++f)
+            if (f < R.n_loc) {
+                const uint32_t cnt = (uint32_t)__popc(pm & b8(R.loc_leaf2, f)) + (uint32_t)__popc(qm & b8(R.loc_side2, f));
+                if (cnt > 1u) {
+                    const float bv = 2.0f * (float)cnt * (float)cnt;
+                    if (!hav || bv < best) best = bv;
+                    hav = true;
+                }
+            }
+        if (hav) score *= best;
+    }
+    const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+    bool pending = have && key > *cs.thr;
+    while (true) {
+        if (pending) {
+            if (key > *cs.thr) {
+                uint32_t pos = atomicAdd(cs.n, 1u);
+                if (pos < cs.cap) {
+                    cs.cand[pos] = key;
+                    pending = false;
+                }
+            } else pending = false;
+        }
+        const int need = __syncthreads_or(pending ? 1 : 0);
+        if (!need) break;
+        cand_prune(cs, top_k);
+    }
+}
+
+// One id list of the tile: stream its doc ids from the cursor (64 lanes x 16 B per round), set the bits of the docs inside
+// [lo_bound, tile_hi) in the LDS tile, count with ballots (sorted list: the tile's entries are a prefix).  Returns the index of the
+// first in-tile entry; `cur` / `nxt` advance to the first entry of the next tile.
+__device__ __forceinline__ uint32_t simple_scatter_list(const uint32_t* docs, uint32_t len, uint32_t& cur, uint32_t& nxt, uint32_t* bmi, u32x4 d4, bool prefetch,
+                                                        uint32_t tile_lo, uint32_t tile_hi, uint32_t lo_bound) {
+    const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c0v = cur & ~3u;
+    const uint32_t nvec = (len + 3u) >> 2;
+    const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(docs));
+    uint32_t v = (c0v >> 2) + lane;
+    uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
+    while (true) {
+        const uint32_t vn = v + 64u;
+        u32x4 nx = kSent;
+        if (prefetch && vn < nvec) nx = dptr[vn];
+        const bool ix = d4.x < tile_hi, iy = d4.y < tile_hi, iz = d4.z < tile_hi, iw = d4.w < tile_hi;
+        const uint32_t mine = (uint32_t)ix + (uint32_t)iy + (uint32_t)iz + (uint32_t)iw;
+        const uint32_t full = (uint32_t)__popcll(__ballot(iw));
+        if (!prefetch && full == 64u && vn < nvec) nx = dptr[vn];  // sparse list: load the next round only when needed
+        uint32_t n_in = full << 2;
+        if (full < 64u) n_in += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)full);
+        total_in += n_in;
+        const unsigned long long lom = __ballot(d4.x < lo_bound);
+        if (lom) {
+            const bool lx = d4.x < lo_bound, ly = d4.y < lo_bound, lz = d4.z < lo_bound, lw = d4.w < lo_bound;
+            total_lo += (uint32_t)(__popcll(lom) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
+            if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+            if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+            if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+            if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+        } else {
+            if (ix) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
+            if (iy) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
+            if (iz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
+            if (iw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
+        }
+        if (full < 64u) {
+            const uint32_t c = mine == 0 ? d4.x : mine == 1 ? d4.y : mine == 2 ? d4.z : d4.w;
+            boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)full);
+            break;
+        }
+        d4 = nx;
+        v = vn;
+    }
+    cur = c0v + total_in;
+    nxt = boundary;
+    return c0v + total_lo;  // index of the first in-tile entry
+}
+
+template <uint32_t NV, bool RICH>  // NV: u32x4 bitmap vectors per lane (the tile is NV * 8192 docs); RICH: DSimple2 queries
 __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                  const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
                                                  unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
@@ -1186,6 +1395,9 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     const DList* gl = reinterpret_cast<const DList*>(blob + H->off_lists);
     const DOp* gops = reinterpret_cast<const DOp*>(blob + H->off_ops);
     const bool seq = (sflags >> 16) & 1u;
+    const DSimple2* S2 = reinterpret_cast<const DSimple2*>(blob + H->off_simple2);  // RICH only
+    RichShape R{};
+    if constexpr (RICH) R = load_rich_shape(S2, reinterpret_cast<const DColBoost*>(blob + H->off_col), H->n_col);
 
     SimpleLeaf lf[4];
     uint8_t order[4] = {0, 1, 2, 3}, slot[4] = {0, 0, 0, 0};
@@ -1193,12 +1405,13 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     for (uint32_t k = 0; k < 4; ++k) {
         lf[k] = SimpleLeaf{nullptr, nullptr, nullptr, nullptr, 0u, 0.f};
         if (k < n) {
-            const DList& d = gl[gops[k].list_begin];
+            const DList& d = gl[RICH ? (uint32_t)S2->leaf_list[k] : (uint32_t)gops[k].list_begin];
             lf[k] = SimpleLeaf{d.docs, d.scores, d.bitmap, d.rank_dir, d.len, d.term_score};
         }
     }
     uint32_t kind = OP_LEAF, nslots = 1;
-    if (n > 1) {
+    if (RICH) kind = 0xFFu;  // presence and scores follow the DSimple2 shape
+    else if (n > 1) {
         kind = gops[n].kind;
         nslots = gops[n].nslots;
 #pragma unroll
@@ -1212,6 +1425,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     uint32_t* cand_n = lds + 2;
     uint32_t* qdoc = lds + kSLdsQDoc;
     uint32_t* qidx = lds + kSLdsQIdx;
+    uint32_t* qmask = lds + kSLdsQMask;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kSLdsCand);
     uint32_t* bml = lds + kSLdsCand + 2 * cand_cap;  // [number of scattered (id) lists][SWW]: lists read as bitmap images need no LDS tile
     uint32_t bslot[4];                                // LDS tile of list k
@@ -1234,6 +1448,22 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
             cur[k] = wave_lower_bound(lf[k].docs, lf[k].len, span_lo);
             nxt[k] = cur[k] < lf[k].len ? as_global(lf[k].docs)[cur[k]] : 0xFFFFFFFFu;
         }
+    }
+    // side lists (rich queries): id lists that only the sink stages look at; each has an LDS tile behind the scattered leaves' tiles
+    const uint32_t* sdocs[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t slen[4] = {0, 0, 0, 0}, scur[4] = {0, 0, 0, 0}, snxt[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, sslot[4] = {0, 0, 0, 0};
+    if constexpr (RICH) {
+        const uint32_t n_scatter = (uint32_t)__popc(~sflags & ((1u << n) - 1u) & 0xFu);
+#pragma unroll
+        for (uint32_t s = 0; s < 4; ++s)
+            if (s < R.n_side) {
+                const DList& d = gl[S2->side_list[s]];
+                sdocs[s] = d.docs;
+                slen[s] = d.len;
+                sslot[s] = (n_scatter + s) * SWW;
+                scur[s] = wave_lower_bound(sdocs[s], slen[s], span_lo);
+                snxt[s] = scur[s] < slen[s] ? as_global(sdocs[s])[scur[s]] : 0xFFFFFFFFu;
+            }
     }
     if (lane == 0) {
         *thr = 0ull;
@@ -1295,55 +1525,25 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
             }
         }
         // scatter the id lists (rounds of 64 x 16 B, counted with ballots; see k_tile_scan P2)
+        if constexpr (RICH) {
+            u32x4 sfirst[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (k < n && !((sflags >> k) & 1u)) {
-                const uint32_t c0v = cur[k] & ~3u;
-                const uint32_t nvec = (lf[k].len + 3u) >> 2;
-                const VQ_GLOBAL u32x4* dptr = as_global(reinterpret_cast<const u32x4*>(lf[k].docs));
-                uint32_t* bmi = bml + bslot[k];
-                uint32_t v = (c0v >> 2) + lane;
-                u32x4 d4 = wk[k][0];
-                uint32_t total_in = 0, total_lo = 0, boundary = 0xFFFFFFFFu;
-                while (true) {
-                    const uint32_t vn = v + 64u;
-                    u32x4 nx = kSent;
-                    const bool prefetch = (sflags >> (20 + k)) & 1u;  // lists with >= ~200 entries per tile
-                    if (prefetch && vn < nvec) nx = dptr[vn];
-                    const bool ix = d4.x < tile_hi, iy = d4.y < tile_hi, iz = d4.z < tile_hi, iw = d4.w < tile_hi;
-                    const uint32_t mine = (uint32_t)ix + (uint32_t)iy + (uint32_t)iz + (uint32_t)iw;
-                    const uint32_t full = (uint32_t)__popcll(__ballot(iw));
-                    if (!prefetch && full == 64u && vn < nvec) nx = dptr[vn];  // sparse list: load the next round only when needed
-                    uint32_t n_in = full << 2;
-                    if (full < 64u) n_in += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)full);
-                    total_in += n_in;
-                    const unsigned long long lom = __ballot(d4.x < lo_bound);
-                    if (lom) {
-                        const bool lx = d4.x < lo_bound, ly = d4.y < lo_bound, lz = d4.z < lo_bound, lw = d4.w < lo_bound;
-                        total_lo += (uint32_t)(__popcll(lom) + __popcll(__ballot(ly)) + __popcll(__ballot(lz)) + __popcll(__ballot(lw)));
-                        if (ix && !lx) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
-                        if (iy && !ly) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
-                        if (iz && !lz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
-                        if (iw && !lw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
-                    } else {
-                        if (ix) atomicOr(&bmi[(d4.x - tile_lo) >> 5], 1u << ((d4.x - tile_lo) & 31u));
-                        if (iy) atomicOr(&bmi[(d4.y - tile_lo) >> 5], 1u << ((d4.y - tile_lo) & 31u));
-                        if (iz) atomicOr(&bmi[(d4.z - tile_lo) >> 5], 1u << ((d4.z - tile_lo) & 31u));
-                        if (iw) atomicOr(&bmi[(d4.w - tile_lo) >> 5], 1u << ((d4.w - tile_lo) & 31u));
-                    }
-                    if (full < 64u) {
-                        const uint32_t c = mine == 0 ? d4.x : mine == 1 ? d4.y : mine == 2 ? d4.z : d4.w;
-                        boundary = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)full);
-                        break;
-                    }
-                    d4 = nx;
-                    v = vn;
+            for (uint32_t s = 0; s < 4; ++s)
+                if (s < R.n_side) {
+                    if (snxt[s] < tile_lo && tile_lo - snxt[s] >= SW) scur[s] += wave_lower_bound(sdocs[s] + scur[s], slen[s] - scur[s], tile_lo);
+                    const uint32_t v = (scur[s] >> 2) + lane;
+                    sfirst[s] = v < ((slen[s] + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(sdocs[s]))[v] : kSent;
+#pragma unroll
+                    for (uint32_t h = 0; h < NV; ++h) reinterpret_cast<u32x4*>(bml + sslot[s])[lane * NV + h] = kZero;
                 }
-                base_idx[k] = c0v + total_lo;  // index of the first in-tile entry
-                cur[k] = c0v + total_in;
-                nxt[k] = boundary;
-            }
+#pragma unroll
+            for (uint32_t s = 0; s < 4; ++s)
+                if (s < R.n_side) (void)simple_scatter_list(sdocs[s], slen[s], scur[s], snxt[s], bml + sslot[s], sfirst[s], false, tile_lo, tile_hi, lo_bound);
         }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n && !((sflags >> k) & 1u))
+                base_idx[k] = simple_scatter_list(lf[k].docs, lf[k].len, cur[k], nxt[k], bml + bslot[k], wk[k][0], (sflags >> (20 + k)) & 1u, tile_lo, tile_hi, lo_bound);
         __syncthreads();  // one wave: LDS atomics above are ordered before the reads below
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
@@ -1358,7 +1558,21 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
 #pragma unroll
         for (uint32_t h = 0; h < NV; ++h) {
             r[h] = wk[0][h];
-            if (kind == OP_AND) {
+            if constexpr (RICH) {  // groups of leaves, then the root over the groups
+                const bool root_and = R.root_kind == OP_AND;
+                r[h] = root_and ? ~kZero : kZero;
+#pragma unroll
+                for (uint32_t g = 0; g < 4; ++g)
+                    if (g < R.ngroups) {  // uniform
+                        const bool g_and = b8(R.g_kind4, g) == OP_AND;
+                        const uint32_t gm = b8(R.g_mask4, g);
+                        u32x4 gw = g_and ? ~kZero : kZero;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k)
+                            if ((gm >> k) & 1u) gw = g_and ? (gw & wk[k][h]) : (gw | wk[k][h]);
+                        r[h] = root_and ? (r[h] & gw) : (r[h] | gw);
+                    }
+            } else if (kind == OP_AND) {
 #pragma unroll
                 for (uint32_t k = 1; k < 4; ++k)
                     if (k < n) r[h] &= wk[k][h];
@@ -1487,16 +1701,25 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                             qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + before + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
                         }
                     }
+                    if constexpr (RICH) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (uint32_t s2 = 0; s2 < 4; ++s2)
+                            if (s2 < R.n_side) m |= ((bml[sslot[s2] + lane * NW + j] >> b) & 1u) << s2;
+                        qmask[p] = m;
+                    }
                 }
                 qlen += (uint32_t)__popcll(mask);
                 if (qlen >= 64u) {  // uniform
                     __syncthreads();
-                    simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+                    if constexpr (RICH) rich_flush(64u, n, lf, R, qdoc, qidx, qmask, cs, top_k);
+                    else simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
                     // move the remainder to the front
                     const uint32_t rem = qlen - 64u;
-                    uint32_t td = 0, ti[4] = {0, 0, 0, 0};
+                    uint32_t td = 0, tm = 0, ti[4] = {0, 0, 0, 0};
                     if (lane < rem) {
                         td = qdoc[64u + lane];
+                        tm = qmask[64u + lane];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k)
                             if (k < n) ti[k] = qidx[k * kQCap + 64u + lane];
@@ -1504,6 +1727,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                     __syncthreads();
                     if (lane < rem) {
                         qdoc[lane] = td;
+                        qmask[lane] = tm;
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k)
                             if (k < n) qidx[k * kQCap + lane] = ti[k];
@@ -1515,7 +1739,10 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         }
     }
     __syncthreads();
-    if (qlen) simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+    if (qlen) {
+        if constexpr (RICH) rich_flush(qlen, n, lf, R, qdoc, qidx, qmask, cs, top_k);
+        else simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+    }
     cand_prune(cs, top_k);
     {
         const uint32_t cn = *cand_n;
@@ -1527,24 +1754,28 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
 
 // 16384-doc tiles (NV = 2) cut the per-tile instruction overhead — with LDS sized by need the kernel is VALU-issue bound, not
 // bandwidth bound (rocprofv3 SQ_INSTS_VALU: 60 % of the issue slots at 8192 docs per tile).  VQ_SIMPLE_NV=1 / 2 forces one width.
-template <uint32_t NV>
+template <uint32_t NV, bool RICH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                     uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
                                                     unsigned long long* __restrict__ num_hits) {
-    scan_simple_body<NV>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+    scan_simple_body<NV, RICH>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
 }
 
-void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+// n_scatter: LDS tiles per workgroup (scattered leaves + side lists, maximum over the launch's queries)
+void launch_scan_simple(hipStream_t st, bool rich, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
     if (!total_spans) return;
     static const uint32_t force_nv = std::getenv("VQ_SIMPLE_NV") ? uint32_t(std::atoi(std::getenv("VQ_SIMPLE_NV"))) : 0u;
-    if (force_nv ? force_nv == 2u : wide)
-        hipLaunchKernelGGL(k_scan_simple<2>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
-                           span_keys, num_hits);
+    if (rich)
+        hipLaunchKernelGGL((k_scan_simple<2, true>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits);
+    else if (force_nv == 1u)
+        hipLaunchKernelGGL((k_scan_simple<1, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits);
     else
-        hipLaunchKernelGGL(k_scan_simple<1>, dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter), st, blobs, blob_off, span_base, qmap, nq, cand_cap,
-                           span_keys, num_hits);
+        hipLaunchKernelGGL((k_scan_simple<2, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits);
 }
 
 }  // namespace vq
