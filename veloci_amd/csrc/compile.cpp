@@ -856,7 +856,9 @@ struct Compiler {
     // sink stages that need membership in <= 4 id lists, the leaves' own presence, or a gather by doc id.
     void detect_rich_simple() {
         static const bool off = std::getenv("VQ_FORCE_GENERIC") != nullptr || std::getenv("VQ_NO_RICH") != nullptr;
-        if (off || !count_reqs.empty() || !cq.fops.empty() || !cq.facets.empty() || cq.ops.empty()) return;
+        if (off || !count_reqs.empty() || cq.ops.empty() || cq.facets.size() > 2) return;
+        // a filter that is one leaf (one term, possibly several id lists: case variants) is a side-list membership test
+        if (!cq.fops.empty() && !(cq.fops.size() == 1 && cq.fops[0].kind == OP_LEAF && cq.fops[0].list_count <= 4)) return;
         if (uint64_t(idx.doc_hi) - idx.doc_lo < 65536 || cq.n_top_cols != cq.cols.size() || cq.cols.size() > 4) return;
         DSimple2 S{};
         std::vector<uint16_t> leaves;  // list index of leaf k
@@ -941,6 +943,14 @@ struct Compiler {
             return int(sides.size() - 1);
         };
         if (cq.groups.size() > 4 || cq.tboosts.size() > 4 || cq.locf.size() > 2) return;
+        if (!cq.fops.empty()) {
+            S.has_filter = 1;
+            for (uint32_t j = 0; j < cq.fops[0].list_count; ++j) {
+                const int s2 = side_of(cq.fops[0].list_begin + j);
+                if (s2 < 0) return;
+                S.filter_mask |= uint8_t(1u << s2);
+            }
+        }
         for (size_t g = 0; g < cq.groups.size(); ++g) {
             for (uint32_t j = 0; j < cq.groups[g].list_count; ++j) {
                 const int s2 = side_of(cq.groups[g].list_begin + j);

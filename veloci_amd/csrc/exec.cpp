@@ -673,16 +673,16 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
     launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_r),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_r), n_rich, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     VQ_HIP(hipGetLastError());
     launch_scan_simple(st, false, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     VQ_HIP(hipGetLastError());
     // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy)
     launch_scan_simple(st, false, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
+                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
     VQ_HIP(hipGetLastError());
     launch_scan_union(st, union_has_or, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
                       reinterpret_cast<const uint32_t*>(dup + up_qmap_d), n_dense, cand_cap, ws.d_span_keys.as<unsigned long long>(),

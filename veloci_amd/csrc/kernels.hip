@@ -1164,7 +1164,10 @@ struct RichShape {
     uint32_t ngroups, root_kind, root_nslots, n_side;
     uint32_t g_kind4, g_mask4, g_nslots4, r_order4, r_slot4;
     uint32_t g_order4[4], g_slot4[4];
-    uint32_t n_grp, n_tb, n_loc, grp_mask4, tb_side4, loc_leaf2, loc_side2;
+    uint32_t n_grp, n_tb, n_loc, grp_mask4, tb_side4, loc_leaf2, loc_side2, has_filter, filter_mask;
+    const DFacet* facets;
+    uint32_t n_facets;
+    uint32_t* hist;
     float grp_mult[4], tb_mult[4];
     const DColBoost* cols;
     uint32_t n_col;
@@ -1186,7 +1189,8 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
         R.grp_mult[g] = S2->grp_mult[g];
         R.tb_mult[g] = S2->tb_mult[g];
     }
-    R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc;
+    R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc; R.has_filter = S2->has_filter; R.filter_mask = S2->filter_mask;
+    R.facets = nullptr; R.n_facets = 0; R.hist = nullptr;
     R.grp_mask4 = *reinterpret_cast<const uint32_t*>(S2->grp_mask);
     R.tb_side4 = *reinterpret_cast<const uint32_t*>(S2->tb_side);
     R.loc_leaf2 = (uint32_t)S2->loc_leaf[0] | ((uint32_t)S2->loc_leaf[1] << 8);
@@ -1299,6 +1303,19 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
             }
         if (hav) score *= best;
     }
+    if (have) {  // persistence.rs:164-175 count_values_for_ids: every hit counts, whatever its score
+        for (uint32_t f = 0; f < R.n_facets; ++f) {
+            const DFacet& fa = R.facets[f];
+            if (doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
+                const uint32_t row = doc - fa.key_base;
+                const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+                for (unsigned long long e = e0; e < e1; ++e) {
+                    const uint32_t v = as_global(fa.values)[e];
+                    if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
+                }
+            }
+        }
+    }
     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
     bool pending = have && key > *cs.thr;
     while (true) {
@@ -1370,7 +1387,7 @@ __device__ __forceinline__ uint32_t simple_scatter_list(const uint32_t* docs, ui
 template <uint32_t NV, bool RICH>  // NV: u32x4 bitmap vectors per lane (the tile is NV * 8192 docs); RICH: DSimple2 queries
 __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                  const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
-                                                 unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
+                                                 unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t SW = kSW * NV, SWW = kSWW * NV, NW = 4u * NV;  // docs / words per tile, words per lane
     const uint32_t lane = threadIdx.x;
@@ -1397,7 +1414,12 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     const bool seq = (sflags >> 16) & 1u;
     const DSimple2* S2 = reinterpret_cast<const DSimple2*>(blob + H->off_simple2);  // RICH only
     RichShape R{};
-    if constexpr (RICH) R = load_rich_shape(S2, reinterpret_cast<const DColBoost*>(blob + H->off_col), H->n_col);
+    if constexpr (RICH) {
+        R = load_rich_shape(S2, reinterpret_cast<const DColBoost*>(blob + H->off_col), H->n_col);
+        R.facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
+        R.n_facets = H->n_facets;
+        R.hist = hist;
+    }
 
     SimpleLeaf lf[4];
     uint8_t order[4] = {0, 1, 2, 3}, slot[4] = {0, 0, 0, 0};
@@ -1572,6 +1594,13 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                             if ((gm >> k) & 1u) gw = g_and ? (gw & wk[k][h]) : (gw | wk[k][h]);
                         r[h] = root_and ? (r[h] & gw) : (r[h] | gw);
                     }
+                if (R.has_filter) {  // uniform: the doc must be in one of the filter's lists
+                    u32x4 fw = kZero;
+#pragma unroll
+                    for (uint32_t s2 = 0; s2 < 4; ++s2)
+                        if (s2 < R.n_side && ((R.filter_mask >> s2) & 1u)) fw |= reinterpret_cast<const u32x4*>(bml + sslot[s2])[lane * NV + h];
+                    r[h] &= fw;
+                }
             } else if (kind == OP_AND) {
 #pragma unroll
                 for (uint32_t k = 1; k < 4; ++k)
@@ -1758,24 +1787,24 @@ template <uint32_t NV, bool RICH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                     uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
-                                                    unsigned long long* __restrict__ num_hits) {
-    scan_simple_body<NV, RICH>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+                                                    unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
+    scan_simple_body<NV, RICH>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits, hist);
 }
 
 // n_scatter: LDS tiles per workgroup (scattered leaves + side lists, maximum over the launch's queries)
 void launch_scan_simple(hipStream_t st, bool rich, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
     if (!total_spans) return;
     static const uint32_t force_nv = std::getenv("VQ_SIMPLE_NV") ? uint32_t(std::atoi(std::getenv("VQ_SIMPLE_NV"))) : 0u;
     if (rich)
         hipLaunchKernelGGL((k_scan_simple<2, true>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits);
+                           cand_cap, span_keys, num_hits, hist);
     else if (force_nv == 1u)
         hipLaunchKernelGGL((k_scan_simple<1, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits);
+                           cand_cap, span_keys, num_hits, hist);
     else
         hipLaunchKernelGGL((k_scan_simple<2, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits);
+                           cand_cap, span_keys, num_hits, hist);
 }
 
 }  // namespace vq
