@@ -875,8 +875,9 @@ struct Compiler {
             if (op.kind == OP_LEAF) {
                 if (op.list_count != 1) return;
                 const HList& l = cq.lists[op.list_begin];
-                if (!(l.flags & LIST_HAS_SCORES) || (l.flags & LIST_F32) || l.inline_idx >= 0) return;
+                if (!(l.flags & LIST_HAS_SCORES) || l.inline_idx >= 0 || l.inline_val_idx >= 0) return;
                 if (leaves.size() >= 4) return;
+                if (l.flags & LIST_F32) S.f32_mask |= uint8_t(1u << leaves.size());
                 st.push_back(Node{true, uint32_t(leaves.size()), op, {}});
                 leaves.push_back(op.list_begin);
             } else if (op.kind == OP_AND || op.kind == OP_OR) {
@@ -1362,6 +1363,7 @@ struct Compiler {
         cq.tile_words = ww;
         cq.stack_depth = std::max<uint32_t>(max_depth, 1);
         uint64_t spans = (cq.total_len + span_postings - 1) / span_postings;
+        if (!cq.facets.empty()) spans = (cq.total_len + 4095) / 4096;  // every hit walks its facet rows: per-hit work, not per-posting streaming
         const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
         {  // k_tile_scan pays a latency-bound round trip per visited tile (score gathers, facet rows): at most ~16 visited tiles per span
             uint64_t cover_len = 0;
@@ -1370,6 +1372,7 @@ struct Compiler {
             const uint64_t visited = std::max<uint64_t>(std::min<uint64_t>(cover_len, tiles), 1);
             // (k_scan_simple batches its gathers across tiles; tiles with a lot of postings are bandwidth-, not latency-bound)
             if (!cq.simple_flags && cq.total_len / visited < 1024) spans = std::max<uint64_t>(spans, visited / 16);
+            if (((cq.simple_flags >> 18) & 1u) && cq.total_len / visited < 1024) spans = std::max<uint64_t>(spans, visited / 64);  // rich: 16384-doc tiles, cheaper each
         }
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);

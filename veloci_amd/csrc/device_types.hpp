@@ -126,7 +126,7 @@ struct DSimple2 {
     uint8_t r_order[4];                         // root AND: groups in summation order
     uint8_t r_slot[4];                          // root OR: term slot of group g
     uint8_t n_grp, n_tb, n_loc, has_filter;
-    uint8_t filter_mask, pad1, pad2, pad3;      // has_filter: a doc must be in one of these side lists (a filter that is one leaf)
+    uint8_t filter_mask, f32_mask, pad2, pad3;  // f32_mask: leaf k is a materialised list (LIST_F32: final f32 values); has_filter: a doc must be in one of these side lists (a filter that is one leaf)
     uint8_t grp_mask[4];                        // phrase group g: its side lists (bit s)
     uint8_t tb_side[4];                         // boost_term t: its side list
     uint8_t loc_leaf[2], loc_side[2];           // locality field f: leaves / side lists that are the terms' token->text lists

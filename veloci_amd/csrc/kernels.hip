@@ -1164,7 +1164,7 @@ struct RichShape {
     uint32_t ngroups, root_kind, root_nslots, n_side;
     uint32_t g_kind4, g_mask4, g_nslots4, r_order4, r_slot4;
     uint32_t g_order4[4], g_slot4[4];
-    uint32_t n_grp, n_tb, n_loc, grp_mask4, tb_side4, loc_leaf2, loc_side2, has_filter, filter_mask;
+    uint32_t n_grp, n_tb, n_loc, grp_mask4, tb_side4, loc_leaf2, loc_side2, has_filter, filter_mask, f32_mask;
     const DFacet* facets;
     uint32_t n_facets;
     uint32_t* hist;
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
         R.grp_mult[g] = S2->grp_mult[g];
         R.tb_mult[g] = S2->tb_mult[g];
     }
-    R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc; R.has_filter = S2->has_filter; R.filter_mask = S2->filter_mask;
+    R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc; R.has_filter = S2->has_filter; R.filter_mask = S2->filter_mask; R.f32_mask = S2->f32_mask;
     R.facets = nullptr; R.n_facets = 0; R.hist = nullptr;
     R.grp_mask4 = *reinterpret_cast<const uint32_t*>(S2->grp_mask);
     R.tb_side4 = *reinterpret_cast<const uint32_t*>(S2->tb_side);
@@ -1215,17 +1215,18 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
         for (uint32_t k = 0; k < 4; ++k)
             if (k < n) idx[k] = qidx[k * kQCap + lane];
     }
-    uint16_t raw[4] = {0, 0, 0, 0};
+    uint32_t raw[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (k < n && idx[k] != 0xFFFFFFFFu) {
-            raw[k] = as_global(lf[k].scores)[idx[k]];
+            if ((R.f32_mask >> k) & 1u) raw[k] = as_global(reinterpret_cast<const uint32_t*>(lf[k].scores))[idx[k]];  // uniform: materialised leaf
+            else raw[k] = as_global(lf[k].scores)[idx[k]];
             pm |= 1u << k;
         }
     float val[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
-        if (k < n) val[k] = posting_value(lf[k].ts, raw[k]);
+        if (k < n) val[k] = ((R.f32_mask >> k) & 1u) ? __uint_as_float(raw[k]) : posting_value(lf[k].ts, (uint16_t)raw[k]);
     // groups
     float gv[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t gp = 0;
