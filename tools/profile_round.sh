@@ -2,13 +2,15 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01d
+O=gpurun_out/r01e
 S=/tmp/prof_scratch
 rm -rf $S && mkdir -p $O $S
 python3 bench.py > $O/bench_and.json 2> $O/bench_and.log
 python3 bench.py --workload or --no-cpu --steps 5 > $O/bench_or.json 2> $O/bench_or.log
 python3 bench.py --workload single --no-cpu --steps 5 > $O/bench_single.json 2> $O/bench_single.log
 python3 bench.py --workload config3 --docs 10000000 --no-cpu --steps 5 > $O/bench_config3_10m.json 2> $O/bench_config3.log
+python3 bench.py --workload config3 --docs 100000000 --no-cpu --steps 3 > $O/bench_config3_100m.json 2>> $O/bench_config3.log
+python3 bench.py --workload and_of_ors --docs 100000000 --no-cpu --steps 3 > $O/bench_and_of_ors_100m.json 2>> $O/bench_config3.log
 python3 bench.py --workload mix --docs 100000000 --no-cpu --steps 5 > $O/bench_mix_100m.json 2> $O/bench_mix.log
 python3 bench.py --workload config4 --docs 10000000 --terms 1000000 --no-cpu --steps 3 > $O/bench_config4_10m.json 2> $O/bench_config4.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats -o stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-latency > $O/bench_under_rocprof.json 2> $O/rocprof_stats.log
