@@ -7,6 +7,9 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <thread>
+#include <functional>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -265,8 +268,28 @@ struct Profile {
     uint64_t algorithmic_bytes = 0;
 };
 
+// A few persistent host threads for the per-request work of a batch (query compilation): spawning threads per chunk costs more
+// than compiling a small chunk.
+class HostPool {
+public:
+    explicit HostPool(size_t workers);
+    ~HostPool();
+    void run(size_t parts, const std::function<void(size_t)>& fn);  // fn(0..parts-1), the caller takes part; returns when all are done
+private:
+    void worker();
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t parts_ = 0, next_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 struct Index {
     int device = 0;
+    mutable std::unique_ptr<HostPool> pool;  // created on first use
+    mutable std::mutex pool_mu;
     uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;
     uint32_t bitmap_base = 0;   // doc id of bit 0 of the list bitmaps: doc_lo rounded down to 65536
     uint64_t bitmap_words = 0;  // words of one list bitmap

@@ -31,6 +31,59 @@ void PinnedBuf::ensure(size_t n) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+HostPool::HostPool(size_t workers) {
+    for (size_t i = 0; i < workers; ++i) threads_.emplace_back([this] { worker(); });
+}
+HostPool::~HostPool() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        stop_ = true;
+    }
+    cv_start_.notify_all();
+    for (auto& t : threads_) t.join();
+}
+void HostPool::worker() {
+    uint64_t seen = 0;
+    while (true) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_start_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        while (next_ < parts_) {
+            const size_t part = next_++;
+            lk.unlock();
+            (*fn_)(part);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+}
+void HostPool::run(size_t parts, const std::function<void(size_t)>& fn) {
+    if (parts == 0) return;
+    std::lock_guard<std::mutex> one(run_mu_);
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &fn;
+    parts_ = parts;
+    next_ = 0;
+    pending_ = parts;
+    ++generation_;
+    cv_start_.notify_all();
+    while (next_ < parts_) {  // the caller works too
+        const size_t part = next_++;
+        lk.unlock();
+        fn(part);
+        lk.lock();
+        --pending_;
+    }
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+}
+static HostPool& host_pool(const Index& idx) {
+    std::lock_guard<std::mutex> g(idx.pool_mu);
+    if (!idx.pool) idx.pool = std::make_unique<HostPool>(7);
+    return *idx.pool;
+}
+
 // serialise one compiled query into `dst` (host), whose device address will be `dev`
 static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst, const uint8_t* dev, uint32_t keys_base, uint32_t part_keys_off,
                         const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off, size_t* desc_bytes_out = nullptr) {
@@ -426,12 +479,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             } else pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy);
         }
     };
-    if (n >= 256) {  // query compilation is independent per request: fan out over a few host threads
-        const size_t nt = 4;
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < nt; ++t) th.emplace_back(compile_range, n * t / nt, n * (t + 1) / nt);
-        compile_range(0, n / nt);
-        for (auto& t : th) t.join();
+    if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
+        const size_t parts = std::min<size_t>(8, n / 16);
+        host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
     double t_unions = t_pass1;
