@@ -572,3 +572,45 @@ def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     for req, g in zip(reqs, got):
         assert not isinstance(g, Exception), (str(g), json.dumps(req))
         assert_same(req, g, ora.search_json(json.dumps(req)))
+
+
+def test_concurrent_searches_from_host_threads(corpus):
+    """The reference serves `search` from many rocket worker threads on one Persistence (server/rocket_server.rs:139-145);
+    the index handle must take concurrent vq_search / vq_search_batch calls (ctypes drops the GIL during them)."""
+    import threading
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    a, b, c = meta.triples[0]
+    d, e, f = meta.triples[1]
+    reqs = [synth.req_and([a, b, c]), synth.req_or([a, e]), synth.req_single(meta.extra_probes[1], top=20), synth.req_and_phrase_locality([a, b, c]),
+            synth.req_and_of_ors([a, b], [c, d]), {"search_req": {"search": {"path": "body", "terms": [a[:3]], "starts_with": True}}, "top": 5},
+            dict(synth.req_or([d, e, f], top=15), facets=[{"field": "cat"}]),
+            {"search_req": {"and": {"queries": [{"or": {"queries": [{"search": {"path": "body", "terms": [t]}} for t in (a, d)]}},
+                                                {"or": {"queries": [{"search": {"path": "body", "terms": [t]}} for t in (b, e)]}},
+                                                {"search": {"path": "body", "terms": [c]}}]}}}]
+    want = [ora.search_json(json.dumps(r)) for r in reqs]
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for it in range(40):
+                if it % 3 == 0:
+                    order = [int(x) for x in rng.permutation(len(reqs))]
+                    got = veloci_amd.search_batch([reqs[i] for i in order], idx)
+                    for i, g in zip(order, got):
+                        assert_same(reqs[i], g, want[i], exact_scores=(i != 4))
+                else:
+                    i = int(rng.integers(0, len(reqs)))
+                    assert_same(reqs[i], veloci_amd.search(reqs[i], idx), want[i], exact_scores=(i != 4))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex)[:2000])
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
