@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="and", choices=["and", "or", "single", "config3", "and_of_ors", "mix", "config4"],
+    ap.add_argument("--workload", default="and", choices=["and", "or", "single", "config3", "and_of_ors", "mix", "config4", "or8", "and_of_or4"],
                     help="and = the headline metric; or / single = extra shapes; config3 = AND + 2 phrase pairs + text locality; "
                          "and_of_ors = AND(OR,OR) + Log10 boost + phrase + locality; mix = 40%% and / 40%% or / 20%% and_of_ors (BASELINE configs #3 / #5); "
                          "config4 = lev-2 fuzzy term + facets on cat and tags[] (use --docs 10000000 --terms 1000000)")
@@ -115,6 +115,20 @@ def main():
         qterms = [edit(pool[int(rng.integers(0, len(pool)))]) for _ in range(100)]
         reqs_json = [{"search_req": {"search": {"path": "body", "terms": [qterms[i % len(qterms)]], "levenshtein_distance": 2}}, "top": 10,
                       "facets": [{"field": "cat"}, {"field": "tags[]"}]} for i in range(args.batch)]
+    elif args.workload in ("or8", "and_of_or4"):
+        # shapes of the reference's query generator (one term expanded over several fields, src/query_generator.rs): a flat OR over 8
+        # leaves, and an AND of two 4-leaf ORs
+        def terms8(i):
+            t = []
+            for j in range(3):
+                t += list(meta.triples[(i + j) % len(meta.triples)])
+            return t[:8]
+        leaf = lambda t: {"search": {"path": "body", "terms": [t]}}
+        if args.workload == "or8":
+            reqs_json = [{"search_req": {"or": {"queries": [leaf(t) for t in terms8(i)]}}, "top": 10} for i in range(args.batch)]
+        else:
+            reqs_json = [{"search_req": {"and": {"queries": [{"or": {"queries": [leaf(t) for t in terms8(i)[:4]]}}, {"or": {"queries": [leaf(t) for t in terms8(i)[4:]]}}]}},
+                          "top": 10} for i in range(args.batch)]
     elif args.workload == "single":
         reqs_json = [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(args.batch)]
     else:
@@ -205,7 +219,8 @@ def main():
                                                                               "config3": "3-term AND + 2 phrase pairs + text locality",
                                                                               "and_of_ors": "AND(OR,OR) + Log10 boost + phrase + locality",
                                                                               "mix": "40% AND / 40% OR / 20% AND(OR,OR)+boost+phrase+locality",
-                                                                              "config4": "lev-2 fuzzy term + facets (cat, tags[])"}[args.workload] +
+                                                                              "config4": "lev-2 fuzzy term + facets (cat, tags[])", "or8": "flat OR over 8 terms",
+                                                                              "and_of_or4": "AND of two 4-term ORs"}[args.workload] +
                        f" (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},

@@ -438,6 +438,7 @@ struct Compiler {
                             h.global_len = done->len;
                             h.flags = LIST_HAS_SCORES | LIST_F32;
                             h.term_score = 1.0f;
+                            h.max_value = done->max_value;
                             uint32_t li = add_list(h);
                             info.cover.push_back(li);
                             info.cover_len += h.len;
@@ -850,6 +851,124 @@ struct Compiler {
         }
         cq.n_temps = next_temp;
         if (next_temp > 32) unsupported("presence program needs more than 32 temporary bitmaps");
+    }
+
+    // Top-k pruning table of k_tile_scan.  G(k) = the largest score a doc can have when at most k of the score tree's leaf lists hold it:
+    // every leaf at its list's largest value, a dynamic programme over the tree for the best split of the k lists among the children
+    // (OR: every child its own slot — a sum instead of a max — times (present children)^2; AND: every child present), times the largest
+    // product of the bitmap-driven multipliers (phrase groups, term boosts, locality).  All of it is monotone, so G bounds the score.
+    void compute_prune_table() {
+        static const bool off = std::getenv("VQ_NO_PRUNE") != nullptr;
+        if (off || !count_reqs.empty() || !cq.cols.empty() || !cq.facets.empty() || cq.ops.empty()) return;
+        for (auto& f : cq.locf)
+            if (f.list_count == kLocPrecomputed) return;
+        std::vector<uint32_t> leaf_lists;
+        for (auto& op : cq.ops) {
+            if (op.kind == OP_BOOST1N) return;
+            if (op.kind == OP_LEAF)
+                for (uint32_t j = 0; j < op.list_count; ++j) leaf_lists.push_back(op.list_begin + j);
+        }
+        std::sort(leaf_lists.begin(), leaf_lists.end());
+        if (std::adjacent_find(leaf_lists.begin(), leaf_lists.end()) != leaf_lists.end()) return;  // a list under two leaves would count once but score twice
+        const size_t K = leaf_lists.size();
+        if (K < 2 || K > 15) return;
+        const double NEG = -1.0;  // "cannot be present"
+        struct Node {
+            std::vector<double> ub;  // ub[k], k = 0..K: best score with at most k lists (NEG: not present)
+            size_t need;             // fewest lists that make the node present
+        };
+        auto monotone = [&](Node& n) {
+            for (size_t k = 1; k <= K; ++k) n.ub[k] = std::max(n.ub[k], n.ub[k - 1]);
+        };
+        std::vector<Node> st;
+        for (auto& op : cq.ops) {
+            if (op.kind == OP_LEAF) {
+                Node n{std::vector<double>(K + 1, NEG), 1};
+                double best = NEG;
+                for (uint32_t j = 0; j < op.list_count; ++j) {
+                    const HList& l = cq.lists[op.list_begin + j];
+                    double v;
+                    if (l.flags & LIST_F32) v = l.max_value;
+                    else if (l.max_raw >= 0x7C00 || l.term_score < 0.0f) return;
+                    else {
+                        const uint16_t h = l.max_raw;  // finite non-negative f16
+                        const int e = (h >> 10) & 31, m = h & 1023;
+                        const double a = e ? std::ldexp(1.0 + m / 1024.0, e - 15) : std::ldexp(m / 1024.0, -14);
+                        v = double(l.term_score) * (a / 100.0);
+                    }
+                    if (!(v >= 0.0) || std::isinf(v)) return;
+                    best = std::max(best, v);
+                }
+                if (op.list_count == 0) n.need = K + 1;
+                else
+                    for (size_t k = 1; k <= K; ++k) n.ub[k] = best;
+                st.push_back(std::move(n));
+            } else {
+                const size_t nc = op.nchild;
+                std::vector<Node> ch(st.end() - nc, st.end());
+                st.resize(st.size() - nc);
+                Node n{std::vector<double>(K + 1, NEG), 0};
+                if (op.kind == OP_AND) {
+                    std::vector<double> g(K + 1, NEG);
+                    g[0] = 0.0;
+                    for (auto& c : ch) {
+                        std::vector<double> ng(K + 1, NEG);
+                        for (size_t j = 0; j <= K; ++j)
+                            if (g[j] >= 0.0)
+                                for (size_t kc = std::max<size_t>(c.need, 1); j + kc <= K; ++kc)
+                                    if (c.ub[kc] >= 0.0) ng[j + kc] = std::max(ng[j + kc], g[j] + c.ub[kc]);
+                        g.swap(ng);
+                        n.need += c.need;
+                    }
+                    for (size_t k = 0; k <= K; ++k) n.ub[k] = g[k];
+                } else {  // OR
+                    std::vector<std::vector<double>> f(nc + 1, std::vector<double>(K + 1, NEG));  // f[t][j]: t children present, j lists used
+                    f[0][0] = 0.0;
+                    n.need = K + 1;
+                    for (auto& c : ch) {
+                        auto nf = f;  // child absent
+                        for (size_t t = 0; t < nc; ++t)
+                            for (size_t j = 0; j <= K; ++j)
+                                if (f[t][j] >= 0.0)
+                                    for (size_t kc = std::max<size_t>(c.need, 1); j + kc <= K; ++kc)
+                                        if (c.ub[kc] >= 0.0) nf[t + 1][j + kc] = std::max(nf[t + 1][j + kc], f[t][j] + c.ub[kc]);
+                        f.swap(nf);
+                        n.need = std::min(n.need, c.need);
+                    }
+                    for (size_t t = 1; t <= nc; ++t)
+                        for (size_t j = 0; j <= K; ++j)
+                            if (f[t][j] >= 0.0) n.ub[j] = std::max(n.ub[j], f[t][j] * double(t) * double(t));
+                }
+                monotone(n);
+                st.push_back(std::move(n));
+            }
+        }
+        if (st.size() != 1) return;
+        double mult = 1.00001;  // the kernel's f32 roundings never exceed this margin
+        for (auto& g : cq.groups) {
+            if (g.mult < 0.0f) return;
+            mult *= std::max(1.0, double(g.mult));
+        }
+        for (auto& t : cq.tboosts) {
+            if (t.mult < 0.0f) return;
+            mult *= std::max(1.0, double(t.mult));
+        }
+        if (!cq.locf.empty()) {
+            double cmax = 1;
+            for (auto& f : cq.locf) cmax = std::max(cmax, double(f.list_count));
+            mult *= std::max(1.0, 2.0 * cmax * cmax);
+        }
+        const Node& root = st[0];
+        for (size_t k = 0; k < 16; ++k) {
+            const double g = k <= K ? root.ub[k] : root.ub[K];
+            float gf = g < 0.0 ? 0.0f : float(g * mult);
+            if (double(gf) < g * mult) gf = std::nextafter(gf, std::numeric_limits<float>::infinity());
+            uint32_t bits;
+            std::memcpy(&bits, &gf, 4);
+            cq.prune_gbits[k] = order_f32(bits);
+        }
+        cq.prune_n = uint32_t(K);
+        for (uint32_t li : leaf_lists) cq.prune_mask |= 1ull << li;
     }
 
     // Rich simple queries (DSimple2, k_scan_simple<2, true>): <= 4 single-list posting leaves in a tree of depth <= 2, no filter, no facets,
@@ -1329,6 +1448,7 @@ struct Compiler {
         }
 
         if (!cq.simple_flags) detect_rich_simple();
+        if (!cq.simple_flags) compute_prune_table();
 
         // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
         const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);

@@ -150,7 +150,10 @@ struct QHeader {
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
     uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
     uint32_t off_simple2;    // DSimple2 (simple_flags bit 18)
-    uint32_t pad1;
+    uint32_t prune_n;        // k_tile_scan top-k pruning: != 0: number of lists in prune_mask; a doc present in k of them scores at most
+                             // unorder(prune_gbits[k]) (monotone in k), so docs with too few of them are counted as hits but never scored
+    uint64_t prune_mask;     // the leaf lists of the score tree
+    uint32_t prune_gbits[16];
     uint32_t n_counts;       // != 0: count pre-pass — only the presence program runs, PRES_COUNT counters are added to
                              // counts[part_keys_off + c] (the buffer passed as `num_hits`); nothing is scored
     uint32_t bitmap_base;    // doc id of bit 0 of every list bitmap of this shard (multiple of 65536)

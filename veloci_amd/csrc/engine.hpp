@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdint>
 #include <map>
+#include <limits>
 #include <memory>
 #include <thread>
 #include <functional>
@@ -152,6 +153,7 @@ struct UnionJob {
     // result (valid until the batch that ran it is finished; lives in the batch workspace)
     const uint32_t* d_docs = nullptr;
     const float* d_vals = nullptr;
+    float max_value = std::numeric_limits<float>::infinity();  // largest value of the merged list (read back after the write pass)
     uint32_t len = 0;
     uint64_t input_postings = 0;
 };
@@ -258,7 +260,7 @@ struct Workspace {  // scratch of one in-flight batch
     DevBuf d_partial;
     DevBuf d_hist_sum;
     DevBuf d_down;      // results
-    DevBuf d_union_docs[2], d_union_vals[2], d_union_meta;  // materialised leaves (k_union), level 1 / level 2
+    DevBuf d_union_docs[2], d_union_vals[2], d_union_max, d_union_meta;  // materialised leaves (k_union), level 1 / level 2
 };
 
 struct Profile {
@@ -326,6 +328,7 @@ struct HList {
     uint32_t flags = 0;
     float term_score = 0.f;
     uint16_t max_raw = 0x7C00;  // +inf: no bound known
+    float max_value = std::numeric_limits<float>::infinity();  // LIST_F32 (materialised leaf): its largest value
     uint64_t global_len = 0;
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;
@@ -350,6 +353,9 @@ struct CompiledQuery {
     std::vector<std::vector<uint32_t>> inline_lists;
     std::vector<std::vector<float>> inline_vals;
     std::vector<DColBoost> leaf_cols;  // compile-time staging of the OP_BOOST1N parameters
+    uint32_t prune_n = 0;            // see QHeader::prune_n
+    uint64_t prune_mask = 0;
+    uint32_t prune_gbits[16] = {};
     uint32_t n_top_cols = 0;  // cols[0 .. n_top_cols) are the request-level boosts; the rest belong to OP_BOOST1N ops
     std::vector<DOp> ops, fops;
     std::vector<DPresOp> pres;

@@ -117,6 +117,9 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : 0));
     h.n_temps = cq.n_temps;
     h.n_counts = cq.n_counts;
+    h.prune_n = cq.prune_n;
+    h.prune_mask = cq.prune_mask;
+    std::memcpy(h.prune_gbits, cq.prune_gbits, sizeof h.prune_gbits);
     h.simple_n = cq.simple_n;
     h.bitmap_base = idx.bitmap_base;
     h.simple_flags = cq.simple_flags;
@@ -266,9 +269,10 @@ struct UnionTaskH {
     size_t parent = SIZE_MAX;  // level 1: index of the level-2 task that consumes this output
     uint64_t out_off = 0;
     uint32_t len = 0;
+    float max_value = std::numeric_limits<float>::infinity();
 };
 
-void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals, DevBuf& meta, hipStream_t st) {
+void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals, DevBuf& maxes, DevBuf& meta, hipStream_t st) {
     if (tasks.empty()) return;
     std::vector<UList> ulists;
     std::vector<UTask> utasks;
@@ -304,7 +308,7 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
     auto launch = [&](bool write) {
         launch_union(st, write, uint32_t(n_spans), reinterpret_cast<const UList*>(m + o_lists), reinterpret_cast<const UTask*>(m + o_tasks),
                      reinterpret_cast<const uint32_t*>(m + o_st), reinterpret_cast<uint32_t*>(m + o_cnt), reinterpret_cast<const uint64_t*>(m + o_off),
-                     docs.as<uint32_t>(), vals.as<float>());
+                     docs.as<uint32_t>(), vals.as<float>(), maxes.as<uint32_t>());
         VQ_HIP(hipGetLastError());
     };
     launch(false);
@@ -326,8 +330,19 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
     }
     docs.ensure(cursor * 4 + 64);
     vals.ensure(cursor * 4 + 64);
+    maxes.ensure(tasks.size() * 4 + 64);
+    VQ_HIP(hipMemsetAsync(maxes.p, 0xFF, tasks.size() * 4, st));  // min(~order(value)) per task, written by the write pass
     VQ_HIP(hipMemcpyAsync(m + o_off, off.data(), n_spans * 8, hipMemcpyHostToDevice, st));
     launch(true);
+    // the largest value of every merged list: the compiler's score bounds need it (top-k pruning of the scan)
+    std::vector<uint32_t> mins(tasks.size());
+    VQ_HIP(hipMemcpyAsync(mins.data(), maxes.p, tasks.size() * 4, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    for (size_t t = 0; t < tasks.size(); ++t)
+        if (mins[t] != 0xFFFFFFFFu) {
+            const uint32_t bits = unorder_f32(~mins[t]);
+            std::memcpy(&tasks[t].max_value, &bits, 4);
+        } else tasks[t].max_value = 0.0f;
 }
 }  // namespace
 
@@ -363,13 +378,14 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
             l2.push_back(std::move(top));
         }
     }
-    run_union_level(l1, ws.d_union_docs[0], ws.d_union_vals[0], ws.d_union_meta, st);
+    run_union_level(l1, ws.d_union_docs[0], ws.d_union_vals[0], ws.d_union_max, ws.d_union_meta, st);
     for (auto& t : l1) {
         const uint32_t* d = ws.d_union_docs[0].as<uint32_t>() + t.out_off;
         const float* v = ws.d_union_vals[0].as<float>() + t.out_off;
         if (t.job) {
             t.job->d_docs = d;
             t.job->d_vals = v;
+            t.job->max_value = t.max_value;
             t.job->len = t.len;
         } else {
             UList u{};
@@ -382,9 +398,9 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
         }
     }
     if (!l2.empty()) {
-        VQ_HIP(hipStreamSynchronize(st));  // the level-2 meta upload reuses the level-1 meta buffer
-        run_union_level(l2, ws.d_union_docs[1], ws.d_union_vals[1], ws.d_union_meta, st);
+        run_union_level(l2, ws.d_union_docs[1], ws.d_union_vals[1], ws.d_union_max, ws.d_union_meta, st);  // (level 1 has synchronised)
         for (auto& t : l2) {
+            t.job->max_value = t.max_value;
             t.job->d_docs = ws.d_union_docs[1].as<uint32_t>() + t.out_off;
             t.job->d_vals = ws.d_union_vals[1].as<float>() + t.out_off;
             t.job->len = t.len;

@@ -788,6 +788,56 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         const uint32_t my_excl = wave_excl_scan_u32(surv, &S);
         VQ_STAMP_AT(3)
 
+        uint32_t my_excl2 = my_excl;
+        if (S && !n_counts) {
+            my_hits += surv;  // every doc of the root words is a hit, scored or not
+            // ---- top-k pruning (exact): count, bit-sliced, how many of the score tree's leaf lists hold each doc; a doc in fewer than
+            //      k_min of them cannot reach the threshold (QHeader::prune_gbits) and leaves the root words unscored
+            const uint32_t prune_n = H->prune_n;
+            const uint32_t thr_hi = (uint32_t)(*thr >> 32);
+            if (prune_n && thr_hi) {  // uniform
+                uint32_t k_min = 1;
+                while (k_min <= prune_n && H->prune_gbits[k_min] < thr_hi) ++k_min;
+                if (k_min > 1) {
+                    const unsigned long long pmask = H->prune_mask;
+                    surv = 0;
+                    for (uint32_t k = 0; k < WPL; ++k) {
+                        uint32_t rw = rootw[w0 + k];
+                        if (rw) {
+                            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+                            for (uint32_t i = 0; i < L; ++i) {
+                                if ((pmask >> i) & 1ull) {  // uniform
+                                    const uint32_t x = bm[i * WW + w0 + k];
+                                    const uint32_t c0 = p0 & x;
+                                    p0 ^= x;
+                                    const uint32_t c1 = p1 & c0;
+                                    p1 ^= c0;
+                                    const uint32_t c2 = p2 & c1;
+                                    p2 ^= c1;
+                                    p3 ^= c2;
+                                }
+                            }
+                            uint32_t gt = 0u, eq = ~0u;  // count >= k_min, one bit per doc
+                            {
+                                const uint32_t pl[4] = {p0, p1, p2, p3};
+#pragma unroll
+                                for (int bit = 3; bit >= 0; --bit) {
+                                    if ((k_min >> bit) & 1u) eq &= pl[bit];
+                                    else {
+                                        gt |= eq & pl[bit];
+                                        eq &= ~pl[bit];
+                                    }
+                                }
+                            }
+                            rw = k_min > prune_n ? 0u : (rw & (gt | eq));  // (k_min == prune_n + 1: no doc can reach the threshold)
+                            rootw[w0 + k] = rw;
+                        }
+                        surv += (uint32_t)__popc(rw);
+                    }
+                    my_excl2 = wave_excl_scan_u32(surv, &S);
+                }
+            }
+        }
         if (S && !n_counts) {  // uniform
             // ---- P4: rank support for the score gathers: exclusive prefix popcount per posting list
             for (uint32_t i = 0; i < L; ++i) {
@@ -809,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             const bool compact = S <= kSurvCap;
             uint16_t* surv_list = reinterpret_cast<uint16_t*>(lds + kLdsSurv);
             if (compact) {
-                uint32_t pos = my_excl;
+                uint32_t pos = my_excl2;
                 for (uint32_t k = 0; k < WPL; ++k) {
                     uint32_t r = rootw[w0 + k];
                     while (r) {
@@ -856,7 +906,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
                     const uint32_t doc = tile_lo + (w << 5) + b;
                     float score = sc.simple_n ? tree_score_simple(sc, w, b) : tree_score_generic(sc, w, b);
                     score = sink_stages(sc, score, doc, w, b);
-                    ++my_hits;
                     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
                     if (key > *thr) {
                         uint32_t pos = atomicAdd(cand_n, 1u);
@@ -1917,7 +1966,7 @@ constexpr uint32_t kUnionWindow = 16;
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_union(const UList* __restrict__ ulists, const UTask* __restrict__ tasks, const uint32_t* __restrict__ span_task,
                                               uint32_t* __restrict__ span_cnt, const uint64_t* __restrict__ span_off, uint32_t* __restrict__ out_docs,
-                                              float* __restrict__ out_vals) {
+                                              float* __restrict__ out_vals, uint32_t* __restrict__ task_min) {
     __shared__ unsigned long long win[kUnionWindow][64];
     const uint32_t span = blockIdx.x, lane = threadIdx.x;
     const UTask task = tasks[span_task[span]];
@@ -1961,10 +2010,12 @@ __global__ __launch_bounds__(64) void k_union(const UList* __restrict__ ulists, 
     }
     const uint64_t base = WRITE ? span_off[span] : 0ull;
     uint32_t n = 0;
+    uint32_t best = 0xFFFFFFFFu;  // min of ~order(value) over the emitted docs == the largest value of the merged list
     unsigned long long pending = 0ull;
     while (true) {
         const unsigned long long m = wave_min_u64(head);
         if (m == ~0ull) break;
+        if (WRITE) best = (uint32_t)m < best ? (uint32_t)m : best;
         if (WRITE) {
             if ((n & 63u) == lane) pending = m;
             if ((n & 63u) == 63u) {
@@ -1988,6 +2039,7 @@ __global__ __launch_bounds__(64) void k_union(const UList* __restrict__ ulists, 
             out_docs[base + done + lane] = (uint32_t)(pending >> 32);
             out_vals[base + done + lane] = __uint_as_float(unorder_f32(~(uint32_t)pending));
         }
+        if (lane == 0 && best != 0xFFFFFFFFu) atomicMin(&task_min[span_task[span]], best);
         if (s + 1 == task.n_spans && lane < 8u) {  // list padding: sentinel docs up to the vector width and beyond
             out_docs[base + n + lane] = 0xFFFFFFFFu;
             out_vals[base + n + lane] = 0.0f;
@@ -1998,10 +2050,10 @@ __global__ __launch_bounds__(64) void k_union(const UList* __restrict__ ulists, 
 }
 
 void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList* ulists, const UTask* tasks, const uint32_t* span_task, uint32_t* span_cnt,
-                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals) {
+                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals, uint32_t* task_min) {
     if (!total_spans) return;
-    if (write) hipLaunchKernelGGL(k_union<true>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals);
-    else hipLaunchKernelGGL(k_union<false>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals);
+    if (write) hipLaunchKernelGGL(k_union<true>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals, task_min);
+    else hipLaunchKernelGGL(k_union<false>, dim3(total_spans), dim3(64), 0, st, ulists, tasks, span_task, span_cnt, span_off, out_docs, out_vals, task_min);
 }
 
 }  // namespace vq

@@ -52,7 +52,7 @@ void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, 
                          uint32_t* out_n);
 
 void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList* ulists, const UTask* tasks, const uint32_t* span_task, uint32_t* span_cnt,
-                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals);
+                  const uint64_t* span_off, uint32_t* out_docs, float* out_vals, uint32_t* task_min);
 void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
                        uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
 void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t n_probes, uint32_t max_terms);
