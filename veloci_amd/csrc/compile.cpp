@@ -1449,6 +1449,15 @@ struct Compiler {
 
         if (!cq.simple_flags) detect_rich_simple();
         if (!cq.simple_flags) compute_prune_table();
+        if (!cq.simple_flags && count_reqs.empty()) {  // k_tile_scan: a dense cover list means every tile gets visited anyway: walk them in order
+            bool dense_cover = false;                   // and read the dense lists as bitmap images instead of scattering them
+            for (auto& l : cq.lists) dense_cover = dense_cover || ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP));
+            if (dense_cover) {
+                cq.seq_tiles = 1;
+                for (auto& l : cq.lists)
+                    if (l.flags & LIST_BITMAP) l.flags &= ~uint32_t(LIST_COVER);
+            }
+        }
 
         // ---- tiling: tile width from the LDS budget and the cover density; spans from the work volume
         const uint32_t L = std::max<uint32_t>(uint32_t(cq.lists.size()), 1);

@@ -153,6 +153,9 @@ struct QHeader {
     uint32_t prune_n;        // k_tile_scan top-k pruning: != 0: number of lists in prune_mask; a doc present in k of them scores at most
                              // unorder(prune_gbits[k]) (monotone in k), so docs with too few of them are counted as hits but never scored
     uint64_t prune_mask;     // the leaf lists of the score tree
+    uint32_t seq_tiles;      // k_tile_scan: a dense list is in the cover -> every tile of the span is visited, dense lists are copied from
+                             // their bitmap images (their LIST_COVER flag is dropped)
+    uint32_t pad2;
     uint32_t prune_gbits[16];
     uint32_t n_counts;       // != 0: count pre-pass — only the presence program runs, PRES_COUNT counters are added to
                              // counts[part_keys_off + c] (the buffer passed as `num_hits`); nothing is scored

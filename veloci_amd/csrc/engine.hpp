@@ -353,6 +353,7 @@ struct CompiledQuery {
     std::vector<std::vector<uint32_t>> inline_lists;
     std::vector<std::vector<float>> inline_vals;
     std::vector<DColBoost> leaf_cols;  // compile-time staging of the OP_BOOST1N parameters
+    uint32_t seq_tiles = 0;          // see QHeader::seq_tiles
     uint32_t prune_n = 0;            // see QHeader::prune_n
     uint64_t prune_mask = 0;
     uint32_t prune_gbits[16] = {};

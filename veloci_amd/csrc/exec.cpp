@@ -118,6 +118,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.n_temps = cq.n_temps;
     h.n_counts = cq.n_counts;
     h.prune_n = cq.prune_n;
+    h.seq_tiles = cq.seq_tiles;
     h.prune_mask = cq.prune_mask;
     std::memcpy(h.prune_gbits, cq.prune_gbits, sizeof h.prune_gbits);
     h.simple_n = cq.simple_n;

@@ -570,14 +570,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     for (uint32_t c = tid; c < n_counts; c += kBlock) reinterpret_cast<uint32_t*>(cand)[c] = 0u;  // the candidate area holds the counters
     uint32_t my_hits = 0;
     uint32_t par = 0;  // parity of the cursor buffers
+    const bool seq_tiles = H->seq_tiles != 0u;
+    uint32_t seq_pos = span_lo;
     __syncthreads();
     VQ_STAMP_AT(0)
 
     while (true) {
         uint32_t* cur = cur2 + par * kMaxLists;
         uint32_t* nxt = nxt2 + par * kMaxLists;
-        // ---- P0: next tile = the tile holding the smallest pending doc of the cover lists (LDS only)
+        // ---- P0: next tile = the tile holding the smallest pending doc of the cover lists (LDS only), or simply the next one
         uint32_t head = 0xFFFFFFFFu;
+        if (seq_tiles) head = seq_pos;
+        else
         for (uint32_t i = 0; i < L; ++i) {
             if (lists[i].flags & LIST_COVER) {
                 const uint32_t d = nxt[i];
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         const uint32_t tile_end = tile_lo + W;  // may wrap to 0 at the top of the id space
         const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
         const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;  // entries below it are not this tile's
+        seq_pos = tile_end > tile_lo ? tile_end : 0xFFFFFFFFu;
 
         // ---- P0b: a list outside the cover that is more than a tile behind skips ahead with a wave-wide search
         for (uint32_t i = wave; i < L; i += kBlock / 64) {
