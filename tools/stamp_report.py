@@ -6,13 +6,15 @@ import veloci_amd
 from veloci_amd import synth
 docs = int(os.environ.get("DOCS", "100000000")); tri = int(os.environ.get("TRIPLES", "8"))
 kind = os.environ.get("KIND", "and")  # and | config3 | and_of_ors
-rich = kind != "and"
+rich = kind in ("config3", "and_of_ors")
 spec = synth.SynthSpec(num_docs=docs, num_terms=10000, triples=tri, with_t2t=rich, with_facets=False, with_boost=rich, with_phrase=rich)
 data, meta = synth.generate(spec)
 idx = veloci_amd.Index(data)
 T = lambda i: list(meta.triples[i % tri])
 mk = {"and": lambda i: synth.req_and(T(i)), "config3": lambda i: synth.req_and_phrase_locality(T(i)),
-      "and_of_ors": lambda i: synth.req_and_of_ors(T(i)[:2], [T(i)[2], T(i + 1)[2]])}[kind]
+      "and_of_ors": lambda i: synth.req_and_of_ors(T(i)[:2], [T(i)[2], T(i + 1)[2]]),
+      "or8": lambda i: synth.req_or((T(i) + T(i + 1) + T(i + 2))[:8]),
+      "and_of_or4": lambda i: {"search_req": {"and": {"queries": [synth.req_or((T(i) + T(i + 1))[:4])["search_req"], synth.req_or((T(i + 1) + T(i + 2))[1:5])["search_req"]]}}, "top": 10}}[kind]
 reqs = [veloci_amd.Request(mk(i)) for i in range(int(os.environ.get("BATCH", "256")))]
 L = veloci_amd.lib()
 buf = (C.c_ulonglong * 16)()

@@ -153,6 +153,8 @@ struct QHeader {
     uint32_t prune_n;        // k_tile_scan top-k pruning: != 0: number of lists in prune_mask; a doc present in k of them scores at most
                              // unorder(prune_gbits[k]) (monotone in k), so docs with too few of them are counted as hits but never scored
     uint64_t prune_mask;     // the leaf lists of the score tree
+    unsigned long long gthr; // written by the kernels: the best top-k threshold any span of this query has reached so far (atomicMax);
+                             // every span may drop docs below it — some span alone already holds top_k better ones
     uint32_t seq_tiles;      // k_tile_scan: a dense list is in the cover -> every tile of the span is visited, dense lists are copied from
                              // their bitmap images (their LIST_COVER flag is dropped)
     uint32_t pad2;

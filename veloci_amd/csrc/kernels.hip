@@ -100,6 +100,7 @@ struct CandState {
     uint32_t* n;               // pushes so far (may exceed cap)
     unsigned long long* thr;   // keys <= thr cannot enter the top-k any more
     uint32_t cap;              // power of two, >= 2 * k
+    unsigned long long* gthr = nullptr;  // the query's threshold word in HBM, shared by all of its spans (QHeader::gthr)
 };
 
 // All threads of the workgroup call this together.  Without `force` a buffer that already holds <= k keys
@@ -136,7 +137,14 @@ __device__ void cand_prune(const CandState& cs, uint32_t k, bool force = false) 
     }
     if (threadIdx.x == 0) {
         *cs.n = n < k ? n : k;
-        if (n >= k && k > 0) *cs.thr = cs.cand[k - 1];
+        if (n >= k && k > 0) {
+            unsigned long long t = cs.cand[k - 1];
+            if (cs.gthr) {  // publish, and adopt what another span of the query has reached
+                const unsigned long long other = atomicMax(cs.gthr, t);
+                t = other > t ? other : t;
+            }
+            *cs.thr = t;
+        }
     }
     __syncthreads();
 }
@@ -538,7 +546,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     uint32_t* rootw = lds + kLdsDesc + desc_cap / 4 + 2 * cand_cap + stack_depth * kBlock;
     uint32_t* bm = rootw + WW;
     uint16_t* pre = reinterpret_cast<uint16_t*>(bm + (L + H->n_temps) * WW);
-    CandState cs{cand, cand_n, thr, cand_cap};
+    CandState cs{cand, cand_n, thr, cand_cap,
+                 reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blobs) + blob_off[q] + offsetof(QHeader, gthr))};
+    uint32_t tiles_done = 0;
 
     // ---- span of the doc-id space owned by this workgroup
     const uint32_t n_spans = H->n_spans;
@@ -610,6 +620,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             cnt_lo[tid] = 0u;
             cnt_hi[tid] = 0u;
             nxt_new[tid] = 0xFFFFFFFFu;
+        }
+        if ((tiles_done++ & 3u) == 0u && tid == 0) {  // at the start and now and then: adopt the threshold other spans of the query have published
+            const unsigned long long g = *reinterpret_cast<volatile unsigned long long*>(cs.gthr);
+            if (g > *thr) *thr = g;
         }
         __syncthreads();
         VQ_STAMP_AT(1)
@@ -1508,7 +1522,8 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     uint32_t bslot[4];                                // LDS tile of list k
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) bslot[k] = (uint32_t)__popc(~sflags & ((1u << k) - 1u) & 0xFu) * SWW;
-    CandState cs{cand, cand_n, thr, cand_cap};
+    CandState cs{cand, cand_n, thr, cand_cap, reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr))};
+    uint32_t tiles_done = 0;
 
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
@@ -1621,6 +1636,11 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         for (uint32_t k = 0; k < 4; ++k)
             if (k < n && !((sflags >> k) & 1u))
                 base_idx[k] = simple_scatter_list(lf[k].docs, lf[k].len, cur[k], nxt[k], bml + bslot[k], wk[k][0], (sflags >> (20 + k)) & 1u, tile_lo, tile_hi, lo_bound);
+        if (kind != OP_AND && (tiles_done++ & 3u) == 0u && lane == 0) {  // (an AND has few survivors: nothing to prune) adopt the threshold other
+                                                                          // spans of the query have published (QHeader::gthr)
+            const unsigned long long g = *reinterpret_cast<volatile unsigned long long*>(cs.gthr);
+            if (g > *thr) *thr = g;
+        }
         __syncthreads();  // one wave: LDS atomics above are ordered before the reads below
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
