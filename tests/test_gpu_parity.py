@@ -1,6 +1,7 @@
 """GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded synthetic corpora.
 Doc-id lists bit-exact; f32 scores bit-exact wherever only + * / are involved, 1e-5 relative for log boosts."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -474,7 +475,7 @@ def test_random_requests_on_reference_corpus_match_the_oracle():
     idx = veloci_amd.Index(data, device=0)
     ora = O.OracleIndex(data.num_anchors)
     data.load_into(ora)
-    rng = np.random.default_rng(20241003)
+    rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "20241003")))
     ran = declined = 0
     for i in range(600):
         req = _random_request(rng, info)
@@ -508,7 +509,7 @@ def test_random_requests_in_batches_match_the_oracle():
     idx = veloci_amd.Index(data, device=0)
     ora = O.OracleIndex(data.num_anchors)
     data.load_into(ora)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "77")))
     for _ in range(4):
         reqs = [_random_request(rng, info) for _ in range(300)]
         got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
@@ -526,12 +527,34 @@ def test_random_requests_in_batches_match_the_oracle():
             assert_same(req, g, want, exact_scores=exact)
 
 
+@pytest.fixture(scope="module")
+def big_corpus():
+    import veloci_amd
+    from veloci_amd import synth
+    from oracle import binding as O
+    spec = synth.SynthSpec(num_docs=4_000_000, num_terms=3000, triples=3, extra_probe_dfs=(5000, 400_000), background_terms=30)
+    data, meta = synth.generate(spec)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    return data, meta, idx, ora
+
+
+def test_random_requests_on_a_4m_doc_corpus_match_the_oracle(big_corpus):
+    """The same generator on 4 M docs: many spans per query, sequential tiles, the shared threshold word, pruning tables."""
+    _random_synthetic(big_corpus, n_requests=70, seed=int(os.environ.get("VQ_TEST_SEED", "4004")))
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
+    _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))
+
+
+def _random_synthetic(corpus, n_requests, seed):
     import veloci_amd
     from parity import assert_same
     data, meta, idx, ora = corpus
-    rng = np.random.default_rng(991)
+    rng = np.random.default_rng(seed)
     pool = [t for tri in meta.triples for t in tri] + list(meta.extra_probes) + list(meta.background[:25])
 
     def leaf():
@@ -552,7 +575,7 @@ def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
         return {("and" if rng.random() < 0.5 else "or"): {"queries": [tree(d + 1) for _ in range(int(rng.integers(2, 5)))]}}
 
     reqs = []
-    for _ in range(240):
+    for _ in range(n_requests):
         req = {"search_req": tree(0), "top": int(rng.choice([1, 10, 40]))}
         if rng.random() < 0.25:
             req["filter"] = tree(1)
