@@ -125,6 +125,12 @@ void vq_index_free(vq_index*);
 /* Run this index's launches on an existing HIP stream (hipStream_t as void*);
  * NULL restores the index's own stream. */
 int vq_index_set_stream(vq_index*, void* hip_stream);
+/* Sharded deployments: a few requests need numbers that are sums over all shards before they can be compiled (result sizes of AND
+ * operands, lengths of merged leaf lists — set_op.rs:388-393 orders an AND's score sum by them).  `fn(ctx, values, n)` must replace
+ * values[0..n) by their sums over all ranks (an all-reduce; every rank calls it with the same n, in the same order) and return 0.
+ * Without it a shard declines such requests with VQ_ERR_UNSUPPORTED.  Called from inside vq_search_batch_partial. */
+typedef int (*vq_allreduce_u64_fn)(void* ctx, uint64_t* values, size_t n);
+int vq_index_set_allreduce(vq_index*, vq_allreduce_u64_fn fn, void* ctx);
 /* Bytes of HBM held by the staged image. */
 uint64_t vq_index_device_bytes(const vq_index*);
 

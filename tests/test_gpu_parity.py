@@ -550,7 +550,13 @@ def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))
 
 
-def _random_synthetic(corpus, n_requests, seed):
+def test_random_requests_over_three_shards_match_the_oracle(corpus):
+    """The same generator, the index cut into three doc-range shards on one GPU, partials gathered and merged.
+    Result sizes and merged list lengths are summed over the shards through the vq_index_set_allreduce hook."""
+    _random_synthetic(corpus, n_requests=160, seed=int(os.environ.get("VQ_TEST_SEED", "3003")), shards=3)
+
+
+def _random_synthetic(corpus, n_requests, seed, shards=1):
     import veloci_amd
     from parity import assert_same
     data, meta, idx, ora = corpus
@@ -591,10 +597,62 @@ def _random_synthetic(corpus, n_requests, seed):
         if rng.random() < 0.2:
             req["boost_term"] = [{"path": "body", "terms": [meta.background[int(rng.integers(0, 30))]], "boost": 3.0}]
         reqs.append(req)
-    got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
+    if shards == 1:
+        got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
+    else:
+        import torch
+        from veloci_amd.dist import device_view
+        N = data.num_anchors
+        cuts = [N * i // shards for i in range(shards + 1)]
+        parts = [veloci_amd.Index(data, device=0, doc_lo=cuts[i], doc_hi=cuts[i + 1]) for i in range(shards)]
+        # the shards run in threads and sum the few numbers some requests need over all shards (vq_index_set_allreduce)
+        import threading
+        barrier = threading.Barrier(shards)
+        slots = [None] * shards
+        totals = [None]
+
+        def make_hook(rank):
+            def hook(values):
+                slots[rank] = values.copy()
+                barrier.wait()
+                if rank == 0:
+                    totals[0] = np.sum(np.stack(slots), axis=0, dtype=np.uint64)
+                barrier.wait()
+                values[:] = totals[0]
+                barrier.wait()
+            return hook
+
+        pbs = [None] * shards
+        errs = []
+
+        def run(rank):
+            try:
+                parts[rank].set_allreduce(make_hook(rank))
+                pbs[rank] = veloci_amd.PartialBatch(parts[rank], reqs)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(shards)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        assert len({pb.nbytes for pb in pbs}) == 1
+        g = torch.cat([device_view(pb.device_ptr, pb.nbytes).clone() for pb in pbs])
+        torch.cuda.synchronize()
+        got = pbs[0].merge(g.data_ptr(), shards, raise_on_error=False)
+        for pb in pbs[1:]:
+            pb.merge(None, 1, raise_on_error=False)
+    declined = 0
     for req, g in zip(reqs, got):
+        if shards > 1 and isinstance(g, veloci_amd.VelociError) and g.kind == "Unsupported":
+            declined += 1
+            continue
         assert not isinstance(g, Exception), (str(g), json.dumps(req))
         assert_same(req, g, ora.search_json(json.dumps(req)))
+    assert declined == 0, declined
 
 
 def test_concurrent_searches_from_host_threads(corpus):

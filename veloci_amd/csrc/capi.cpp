@@ -173,6 +173,14 @@ int vq_index_set_stream(vq_index* i, void* hip_stream) {
         i->idx->fin_stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_fin_stream;
     });
 }
+int vq_index_set_allreduce(vq_index* i, vq_allreduce_u64_fn fn, void* ctx) {
+    return guard([&] {
+        if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_allreduce: null index");
+        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
+        i->idx->allreduce_fn = fn;
+        i->idx->allreduce_ctx = ctx;
+    });
+}
 uint64_t vq_index_device_bytes(const vq_index* i) { return i ? i->idx->device_bytes : 0; }
 
 // ------------------------------------------------------------------ requests

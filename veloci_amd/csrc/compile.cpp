@@ -405,16 +405,16 @@ struct Compiler {
                 const PostingStore& ps = posting_store(l.path);
                 uint32_t count = 0;
                 uint32_t with_entries = 0;
-                size_t nonempty = 0;
+                size_t nonempty = 0;  // lists with entries anywhere: every shard must take the same decision (the pre-passes are collective)
                 for (auto& [tid, score] : l.hits_scores)
-                    if (tid < ps.num_tokens && ps.len[tid]) ++nonempty;
+                    if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
                 if (nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req))) {
                     // K2: the leaf's hits are materialised once per batch (union, max per doc) and scanned as one list
                     UnionJob job;
                     job.store_path = l.path + TO_ANCHOR_ID_SCORE;
                     key_s(job.key, job.store_path);
                     for (auto& [tid, score] : l.hits_scores)
-                        if (tid < ps.num_tokens && ps.len[tid]) {
+                        if (tid < ps.num_tokens && ps.global_len[tid]) {
                             job.terms.push_back({tid, score});
                             job.key += std::to_string(tid) + ":";
                             key_f(job.key, score);
@@ -435,7 +435,7 @@ struct Compiler {
                             h.d_docs = done->d_docs;
                             h.d_scores = reinterpret_cast<const uint16_t*>(done->d_vals);
                             h.len = done->len;
-                            h.global_len = done->len;
+                            h.global_len = done->global_len;
                             h.flags = LIST_HAS_SCORES | LIST_F32;
                             h.term_score = 1.0f;
                             h.max_value = done->max_value;
@@ -445,9 +445,9 @@ struct Compiler {
                             count = 1;
                         }
                         cq.algorithmic_bytes += 6ull * done->input_postings + 8ull * done->len;
-                        info.glen = done->len;
+                        info.glen = done->global_len;
                         // the merged length is this shard's only: known globally when the index is not sharded
-                        info.len_known = !req.filter && idx.doc_lo == 0 && idx.doc_hi == idx.num_anchors;
+                        info.len_known = !req.filter && idx.can_sum_over_shards();
                     }
                     op.list_count = uint16_t(count);
                     push_op(ops, op, sp);
@@ -702,8 +702,8 @@ struct Compiler {
                 // (two operands: the sum of two floats does not depend on the order; only the label does, and an OR that needs it says so)
                 if (counts && n > 2) unsupported("AND whose operand sizes are still unknown after the count pre-pass (internal)");
                 if (!counts) {
-                    if (n > 2 && (idx.doc_lo != 0 || idx.doc_hi != idx.num_anchors))
-                        unsupported("AND of 3+ operands whose result sizes are only known at run time, on a sharded index (sizes are per shard)");
+                    if (n > 2 && !idx.can_sum_over_shards())
+                        unsupported("AND of 3+ operands whose result sizes are only known at run time, on a sharded index without vq_index_set_allreduce");
                     auto& dst = n > 2 ? count_reqs : maybe_reqs;
                     for (auto& c : ch)
                         if (!c.len_known) dst.push_back({c.node_id, c.root_op});
@@ -1391,8 +1391,8 @@ struct Compiler {
 
         if (label_wanted) {  // some OR needs the label of a nested AND: that takes the sizes of the two-operand ANDs as well
             if (maybe_reqs.empty() && count_reqs.empty()) unsupported("OR over an operand whose term label is only known at run time (set_op.rs:143,439)");
-            if (idx.doc_lo != 0 || idx.doc_hi != idx.num_anchors)
-                unsupported("OR over an AND whose label follows run-time result sizes, on a sharded index (sizes are per shard)");
+            if (!idx.can_sum_over_shards())
+                unsupported("OR over an AND whose label follows run-time result sizes, on a sharded index without vq_index_set_allreduce");
             count_reqs.insert(count_reqs.end(), maybe_reqs.begin(), maybe_reqs.end());
         }
         if (2 * count_reqs.size() + 1 > 256) unsupported("more than 127 AND operands whose sizes must be measured first");

@@ -155,6 +155,7 @@ struct UnionJob {
     const float* d_vals = nullptr;
     float max_value = std::numeric_limits<float>::infinity();  // largest value of the merged list (read back after the write pass)
     uint32_t len = 0;
+    uint64_t global_len = 0;  // merged length over all shards
     uint64_t input_postings = 0;
 };
 using UnionTable = std::map<std::string, UnionJob>;
@@ -290,6 +291,15 @@ private:
 
 struct Index {
     int device = 0;
+    // sums over all shards (vq_index_set_allreduce); null: requests that need them are declined on a sharded index
+    int (*allreduce_fn)(void*, uint64_t*, size_t) = nullptr;
+    void* allreduce_ctx = nullptr;
+    bool sharded() const { return doc_lo != 0 || doc_hi != num_anchors; }
+    bool can_sum_over_shards() const { return !sharded() || allreduce_fn != nullptr; }
+    void sum_over_shards(std::vector<uint64_t>& v) const {
+        if (!sharded() || v.empty()) return;
+        if (!allreduce_fn || allreduce_fn(allreduce_ctx, v.data(), v.size()) != 0) throw vqreq::VelociError(vqreq::ERR_DEVICE, "all-reduce over the shards failed");
+    }
     mutable std::unique_ptr<HostPool> pool;  // created on first use
     mutable std::mutex pool_mu;
     uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;

@@ -512,6 +512,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     if (!again.empty()) {
         run_union_jobs(idx, ws, unions, st);
+        {  // merged lengths over all shards (the AND summation order follows them)
+            std::vector<uint64_t> lens;
+            for (auto& kv : unions) lens.push_back(kv.second.len);
+            if (idx.can_sum_over_shards()) idx.sum_over_shards(lens);
+            size_t k = 0;
+            for (auto& kv : unions) kv.second.global_len = lens[k++];
+        }
         t_unions = now_ms();
         auto recompile = [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
@@ -543,6 +550,25 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         if (!need.empty()) {
             std::vector<QueryCounts> counts;
             run_count_queries(idx, ws, cqs, counts, st);
+            if (idx.sharded()) {  // result sizes are sums over the shards
+                std::vector<uint64_t> flat;
+                for (auto& c : counts) {
+                    flat.push_back(c.filter_count);
+                    for (auto& kv : c.nodes) {
+                        flat.push_back(kv.second.first);
+                        flat.push_back(kv.second.second);
+                    }
+                }
+                idx.sum_over_shards(flat);
+                size_t k = 0;
+                for (auto& c : counts) {
+                    c.filter_count = flat[k++];
+                    for (auto& kv : c.nodes) {
+                        kv.second.first = flat[k++];
+                        kv.second.second = flat[k++];
+                    }
+                }
+            }
             for (size_t k = 0; k < need.size(); ++k) {
                 CompiledQuery& q = pb->queries[need[k]];
                 q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k]);

@@ -72,6 +72,18 @@ class ShardedSearcher:
             # "use the index's own streams".)
             self.stream = torch.cuda.Stream()
             index.set_stream(self.stream.cuda_stream)
+        if self.world > 1:
+            index.set_allreduce(self._sum_over_ranks)
+
+    def _sum_over_ranks(self, values):
+        """vq_index_set_allreduce hook: result sizes / merged list lengths summed over the shards (a few u64 per request that needs
+        them; every rank calls it with the same shape in the same order because the requests are the same)."""
+        import torch.distributed as dist
+        t = torch.from_numpy(values.astype(np.int64))
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        values[:] = t.cpu().numpy().astype(np.uint64)
 
     def _gather(self, pb):
         if self.stream is not None:

@@ -157,6 +157,24 @@ class Index:
     def set_stream(self, hip_stream):
         _lib.check(self.L.vq_index_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
 
+    def set_allreduce(self, fn):
+        """fn(numpy uint64 array) must sum the array over all shards in place (vq_index_set_allreduce); None removes it."""
+        if fn is None:
+            self._allreduce_cb = None
+            _lib.check(self.L.vq_index_set_allreduce(self.h, None, None))
+            return
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)
+
+        def trampoline(_ctx, values, n):
+            try:
+                fn(np.ctypeslib.as_array(values, shape=(n,)))
+                return 0
+            except Exception:  # noqa: BLE001 - reported as VQ_ERR_DEVICE by the library
+                return 1
+
+        self._allreduce_cb = proto(trampoline)  # keep the callback alive
+        _lib.check(self.L.vq_index_set_allreduce(self.h, C.cast(self._allreduce_cb, C.c_void_p), None))
+
     @property
     def device_bytes(self):
         return int(self.L.vq_index_device_bytes(self.h))
