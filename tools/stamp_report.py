@@ -28,3 +28,4 @@ tot = sum(v[k] for k in names)
 for k, n in names.items():
     print(f"{n:26s} {v[k]/tot*100:6.2f}%   {v[k]/max(v[7],1):10.1f} ticks/tile")
 print("tiles", v[7], "wgs", v[8], "ticks/tile total", tot / max(v[7], 1))
+print("hits/tile", v[11] / max(v[7], 1), "scored/tile", v[12] / max(v[7], 1))

@@ -808,6 +808,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
         VQ_STAMP_AT(3)
 
         uint32_t my_excl2 = my_excl;
+#ifdef VQ_STAMP
+        _acc[11] += S;  // hits of the tile
+#endif
         if (S && !n_counts) {
             my_hits += surv;  // every doc of the root words is a hit, scored or not
             // ---- top-k pruning (exact): count, bit-sliced, how many of the score tree's leaf lists hold each doc; a doc in fewer than
@@ -857,6 +860,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
                 }
             }
         }
+#ifdef VQ_STAMP
+        _acc[12] += S;  // docs that survive the pruning (scored)
+#endif
         if (S && !n_counts) {  // uniform
             // ---- P4: rank support for the score gathers: exclusive prefix popcount per posting list
             for (uint32_t i = 0; i < L; ++i) {
