@@ -545,6 +545,24 @@ def test_random_requests_on_a_4m_doc_corpus_match_the_oracle(big_corpus):
     _random_synthetic(big_corpus, n_requests=70, seed=int(os.environ.get("VQ_TEST_SEED", "4004")))
 
 
+def test_single_requests_split_into_many_spans_merge_exactly(big_corpus):
+    """A batch of one is split into many more spans than a full batch (latency path): the span merge's bound filter (top <= 64) and
+    its general rounds (top > 64), AND / OR / single leaf, against the oracle."""
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    data, meta, idx, ora = big_corpus
+    t = list(meta.triples[0])
+    for top in (1, 10, 64, 65, 300):
+        for skip in (0, 7):
+            for req in (synth.req_and(t, top=top), synth.req_or(t, top=top), synth.req_single(t[0], top=top),
+                        synth.req_and_of_ors([t[0], t[1]], [t[2], meta.triples[1][0]], top=top)):
+                req = dict(req, skip=skip)
+                got = veloci_amd.search(req, idx)
+                want = ora.search_json(json.dumps(req))
+                assert_same(req, got, want, exact_scores="boost" not in req)  # (Log10: device log vs glibc, 1e-5)
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))

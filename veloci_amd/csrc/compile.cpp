@@ -1506,6 +1506,7 @@ struct Compiler {
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);
         cq.n_spans = uint32_t(spans);
+        cq.max_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 4096));
     }
 };
 

@@ -386,6 +386,7 @@ struct CompiledQuery {
     uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
     uint64_t algorithmic_bytes = 0;
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
+    uint32_t max_spans = 1;  // tiles of the query's doc range (<= 4096): a small batch splits its queries further, up to this (exec.cpp)
 };
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr,

@@ -591,6 +591,23 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     std::vector<FacetJob> jobs;
     uint32_t fac_out_total = 0;
     uint64_t algo_bytes = 0;
+    {   // a small batch (one query = the latency case) would leave most of the chip idle with spans sized for streaming efficiency:
+        // split its queries further until the launch holds about one wave per SIMD of every CU
+        static const uint64_t target = [] {
+            const char* e = std::getenv("VQ_SPAN_TARGET");
+            return uint64_t(e ? std::atoll(e) : 2048);
+        }();
+        uint64_t have = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (pb->queries[i].status == 0) have += pb->queries[i].n_spans;
+        if (have && have * 2 <= target) {
+            const uint64_t f = target / have;
+            for (size_t i = 0; i < n; ++i) {
+                CompiledQuery& cq = pb->queries[i];
+                if (cq.status == 0) cq.n_spans = uint32_t(std::max<uint64_t>(cq.n_spans, std::min<uint64_t>(uint64_t(cq.n_spans) * f, cq.max_spans)));
+            }
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         CompiledQuery& cq = pb->queries[i];
         if (cq.status != 0) continue;

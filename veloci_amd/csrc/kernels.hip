@@ -103,6 +103,11 @@ struct CandState {
     unsigned long long* gthr = nullptr;  // the query's threshold word in HBM, shared by all of its spans (QHeader::gthr)
 };
 
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, uint32_t src_lane) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // All threads of the workgroup call this together.  Without `force` a buffer that already holds <= k keys
 // is left as it is (the caller only needs the SET of the best k); with `force` the keys end up sorted
 // descending.  On return *cs.n <= k.
@@ -123,7 +128,7 @@ __device__ void cand_prune(const CandState& cs, uint32_t k, bool force = false) 
     for (uint32_t size = 2; size <= m; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             for (uint32_t t = threadIdx.x; t < (m >> 1); t += kBlock) {
-                uint32_t i = ((t / stride) * stride << 1) + (t % stride);
+                uint32_t i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u));  // (stride is a power of two)
                 uint32_t j = i + stride;
                 bool desc = (i & size) == 0;
                 unsigned long long a = cs.cand[i], b = cs.cand[j];
@@ -974,33 +979,95 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ merges
-__global__ __launch_bounds__(kBlock) void k_merge_spans(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                        const unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ part_keys) {
+constexpr uint32_t kMergeThreads = 1024;
+__global__ __launch_bounds__(kMergeThreads) void k_merge_spans(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                               const unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ part_keys) {
     __shared__ unsigned long long cand[kCandCap];
+    __shared__ unsigned long long lane_max[kBlock];
     __shared__ uint32_t misc[4];
+    __shared__ uint32_t fill[2];  // [0] keys kept so far, [1] overflow flag
     const QHeader* H = reinterpret_cast<const QHeader*>(blobs + blob_off[blockIdx.x]);
     const uint32_t top_k = H->top_k;
     const unsigned long long* src = span_keys + H->keys_base;
     CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
-    if (threadIdx.x == 0) {
-        *cs.thr = 0ull;
-        *cs.n = 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t total = H->n_spans * top_k;
+    bool rounds = true;  // uniform
+    if (top_k >= 1u && top_k <= (uint32_t)kBlock && total > 4u * (uint32_t)kBlock) {
+        // few keys wanted out of many: the top_k-th largest of 64 maxima over disjoint subsets is a lower bound of the answer's smallest
+        // key (at least top_k keys reach it), so a second pass that keeps only the keys at or above it leaves a handful to sort
+        if (tid < (uint32_t)kBlock) lane_max[tid] = 0ull;
+        if (tid == 0) fill[0] = fill[1] = 0u;
+        __syncthreads();
+        unsigned long long mx = 0ull;
+#pragma unroll 4
+        for (uint32_t i = tid; i < total; i += kMergeThreads) {
+            const unsigned long long v = src[i];
+            mx = v > mx ? v : mx;
+        }
+        atomicMax(&lane_max[lane], mx);
+        __syncthreads();
+        const unsigned long long mine = lane_max[lane];
+        uint32_t rank = 0;
+        for (uint32_t l = 0; l < (uint32_t)kBlock; ++l) {
+            const unsigned long long v = lane_max[l];
+            rank += (v > mine || (v == mine && l < lane)) ? 1u : 0u;
+        }
+        const unsigned long long pick = __ballot(rank == top_k - 1u);  // (every wave computes the same)
+        unsigned long long bound = lane_max[(uint32_t)__ffsll((long long)pick) - 1u];
+        if (bound == 0ull) bound = 1ull;  // empty slots never enter
+        for (uint32_t i0 = 0; i0 < total; i0 += 4u * kMergeThreads) {  // uniform trip count; four loads in flight
+            unsigned long long v4[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) v4[j] = i0 + j * kMergeThreads + tid < total ? src[i0 + j * kMergeThreads + tid] : 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const unsigned long long v = v4[j];
+                const bool keep = v >= bound;
+                const unsigned long long m = __ballot(keep);
+                if (m) {
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(&fill[0], cnt);
+                    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+                    if (base + cnt > (uint32_t)kCandCap) fill[1] = 1u;  // (only when nearly all keys tie: take the general path below)
+                    else if (keep) cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+                }
+            }
+        }
+        __syncthreads();
+        rounds = fill[1] != 0u;
+        if (!rounds) {
+            if (tid >= (uint32_t)kBlock) return;  // one wave finishes (cand_prune is written for kBlock threads)
+            if (tid == 0) {
+                *cs.thr = 0ull;
+                *cs.n = fill[0];
+            }
+            cand_prune(cs, top_k, true);
+        }
     }
-    __syncthreads();
-    // rounds: fill the buffer with as many spans as fit next to the kept top_k, prune, continue
-    const uint32_t per_round = ((uint32_t)kCandCap - top_k) / top_k;
-    for (uint32_t s0 = 0; s0 < H->n_spans; s0 += per_round) {
-        const uint32_t cnt = (H->n_spans - s0 < per_round ? H->n_spans - s0 : per_round) * top_k;
-        const uint32_t base = *cs.n;
+    if (rounds) {
+        if (tid >= (uint32_t)kBlock) return;
+        if (tid == 0) {
+            *cs.thr = 0ull;
+            *cs.n = 0;
+        }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) cand[base + i] = src[(size_t)s0 * top_k + i];
-        __syncthreads();
-        if (threadIdx.x == 0) *cs.n = base + cnt;
-        cand_prune(cs, top_k, true);  // sorted descending: empty slots (0) sink to the end
+        // fill the buffer with as many spans as fit next to the kept top_k, prune, continue
+        const uint32_t per_round = ((uint32_t)kCandCap - top_k) / top_k;
+        for (uint32_t s0 = 0; s0 < H->n_spans; s0 += per_round) {
+            const uint32_t cnt = (H->n_spans - s0 < per_round ? H->n_spans - s0 : per_round) * top_k;
+            const uint32_t base = *cs.n;
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += kBlock) cand[base + i] = src[(size_t)s0 * top_k + i];
+            __syncthreads();
+            if (tid == 0) *cs.n = base + cnt;
+            cand_prune(cs, top_k, true);  // sorted descending: empty slots (0) sink to the end
+        }
     }
     unsigned long long* out = part_keys + H->part_keys_off;
     const uint32_t n = *cs.n;
-    for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) out[i] = i < n ? cand[i] : 0ull;
+    for (uint32_t i = tid; i < top_k; i += kBlock) out[i] = i < n ? cand[i] : 0ull;
 }
 
 // gathered: num_shards packed partial buffers, shard-major, each `part_bytes` long.
@@ -1116,7 +1183,7 @@ void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, co
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_merge_spans, dim3(nq), dim3(kBlock), 0, st, blobs, blob_off, span_keys, part_keys);
+    hipLaunchKernelGGL(k_merge_spans, dim3(nq), dim3(kMergeThreads), 0, st, blobs, blob_off, span_keys, part_keys);
 }
 void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const uint8_t* gathered, uint32_t num_shards,
                      const PartialLayout& lay, uint32_t* res_ids, float* res_scores, uint32_t* res_n, unsigned long long* res_hits) {
