@@ -158,6 +158,7 @@ struct Compiler {
 
     const FuzzyTable* fuzzy = nullptr;
     const UnionTable* unions = nullptr;
+    const RangeTable* ranges = nullptr;
     const QueryCounts* counts = nullptr;
     uint32_t next_node = 0;
     std::vector<CountReq> count_reqs;   // operands whose result sizes a count pre-pass must measure
@@ -535,40 +536,98 @@ struct Compiler {
             const uint32_t *rb, *re;
             if (to_anchor.host_row(vid, &rb, &re)) pairs.push_back({*rb, v});
         }
+        bool several = false;
         for (size_t i = 1; i < pairs.size(); ++i) {
             if (pairs[i].first < pairs[i - 1].first) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
-            // several boosted values on one anchor: how many of them the reference applies depends on the neighbouring hits (boost.rs:262-279)
-            if (pairs[i].first == pairs[i - 1].first) unsupported("1:n field boost with several boosted values on one anchor (" + b.path + ")");
+            several = several || pairs[i].first == pairs[i - 1].first;
         }
-        std::vector<uint32_t> docs;
-        std::vector<float> vals;
-        for (auto& pr : pairs)
-            if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi) {
-                docs.push_back(pr.first);
-                vals.push_back(pr.second);
+        // layers[r]: the (r+1)-th value applied to an anchor — each layer is a sorted unique list, applied in order
+        std::vector<std::vector<std::pair<uint32_t, float>>> layers(1);
+        if (!several) layers[0] = pairs;
+        else {
+            // Several boosted values on one anchor.  The reference walks the boost list against the leaf's hits with one look-ahead
+            // entry (boost.rs:262-279): an anchor reached while the look-ahead already rests on its first entry gets that entry ONLY
+            // (the rest is skipped at the next hit); reached by scanning forward, it gets ALL its entries.  With the entry anchors
+            // a_0 < a_1 < ...: a_j is met resting on its first entry iff it is the very first entry, or the leaf has a hit strictly
+            // between a_(j-1) and a_j, or a_(j-1) is a hit that was NOT met that way (its scan stopped on a_j's first entry).
+            if (req.filter) unsupported("1:n field boost with several boosted values on one anchor, under a filter (" + b.path + ")");
+            std::vector<uint32_t> anchors;
+            for (auto& pr : pairs)
+                if (anchors.empty() || anchors.back() != pr.first) anchors.push_back(pr.first);
+            const std::string key = part.key() + "|" + b.path;
+            const RangeJob* done = nullptr;
+            if (ranges) {
+                auto it = ranges->find(key);
+                if (it != ranges->end()) done = &it->second;
             }
-        HList h;
-        h.len = uint32_t(docs.size());
-        h.global_len = pairs.size();
-        h.flags = LIST_HAS_SCORES | LIST_F32;
-        h.term_score = 1.0f;
-        h.inline_idx = int(cq.inline_lists.size());
-        h.inline_val_idx = int(cq.inline_vals.size());
-        cq.inline_lists.push_back(std::move(docs));
-        cq.inline_vals.push_back(std::move(vals));
-        const uint32_t li = add_list(h);
-        cq.algorithmic_bytes += 8ull * h.len;
-        DColBoost cb{};
-        fill_boost_params(cb, b);
-        cb.nskip = 0;  // apply_boost_values_anchor has no skip_when_score
-        cq.leaf_cols.push_back(cb);
-        DOp op{};
-        op.kind = OP_BOOST1N;
-        op.nchild = 1;
-        op.list_begin = uint16_t(li);
-        op.list_count = 1;
-        op.child_slot[0] = uint8_t(cq.leaf_cols.size() - 1);  // rebased behind the request-level boosts when the query is finished
-        push_op(ops, op, sp);
+            if (!done) {  // ask for the leaf's hits at every entry anchor and between neighbouring ones; compiled again afterwards
+                RangeJob job;
+                job.key = key;
+                job.store_path = l.path + TO_ANCHOR_ID_SCORE;
+                posting_store(l.path);
+                for (auto& h : l.hits_scores) job.tokens.push_back(h.first);
+                for (size_t j = 0; j < anchors.size(); ++j) {
+                    job.lo.push_back(anchors[j]);
+                    job.hi.push_back(anchors[j] + 1u);
+                    job.lo.push_back(j ? anchors[j - 1] + 1u : 0u);
+                    job.hi.push_back(j ? anchors[j] : 0u);
+                }
+                cq.range_requests.push_back(std::move(job));
+                layers[0] = pairs;  // (placeholder: this compilation is thrown away)
+                layers[0].erase(std::unique(layers[0].begin(), layers[0].end(), [](auto& x, auto& y) { return x.first == y.first; }), layers[0].end());
+            } else {
+                if (done->counts.size() != 2 * anchors.size()) unsupported("1:n field boost: range pre-pass does not match the boost list (internal)");
+                bool prev_hit = false, prev_first_only = false;
+                size_t p = 0;
+                for (size_t j = 0; j < anchors.size(); ++j) {
+                    const bool hit = done->counts[2 * j] != 0, between = j && done->counts[2 * j + 1] != 0;
+                    const bool first_only = j == 0 || between || (prev_hit && !prev_first_only);
+                    size_t e = p;
+                    while (e < pairs.size() && pairs[e].first == anchors[j]) ++e;
+                    const size_t take = first_only ? 1 : e - p;
+                    if (hit)
+                        for (size_t r = 0; r < take; ++r) {
+                            if (layers.size() <= r) layers.emplace_back();
+                            layers[r].push_back(pairs[p + r]);
+                        }
+                    p = e;
+                    prev_hit = hit;
+                    prev_first_only = first_only;
+                }
+                if (layers.size() > 8) unsupported("1:n field boost with more than 8 boosted values on one anchor (" + b.path + ")");
+            }
+        }
+        for (auto& layer : layers) {
+            std::vector<uint32_t> docs;
+            std::vector<float> vals;
+            for (auto& pr : layer)
+                if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi) {
+                    docs.push_back(pr.first);
+                    vals.push_back(pr.second);
+                }
+            HList h;
+            h.len = uint32_t(docs.size());
+            h.global_len = layer.size();
+            h.flags = LIST_HAS_SCORES | LIST_F32;
+            h.term_score = 1.0f;
+            h.inline_idx = int(cq.inline_lists.size());
+            h.inline_val_idx = int(cq.inline_vals.size());
+            cq.inline_lists.push_back(std::move(docs));
+            cq.inline_vals.push_back(std::move(vals));
+            const uint32_t li = add_list(h);
+            cq.algorithmic_bytes += 8ull * h.len;
+            DColBoost cb{};
+            fill_boost_params(cb, b);
+            cb.nskip = 0;  // apply_boost_values_anchor has no skip_when_score
+            cq.leaf_cols.push_back(cb);
+            DOp op{};
+            op.kind = OP_BOOST1N;
+            op.nchild = 1;
+            op.list_begin = uint16_t(li);
+            op.list_count = 1;
+            op.child_slot[0] = uint8_t(cq.leaf_cols.size() - 1);  // rebased behind the request-level boosts when the query is finished
+            push_op(ops, op, sp);
+        }
     }
 
     NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
@@ -1588,13 +1647,18 @@ void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& tabl
         for (auto& p : *req.boost_term) probe_part(idx, p, table);
 }
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts) {
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts,
+                            const RangeTable* ranges) {
     Compiler c(idx, req, fuzzy);
     c.unions = unions;
     c.counts = counts;
+    c.ranges = ranges;
     try {
         c.run();
-        if (!c.cq.union_requests.empty()) {
+        if (!c.cq.range_requests.empty()) {
+            c.cq.status = kStatusNeedsRanges;
+            c.cq.error = "internal: range jobs pending";
+        } else if (!c.cq.union_requests.empty()) {
             c.cq.status = kStatusNeedsUnion;
             c.cq.error = "internal: union jobs pending";
         } else if (c.cq.n_counts) {

@@ -159,8 +159,19 @@ struct UnionJob {
     uint64_t input_postings = 0;
 };
 using UnionTable = std::map<std::string, UnionJob>;
+// Leaf hits inside doc ranges, counted before the final compilation (k_range_hits): the reference's merge of a 1:n boost list into a
+// leaf's hits applies the first or all of an anchor's values depending on the hits around that anchor (boost.rs:255-281).
+struct RangeJob {
+    std::string key;
+    std::string store_path;          // "<field>.textindex.to_anchor_id_score"
+    std::vector<uint32_t> tokens;    // the leaf's posting lists
+    std::vector<uint32_t> lo, hi;    // doc ranges [lo, hi)
+    std::vector<uint64_t> counts;    // result: leaf postings inside each range, summed over the shards
+};
+using RangeTable = std::map<std::string, RangeJob>;
 constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union jobs have run
 constexpr int kStatusNeedsCounts = -2; // internal: the compiled query IS a count pre-pass; compile again with its results
+constexpr int kStatusNeedsRanges = -3; // internal: compile again once the requested range jobs have run
 
 // Result sizes of the operands of AND nodes, measured by a count pre-pass (the reference orders the score sum of an AND by
 // its operands' result lengths and labels an AND result by them, set_op.rs:388-393,439).
@@ -356,6 +367,7 @@ struct FacetOut {
 struct CompiledQuery {
     int status = 0;
     std::string error;
+    std::vector<RangeJob> range_requests;  // status == kStatusNeedsRanges
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
     std::vector<uint32_t> count_nodes;     // status == kStatusNeedsCounts: node ids; counters 2i / 2i+1 = hits / hits inside the filter, then the filter
     uint32_t n_counts = 0;
@@ -390,7 +402,8 @@ struct CompiledQuery {
 };
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr,
-                            const QueryCounts* counts = nullptr);
+                            const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr);
+void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, hipStream_t st);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 
 // ------------------------------------------------------------------ results

@@ -347,6 +347,45 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
 }
 }  // namespace
 
+// Range jobs (k_range_hits): how many postings of a leaf fall into each requested doc range; summed over the shards.
+void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, hipStream_t st) {
+    std::vector<UList> ulists;
+    std::vector<RangeTask> tasks;
+    for (auto& kv : table) {
+        RangeJob& job = kv.second;
+        const PostingStore& ps = idx.postings.at(job.store_path);
+        const uint32_t lb = uint32_t(ulists.size());
+        for (uint32_t tid : job.tokens) {
+            if (tid >= ps.len.size() || !ps.len[tid]) continue;
+            UList u{};
+            u.docs = ps.docs.as<uint32_t>() + ps.start[tid];
+            u.len = ps.len[tid];
+            ulists.push_back(u);
+        }
+        for (size_t r = 0; r < job.lo.size(); ++r) tasks.push_back(RangeTask{lb, uint32_t(ulists.size()) - lb, job.lo[r], job.hi[r]});
+    }
+    std::vector<uint64_t> counts(tasks.size(), 0);
+    if (!tasks.empty() && !ulists.empty()) {
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t o_tasks = al(ulists.size() * sizeof(UList)), o_cnt = o_tasks + al(tasks.size() * sizeof(RangeTask)), bytes = o_cnt + al(tasks.size() * 8);
+        ws.d_union_meta.ensure(bytes);
+        uint8_t* m = ws.d_union_meta.as<uint8_t>();
+        VQ_HIP(hipMemcpyAsync(m, ulists.data(), ulists.size() * sizeof(UList), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(m + o_tasks, tasks.data(), tasks.size() * sizeof(RangeTask), hipMemcpyHostToDevice, st));
+        launch_range_hits(st, uint32_t(tasks.size()), reinterpret_cast<const UList*>(m), reinterpret_cast<const RangeTask*>(m + o_tasks),
+                          reinterpret_cast<unsigned long long*>(m + o_cnt));
+        VQ_HIP(hipGetLastError());
+        VQ_HIP(hipMemcpyAsync(counts.data(), m + o_cnt, tasks.size() * 8, hipMemcpyDeviceToHost, st));
+        VQ_HIP(hipStreamSynchronize(st));
+    }
+    if (idx.sharded()) idx.sum_over_shards(counts);
+    size_t k = 0;
+    for (auto& kv : table) {
+        kv.second.counts.assign(counts.begin() + k, counts.begin() + k + kv.second.lo.size());
+        k += kv.second.lo.size();
+    }
+}
+
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st) {
     std::vector<UnionTaskH> l1, l2;
     for (auto& kv : table) {
@@ -502,6 +541,35 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
     double t_unions = t_pass1;
+    // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits)
+    RangeTable ranges;
+    {
+        std::vector<size_t> need;
+        for (size_t i = 0; i < n; ++i)
+            if (pb->queries[i].status == kStatusNeedsRanges) {
+                need.push_back(i);
+                for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
+            }
+        if (!need.empty()) {
+            if (idx.sharded() && !idx.can_sum_over_shards()) {
+                for (size_t i : need) {
+                    pb->queries[i].status = ERR_UNSUPPORTED;
+                    pb->queries[i].error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
+                }
+            } else {
+                run_range_jobs(idx, ws, ranges, st);
+                for (size_t i : need) {
+                    CompiledQuery& q = pb->queries[i];
+                    q = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy, nullptr, nullptr, &ranges);
+                    if (q.status == kStatusNeedsRanges) {
+                        q.status = ERR_UNSUPPORTED;
+                        q.error = "unsupported on the MI355X query path: boost list changed between compilation passes (internal)";
+                    }
+                }
+            }
+        }
+    }
+    const RangeTable* rangesp = ranges.empty() ? nullptr : &ranges;
     // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch, compile those queries again
     UnionTable unions;
     std::vector<size_t> again;
@@ -523,7 +591,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         auto recompile = [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
                 CompiledQuery& q = pb->queries[again[k]];
-                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, &unions);
+                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, &unions, nullptr, rangesp);
                 if (q.status == kStatusNeedsUnion) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
@@ -571,7 +639,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             }
             for (size_t k = 0; k < need.size(); ++k) {
                 CompiledQuery& q = pb->queries[need[k]];
-                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k]);
+                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k], rangesp);
                 if (q.status < 0) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: query still needs a pre-pass after the count pre-pass (internal)";
@@ -813,8 +881,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
-        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), pack+launch %.3f ms\n", n,
-                     t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_unions, now_ms() - t_compiled);
+        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), %zu range jobs, pack+launch %.3f ms\n", n,
+                     t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_unions, ranges.size(),
+                     now_ms() - t_compiled);
     return pb;
 }
 

@@ -2059,6 +2059,27 @@ __device__ __forceinline__ uint32_t lane_lower_bound(const VQ_GLOBAL uint32_t* a
     return lo;
 }
 
+// Leaf hits inside doc ranges: task t counts the postings with doc in [lo, hi) over its lists (one wave per task, lanes stride
+// over the lists).  A pre-pass of 1:n field boosts with several values per anchor (compile.cpp emit_boost_1n, boost.rs:255-281).
+__global__ __launch_bounds__(64) void k_range_hits(const UList* __restrict__ ulists, const RangeTask* __restrict__ tasks, uint32_t n_tasks,
+                                                    unsigned long long* __restrict__ counts) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tasks) return;
+    const RangeTask task = tasks[t];
+    unsigned long long c = 0;
+    for (uint32_t i = threadIdx.x; i < task.n_lists; i += 64u) {
+        const UList L = ulists[task.list_begin + i];
+        const VQ_GLOBAL uint32_t* d = as_global(L.docs);
+        c += lane_lower_bound(d, L.len, task.hi) - lane_lower_bound(d, L.len, task.lo);
+    }
+    for (uint32_t off = 32; off > 0; off >>= 1) c += shfl_u64(c, (threadIdx.x + off) & 63u);
+    if (threadIdx.x == 0) counts[t] = c;
+}
+void launch_range_hits(hipStream_t st, uint32_t n_tasks, const UList* ulists, const RangeTask* tasks, unsigned long long* counts) {
+    if (!n_tasks) return;
+    hipLaunchKernelGGL(k_range_hits, dim3(n_tasks), dim3(64), 0, st, ulists, tasks, n_tasks, counts);
+}
+
 constexpr uint32_t kUnionWindow = 16;
 
 template <bool WRITE>
