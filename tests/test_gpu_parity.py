@@ -735,6 +735,52 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
     assert declined == 0, declined
 
 
+def test_rccl_collective_path_with_one_rank(corpus):
+    """dist.ShardedSearcher on the `nccl` (= RCCL) backend with a single rank: the scans run on a torch side stream handed to the
+    index (vq_index_set_stream), the packed partial is all-gathered by RCCL as a zero-copy uint8 view, the merge reads the gathered
+    buffer, the all-reduce hook goes through RCCL — everything the multi-GPU bench does, minus the other ranks."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import veloci_amd
+    from veloci_amd import synth
+    from veloci_amd.dist import ShardedSearcher
+    data, meta, idx, ora = corpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        idx2 = veloci_amd.Index(data, device=0)
+        searcher = ShardedSearcher(idx2, always_collective=True)
+        assert searcher.stream is not None
+        t = [list(x) for x in meta.triples]
+        reqs = []
+        for i in range(96):
+            a = t[i % len(t)]
+            reqs.append([synth.req_and(a), synth.req_or(a, top=25), synth.req_single(a[i % 3], top=3),
+                         dict(synth.req_and(a[:2]), facets=[{"field": "cat", "top": 5}])][i % 4])
+        want = veloci_amd.search_batch(reqs, idx)
+        for _ in range(3):  # several batches back to back on the side stream
+            got = searcher.search_batch(reqs)
+            for g, w in zip(got, want):
+                assert g.num_hits == w.num_hits and list(g.ids) == list(w.ids)
+                assert np.array_equal(np.asarray(g.scores, np.float32).view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
+                assert sorted(map(repr, (g.facets or {}).items())) == sorted(map(repr, (w.facets or {}).items()))
+        plain = [r for r in reqs if "facets" not in r]
+        f_got = searcher.search_batch_flat(plain * 8, stride=25)  # >= 512 requests: the chunked pipeline, one all-gather per chunk
+        f_want = veloci_amd.search_batch_flat(plain * 8, idx, stride=25)
+        for a, b in zip(f_got, f_want):
+            assert np.array_equal(a, b)
+        v = np.array([1, 2, 2**40 + 7], dtype=np.uint64)
+        searcher._sum_over_ranks(v)
+        assert v.tolist() == [1, 2, 2**40 + 7]
+    finally:
+        dist.destroy_process_group()
+
+
 def test_concurrent_searches_from_host_threads(corpus):
     """The reference serves `search` from many rocket worker threads on one Persistence (server/rocket_server.rs:139-145);
     the index handle must take concurrent vq_search / vq_search_batch calls (ctypes drops the GIL during them)."""

@@ -60,19 +60,21 @@ def gather_partials(local, group=None):
 class ShardedSearcher:
     """search_batch over an index sharded by doc-id range across the ranks of `group`."""
 
-    def __init__(self, index, group=None):
+    def __init__(self, index, group=None, always_collective=False):
+        """always_collective: take the collective path even with one rank (tests: RCCL all-gather / all-reduce on a 1-GPU box)."""
         import torch.distributed as dist
         self.index = index
         self.group = group
         self.world = dist.get_world_size(group)
+        self.collective = self.world > 1 or always_collective
         self.stream = None
-        if self.world > 1 and dist.get_backend(group) == "nccl":
+        if self.collective and dist.get_backend(group) == "nccl":
             # scans, the RCCL all-gather and the merge are ordered on ONE side stream: no host synchronisation between
             # the shard scan and the collective.  (Not torch's default stream: its handle is 0, which the C ABI reads as
             # "use the index's own streams".)
             self.stream = torch.cuda.Stream()
             index.set_stream(self.stream.cuda_stream)
-        if self.world > 1:
+        if self.collective:
             index.set_allreduce(self._sum_over_ranks)
 
     def _sum_over_ranks(self, values):
@@ -100,7 +102,7 @@ class ShardedSearcher:
     def search_batch(self, requests):
         from .search import PartialBatch
         pb = PartialBatch(self.index, requests)
-        if self.world == 1:
+        if not self.collective:
             return pb.merge(None, 1)
         gathered = self._gather(pb)
         return pb.merge(gathered.data_ptr(), self.world)
@@ -114,7 +116,7 @@ class ShardedSearcher:
         subs = batch.split(chunks if chunks is not None else (4 if batch.n >= 512 else 1))
 
         def finish(pb):
-            if self.world == 1:
+            if not self.collective:
                 out = pb.merge_flat(None, 1, stride)
             else:
                 gathered = self._gather(pb)
