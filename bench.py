@@ -61,9 +61,15 @@ def main():
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VQ_BENCH_COLLECTIVE=1: take the N>1 code path (process group, sharded searcher, collectives) with however many ranks there are —
+    # with one rank this rehearses the RCCL calls of the multi-GPU run on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("VQ_BENCH_COLLECTIVE") == "1"
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -82,7 +88,7 @@ def main():
                            with_phrase=rich, background_terms=2000 if fuzzy else 0)
     data, meta = synth.generate(spec, doc_lo=lo, doc_hi=hi, device=f"cuda:{local_rank}")
     t_gen = time.time() - t0
-    if world > 1:
+    if dist_on:
         vdist.all_reduce_global_lens(data)
     t0 = time.time()
     index = veloci_amd.Index(data, device=local_rank, doc_lo=lo, doc_hi=hi)
@@ -145,7 +151,8 @@ def main():
                          for i in range(args.batch)]
     reqs = [veloci_amd.Request(r) for r in reqs_json]
     batch = veloci_amd.RequestBatch(reqs)
-    searcher = vdist.ShardedSearcher(index) if world > 1 else None
+    searcher = vdist.ShardedSearcher(index, always_collective=True) if dist_on else None
+    bench_chunks = int(os.environ["VQ_BENCH_CHUNKS"]) if os.environ.get("VQ_BENCH_CHUNKS") else None  # None: the searcher's default
 
     class Row:  # what the bench looks at of a result
         def __init__(self, nh):
@@ -154,7 +161,7 @@ def main():
     def step():
         # flat C-ABI entry points: no per-result Python objects inside the timed region
         if searcher is not None:
-            num_hits, counts, ids, scores, status = searcher.search_batch_flat(batch, stride=10)
+            num_hits, counts, ids, scores, status = searcher.search_batch_flat(batch, stride=10, chunks=bench_chunks)
         else:
             num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(batch, index, stride=10)
         assert not status.any()
@@ -162,7 +169,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -185,7 +192,7 @@ def main():
         log("step times ms:", [round(x * 1e3, 2) for x in step_times], "loop", round(t_loop * 1e3, 2), "with final sync", round(dt * 1e3, 2))
     scan_ms, launches, algo_bytes = index.profile_read(reset=True)
     index.profile_enable(False)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -245,7 +252,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(data, meta, reqs_json, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

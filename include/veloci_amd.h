@@ -125,6 +125,11 @@ void vq_index_free(vq_index*);
 /* Run this index's launches on an existing HIP stream (hipStream_t as void*);
  * NULL restores the index's own stream. */
 int vq_index_set_stream(vq_index*, void* hip_stream);
+/* Two caller streams: the scans of vq_search_batch_partial run on `scan_stream`, everything vq_merge_partials* launches (shard merge,
+ * facet selection, result download) on `finish_stream`, which waits for the batch's scan through an event.  A caller that pipelines
+ * batches puts its collective on `finish_stream` too (after making that stream wait for the scan, e.g. an event recorded on
+ * `scan_stream` right after vq_search_batch_partial returned): the gather and merge of batch c then overlap the scan of batch c+1. */
+int vq_index_set_streams(vq_index*, void* scan_stream, void* finish_stream);
 /* Sharded deployments: a few requests need numbers that are sums over all shards before they can be compiled (result sizes of AND
  * operands, lengths of merged leaf lists — set_op.rs:388-393 orders an AND's score sum by them).  `fn(ctx, values, n)` must replace
  * values[0..n) by their sums over all ranks (an all-reduce; every rank calls it with the same n, in the same order) and return 0.

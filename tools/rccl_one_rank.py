@@ -25,3 +25,19 @@ for k in range(3):
 v = np.array([1, 2, 3], dtype=np.uint64)
 t0 = T(); s._sum_over_ranks(v); print("allreduce", T() - t0, flush=True)
 t0 = T(); dist.destroy_process_group(); print("destroy", T() - t0, flush=True)
+# raw cost of a small all-gather on a side stream: host time per call, and time per call including completion
+dist.init_process_group("nccl", rank=0, world_size=1)
+st = torch.cuda.Stream()
+a = torch.zeros(25000, dtype=torch.uint8, device="cuda"); o = torch.empty_like(a)
+with torch.cuda.stream(st):
+    for _ in range(5): dist.all_gather_into_tensor(o, a)
+    torch.cuda.synchronize()
+    t0 = T()
+    for _ in range(200): dist.all_gather_into_tensor(o, a)
+    t1 = T(); torch.cuda.synchronize(); t2 = T()
+    print("all_gather host us/call", (t1 - t0) / 200 * 1e6, "incl completion us/call", (t2 - t0) / 200 * 1e6, flush=True)
+    t0 = T()
+    for _ in range(200):
+        dist.all_gather_into_tensor(o, a); st.synchronize()
+    print("all_gather + stream sync us/call", (T() - t0) / 200 * 1e6, flush=True)
+dist.destroy_process_group()

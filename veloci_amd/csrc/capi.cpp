@@ -173,6 +173,15 @@ int vq_index_set_stream(vq_index* i, void* hip_stream) {
         i->idx->fin_stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_fin_stream;
     });
 }
+int vq_index_set_streams(vq_index* i, void* scan_stream, void* finish_stream) {
+    return guard([&] {
+        if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_streams: null index");
+        if (!scan_stream || !finish_stream) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_streams: null stream (vq_index_set_stream(index, NULL) restores the index's own)");
+        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
+        i->idx->stream = static_cast<hipStream_t>(scan_stream);
+        i->idx->fin_stream = static_cast<hipStream_t>(finish_stream);
+    });
+}
 int vq_index_set_allreduce(vq_index* i, vq_allreduce_u64_fn fn, void* ctx) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_allreduce: null index");

@@ -68,12 +68,14 @@ class ShardedSearcher:
         self.world = dist.get_world_size(group)
         self.collective = self.world > 1 or always_collective
         self.stream = None
+        self._views = {}
         if self.collective and dist.get_backend(group) == "nccl":
-            # scans, the RCCL all-gather and the merge are ordered on ONE side stream: no host synchronisation between
-            # the shard scan and the collective.  (Not torch's default stream: its handle is 0, which the C ABI reads as
-            # "use the index's own streams".)
+            # scans on one side stream, RCCL all-gather + merge on another that waits for the batch's scan through an event:
+            # no host synchronisation between the shard scan and the collective.  (Not torch's default stream: its handle
+            # is 0, which the C ABI reads as "use the index's own streams".)
             self.stream = torch.cuda.Stream()
-            index.set_stream(self.stream.cuda_stream)
+            self.fin_stream = torch.cuda.Stream()  # all-gather + merge of batch c overlap the scan of batch c+1
+            index.set_streams(self.stream.cuda_stream, self.fin_stream.cuda_stream)
         if self.collective:
             index.set_allreduce(self._sum_over_ranks)
 
@@ -87,11 +89,30 @@ class ShardedSearcher:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         values[:] = t.cpu().numpy().astype(np.uint64)
 
+    def _partial(self, requests):
+        from .search import PartialBatch
+        pb = PartialBatch(self.index, requests)
+        if self.stream is not None:  # the collective (finish stream) must wait for this batch's scan, not for the next one's
+            pb.scanned = torch.cuda.Event()
+            pb.scanned.record(self.stream)
+        return pb
+
     def _gather(self, pb):
         if self.stream is not None:
-            with torch.cuda.stream(self.stream):
-                local = device_view(pb.device_ptr, pb.nbytes)
-                return gather_partials(local, self.group)
+            import torch.distributed as dist
+            self.fin_stream.wait_event(pb.scanned)
+            with torch.cuda.stream(self.fin_stream):
+                # the partial lives in one of the index's two batch workspaces: its view and the gathered buffer are reused as long
+                # as the workspace keeps its address and size (building them costs more host time than the collective itself)
+                key = (pb.device_ptr, pb.nbytes)
+                ent = self._views.get(key)
+                if ent is None:
+                    if len(self._views) > 8:
+                        self._views.clear()
+                    local = device_view(pb.device_ptr, pb.nbytes)
+                    ent = self._views[key] = (local, torch.empty(self.world * pb.nbytes, dtype=torch.uint8, device=local.device))
+                dist.all_gather_into_tensor(ent[1], ent[0], group=self.group)
+                return ent[1]
         # rehearsal backends: the partial is complete (vq_search_batch_partial synchronised the index's own stream);
         # make sure the gathered copy is, too, before the merge kernels (own stream) read it
         local = device_view(pb.device_ptr, pb.nbytes)
@@ -101,7 +122,7 @@ class ShardedSearcher:
 
     def search_batch(self, requests):
         from .search import PartialBatch
-        pb = PartialBatch(self.index, requests)
+        pb = self._partial(requests)
         if not self.collective:
             return pb.merge(None, 1)
         gathered = self._gather(pb)
@@ -128,7 +149,7 @@ class ShardedSearcher:
         for sb in subs:
             if len(inflight) >= 2:
                 outs.append(finish(inflight.pop(0)))
-            inflight.append(PartialBatch(self.index, sb))
+            inflight.append(self._partial(sb))
         while inflight:
             outs.append(finish(inflight.pop(0)))
         if len(outs) == 1:

@@ -157,6 +157,10 @@ class Index:
     def set_stream(self, hip_stream):
         _lib.check(self.L.vq_index_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
 
+    def set_streams(self, scan_stream, finish_stream):
+        """vq_index_set_streams: scans on one caller stream, merges / downloads on another (hipStream_t handles as ints)."""
+        _lib.check(self.L.vq_index_set_streams(self.h, C.c_void_p(scan_stream), C.c_void_p(finish_stream)))
+
     def set_allreduce(self, fn):
         """fn(numpy uint64 array) must sum the array over all shards in place (vq_index_set_allreduce); None removes it."""
         if fn is None:
