@@ -29,3 +29,4 @@ for k, n in names.items():
     print(f"{n:26s} {v[k]/tot*100:6.2f}%   {v[k]/max(v[7],1):10.1f} ticks/tile")
 print("tiles", v[7], "wgs", v[8], "ticks/tile total", tot / max(v[7], 1))
 print("hits/tile", v[11] / max(v[7], 1), "scored/tile", v[12] / max(v[7], 1))
+print("P5 scoring rounds of lane 0 per tile", v[13] / max(v[7], 1), "ticks per round in the score tree", v[14] / max(v[13], 1), "prunes in P5 per tile", v[15] / max(v[7], 1))

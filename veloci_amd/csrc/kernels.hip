@@ -64,6 +64,35 @@ void debug_read_stamps(unsigned long long* out, int reset) {
 #define VQ_STAMP_FLUSH
 #endif
 
+// Uniform (same for the whole wave) read-only descriptors are read through the constant address space: with a wave-uniform address
+// these are scalar loads (SGPR results, scalar cache) instead of one LDS / vector access per lane.
+#define VQ_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const VQ_CONST T* as_const(const void* p) {
+    return (const VQ_CONST T*)(uintptr_t)p;
+}
+
+// A DOp fetched as six dwords through the constant address space (scalar loads), fields decoded with scalar shifts.
+struct KOp {
+    uint32_t r0, r1;
+    unsigned long long slots, order;
+    __device__ __forceinline__ explicit KOp(const VQ_CONST DOp* p) {
+        static_assert(sizeof(DOp) == 24, "DOp layout");
+        const VQ_CONST uint32_t* w = (const VQ_CONST uint32_t*)p;
+        r0 = w[0];
+        r1 = w[1];
+        slots = ((unsigned long long)w[3] << 32) | w[2];
+        order = ((unsigned long long)w[5] << 32) | w[4];
+    }
+    __device__ __forceinline__ uint32_t kind() const { return r0 & 0xFFu; }
+    __device__ __forceinline__ uint32_t nchild() const { return (r0 >> 8) & 0xFFu; }
+    __device__ __forceinline__ uint32_t nslots() const { return (r0 >> 16) & 0xFFu; }
+    __device__ __forceinline__ uint32_t list_begin() const { return r1 & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t list_count() const { return r1 >> 16; }
+    __device__ __forceinline__ uint32_t child_slot(uint32_t k) const { return (uint32_t)(slots >> (8u * k)) & 0xFFu; }
+    __device__ __forceinline__ uint32_t and_order(uint32_t k) const { return (uint32_t)(order >> (8u * k)) & 0xFFu; }
+};
+
 // ------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -273,6 +302,8 @@ struct ScoreCtx {
     uint32_t WW;
     float* fstack;  // this lane's column, stride kBlock
     uint32_t* hist;
+    const VQ_CONST DOp* kops;      // the same ops / lists in the query blob in HBM, for wave-uniform (scalar) reads
+    const VQ_CONST DList* klists;
 };
 
 __device__ __forceinline__ float pick4(float v0, float v1, float v2, float v3, uint32_t k) { return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3; }
@@ -328,54 +359,56 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
     uint32_t sp = 0;
     uint32_t pmask = 0;  // bit s: stack slot s holds a present value
     for (uint32_t o = 0; o < c.n_ops; ++o) {
-        const DOp& op = c.ops[o];
+        const KOp op(c.kops + o);  // (scalar loads: o is uniform)
         float s = 0.0f;
         bool present = false;
-        if (op.kind == OP_LEAF) {
-            for (uint32_t j = 0; j < op.list_count; ++j) {
-                const uint32_t li = op.list_begin + j;
+        if (op.kind() == OP_LEAF) {
+            for (uint32_t j = 0; j < op.list_count(); ++j) {
+                const uint32_t li = op.list_begin() + j;
                 const uint32_t word = c.bm[li * c.WW + w];
                 if ((word >> b) & 1u) {
                     float v = 0.0f;
-                    if (c.lists[li].flags & LIST_HAS_SCORES) {
+                    const uint32_t lflags = c.klists[li].flags;
+                    if (lflags & LIST_HAS_SCORES) {
                         const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
                         const uint32_t idx = c.cur[li] + c.cnt_lo[li] + rank;
-                        if (c.lists[li].flags & LIST_F32) v = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[idx];
-                        else v = posting_value(c.lists[li].term_score, as_global(c.lists[li].scores)[idx]);
+                        const uint16_t* sp16 = c.klists[li].scores;
+                        if (lflags & LIST_F32) v = as_global(reinterpret_cast<const float*>(sp16))[idx];
+                        else v = posting_value(c.klists[li].term_score, as_global(sp16)[idx]);
                     }
                     if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
                     present = true;
                 }
             }
-        } else if (op.kind == OP_BOOST1N) {  // apply_boost_values_anchor (boost.rs:255-281): one boost value per anchor of the leaf below
+        } else if (op.kind() == OP_BOOST1N) {  // apply_boost_values_anchor (boost.rs:255-281): one boost value per anchor of the leaf below
             const uint32_t top = sp - 1u;
             if ((pmask >> top) & 1u) {
-                const uint32_t li = op.list_begin;
+                const uint32_t li = op.list_begin();
                 const uint32_t word = c.bm[li * c.WW + w];
                 if ((word >> b) & 1u) {
                     const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
-                    const float v = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
-                    c.fstack[top * kBlock] = apply_boost_value(c.fstack[top * kBlock], c.cols[op.child_slot[0]], v);
+                    const float v = as_global(reinterpret_cast<const float*>(c.klists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
+                    c.fstack[top * kBlock] = apply_boost_value(c.fstack[top * kBlock], c.cols[op.child_slot(0)], v);
                 }
             }
             continue;
-        } else if (op.kind == OP_AND) {
-            const uint32_t base = sp - op.nchild;
+        } else if (op.kind() == OP_AND) {
+            const uint32_t base = sp - op.nchild();
             present = true;
-            for (uint32_t k = 0; k < op.nchild; ++k) present = present && ((pmask >> (base + k)) & 1u);
+            for (uint32_t k = 0; k < op.nchild(); ++k) present = present && ((pmask >> (base + k)) & 1u);
             if (present) {
                 s = 0.0f;  // set_op.rs:415-416
-                for (uint32_t k = 0; k < op.nchild; ++k) s += c.fstack[(base + op.and_order[k]) * kBlock];
+                for (uint32_t k = 0; k < op.nchild(); ++k) s += c.fstack[(base + op.and_order(k)) * kBlock];
             }
             sp = base;
         } else {
-            const uint32_t base = sp - op.nchild;
+            const uint32_t base = sp - op.nchild();
             float sum = 0.0f;
             float nd = 0.0f;
-            for (uint32_t slot = 0; slot < op.nslots; ++slot) {  // set_op.rs:169-186
+            for (uint32_t slot = 0; slot < op.nslots(); ++slot) {  // set_op.rs:169-186
                 float m = 0.0f;
-                for (uint32_t k = 0; k < op.nchild; ++k) {
-                    if (op.child_slot[k] == slot && ((pmask >> (base + k)) & 1u)) {
+                for (uint32_t k = 0; k < op.nchild(); ++k) {
+                    if (op.child_slot(k) == slot && ((pmask >> (base + k)) & 1u)) {
                         present = true;
                         m = fmaxf(m, c.fstack[(base + k) * kBlock]);
                     }
@@ -485,7 +518,7 @@ size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_w
 
 constexpr int kGroup = 4;  // lists whose first-round loads are issued together
 
-__global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_tile_scan(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                       const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                       uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap,
                                                       unsigned long long* __restrict__ span_keys,
@@ -513,8 +546,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
 
     // ---- stage the query descriptor into LDS: every later phase reads it from there, not from HBM
     uint32_t* desc = lds + kLdsDesc;
+    const uint8_t* gblob8 = blobs + __builtin_amdgcn_readfirstlane(blob_off[q]);  // (in SGPRs: the interpreter's scalar reads go here)
     {
-        const uint32_t* gblob = reinterpret_cast<const uint32_t*>(blobs + blob_off[q]);
+        const uint32_t* gblob = reinterpret_cast<const uint32_t*>(gblob8);
         const uint32_t n32 = reinterpret_cast<const QHeader*>(gblob)->desc_bytes >> 2;
         for (uint32_t x = tid; x < n32; x += kBlock) desc[x] = gblob[x];
     }
@@ -535,6 +569,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
     const DFacet* facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
     const DPresOp* pres = reinterpret_cast<const DPresOp*>(blob + H->off_pres);
     const uint16_t* pres_in = reinterpret_cast<const uint16_t*>(blob + H->off_pres_in);
+    const VQ_CONST DOp* kops = as_const<DOp>(gblob8 + __builtin_amdgcn_readfirstlane(H->off_ops));
+    const VQ_CONST DList* klists = as_const<DList>(gblob8 + __builtin_amdgcn_readfirstlane(H->off_lists));
     const uint32_t n_ops = H->n_ops, n_pres = H->n_pres;
     const uint32_t n_groups = H->n_groups, n_tboost = H->n_tboost, n_col = H->n_col, n_locf = H->n_locf, n_facets = H->n_facets;
 
@@ -903,7 +939,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
             VQ_STAMP_AT(4)
 
             ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
-                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist};
+                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists};
             uint32_t it_a = compact ? lane : 0u;
             uint32_t it_r = compact ? 0u : rootw[w0];
             bool pending = false;
@@ -934,7 +970,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
                         w = w0 + it_a;
                     }
                     const uint32_t doc = tile_lo + (w << 5) + b;
+#ifdef VQ_STAMP
+                    const unsigned long long _ts0 = __builtin_amdgcn_s_memtime();
+#endif
                     float score = sc.simple_n ? tree_score_simple(sc, w, b) : tree_score_generic(sc, w, b);
+#ifdef VQ_STAMP
+                    _acc[13] += 1ull;                                      // scoring rounds of lane 0
+                    _acc[14] += __builtin_amdgcn_s_memtime() - _ts0;       // ticks inside the score tree
+#endif
                     score = sink_stages(sc, score, doc, w, b);
                     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
                     if (key > *thr) {
@@ -949,6 +992,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_scan(const uint8_t* __restrict_
                 }
                 const int need = __syncthreads_or(pending ? 1 : 0);
                 if (!need) break;
+#ifdef VQ_STAMP
+                _acc[15] += 1ull;  // candidate prunes inside P5
+#endif
                 cand_prune(cs, top_k);
             }
             VQ_STAMP_AT(5)
