@@ -554,6 +554,75 @@ def test_1n_boost_with_several_values_per_anchor_follows_the_reference_walk():
         assert_same(req, g, want, exact_scores=True)
 
 
+def _jmdict_request(term, lev):
+    """Request of the reference's own benchmark, benches/bench_jmdict.rs:115-235 (`get_request(term, levenshtein_distance)`): an OR
+    over five field leaves, each with its own anchor-level and 1:n boosts (BASELINE.json configs[0])."""
+    def leaf(path, boosts, starts_with):
+        part = {"terms": [term], "path": path, "levenshtein_distance": lev, "options": {"boost": boosts}}
+        if starts_with:
+            part["starts_with"] = True
+        return {"search": part}
+    common = lambda p: {"path": "commonness", "boost_fun": "Log10", "param": p}
+    return {"search_req": {"or": {"queries": [
+        leaf("kanji[].text", [common(1), {"path": "kanji[].commonness", "boost_fun": "Log10", "param": 1}], True),
+        leaf("kana[].text", [common(1), {"path": "kana[].commonness", "boost_fun": "Log10", "param": 1}], True),
+        leaf("kana[].text", [common(1), {"path": "kana[].commonness", "boost_fun": "Log10", "param": 1}], True),
+        leaf("meanings.ger[].text", [common(0), {"path": "meanings.ger[].rank", "expression": "10 / $SCORE"}], False),
+        leaf("meanings.eng[]", [common(1)], False),
+    ], "options": {"top": 10, "skip": 0}}}}
+
+
+def test_bench_jmdict_request_shape_matches_the_oracle():
+    """BASELINE.json configs[0]: the request shape of the reference's bench_jmdict on a JMdict-like corpus with the index
+    configuration of veloci_bins/src/bin/create_test_index.rs:33-69 (jmdict.json itself is a git-lfs pointer in the reference)."""
+    import veloci_amd
+    from veloci_amd import mini_indexer
+    from oracle import binding as O
+    from parity import assert_same
+    rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "166600")))
+    kanji = ["意慾", "意欲", "慾意", "威容", "偉容", "意地", "意図", "異様"]
+    kana = ["いよく", "いよう", "いじ", "いと", "いよ", "よく"]
+    eng = ["will", "desire", "ambition", "dignity", "majestic appearance", "will power", "intention", "strange", "well", "wish"]
+    ger = ["Wille", "Wunsch", "Begehren", "Ehrgeiz", "majestätischer Anblick", "Absicht", "Wollen", "Willenskraft"]
+    docs = []
+    for d in range(2000):
+        doc = {"commonness": int(rng.choice([0, 5, 20, 350, 3000])), "ent_seq": str(1000000 + d), "pos": [str(rng.choice(["n", "v1", "adj-i"]))]}
+        doc["kanji"] = [{"text": str(rng.choice(kanji)), "commonness": int(rng.choice([0, 3, 40, 500]))} for _ in range(int(rng.integers(0, 3)))]
+        doc["kana"] = [{"text": str(rng.choice(kana)), "romaji": "iyoku", "commonness": int(rng.choice([0, 7, 60]))} for _ in range(int(rng.integers(1, 3)))]
+        doc["meanings"] = {"eng": [str(rng.choice(eng)) for _ in range(int(rng.integers(1, 4)))],
+                           "ger": [{"text": str(rng.choice(ger)), "rank": int(rng.integers(1, 6))} for _ in range(int(rng.integers(0, 3)))]}
+        if not doc["kanji"]:
+            del doc["kanji"]
+        if not doc["meanings"]["ger"]:
+            del doc["meanings"]["ger"]
+        docs.append(doc)
+    indices = {"commonness": {"boost": {"boost_type": "f32"}}, "meanings.ger[].rank": {"boost": {"boost_type": "f32"}},
+               "kanji[].commonness": {"boost": {"boost_type": "f32"}}, "kana[].commonness": {"boost": {"boost_type": "f32"}},
+               "kanji[].text": {"fulltext": {"tokenize": False}}, "kana[].text": {"fulltext": {"tokenize": False}},
+               "kana[].romaji": {"fulltext": {"tokenize": True}}, "meanings.ger[].text": {"fulltext": {"tokenize": True}},
+               "meanings.eng[]": {"fulltext": {"tokenize": True}}, "pos": {"fulltext": {"tokenize": False}}}
+    data, info = mini_indexer.build_index(docs, indices)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    ran = 0
+    for term in ["意慾", "意", "いよ", "いよく", "will", "Wille", "majestic", "desire", "Absicht", "well"]:
+        for lev in (0, 1):
+            req = _jmdict_request(term, lev)
+            js = json.dumps(req)
+            try:
+                want = ora.search_json(js)
+            except O.OracleError as e:
+                with pytest.raises(veloci_amd.VelociError) as g:
+                    veloci_amd.search(req, idx)
+                assert str(g.value) == str(e), js
+                continue
+            got = veloci_amd.search(req, idx)
+            assert_same(req, got, want, exact_scores=False)  # Log10 boosts: device log vs glibc, 1e-5
+            ran += 1
+    assert ran >= 16, ran
+
+
 def test_random_requests_in_batches_match_the_oracle():
     """The same generator through vq_search_batch: dictionary scans, union jobs and count pre-passes of many requests share one batch."""
     import veloci_amd
