@@ -159,6 +159,7 @@ struct Compiler {
     const FuzzyTable* fuzzy = nullptr;
     const UnionTable* unions = nullptr;
     const RangeTable* ranges = nullptr;
+    Boost1nCache* boost_cache = nullptr;
     const QueryCounts* counts = nullptr;
     uint32_t next_node = 0;
     std::vector<CountReq> count_reqs;   // operands whose result sizes a count pre-pass must measure
@@ -395,6 +396,18 @@ struct Compiler {
         if (sp > uint32_t(kStackDepth)) unsupported("query tree deeper than the evaluation stack");
     }
 
+    // key of the union job that materialises this leaf, or "" when the leaf's lists are scanned as they are (same rule and key as
+    // in compile_leaf_scores)
+    std::string leaf_union_key(const Leaf& l) {
+        const PostingStore& ps = posting_store(l.path);
+        size_t nonempty = 0;
+        for (auto& [tid, score] : l.hits_scores)
+            if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
+        if (!(nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req)))) return std::string();
+        // (the matched terms and their scores follow from the leaf's request alone: its key identifies the merged list)
+        return "u|" + l.path + "|" + l.part.key();
+    }
+
     // score leaf: the posting lists of the matched terms (resolve_token_to_anchor, search_field.rs:400-504)
     NodeInfo compile_leaf_scores(const SearchRequest& r, Leaf& l, std::vector<DOp>& ops, uint32_t& sp) {
         NodeInfo info;
@@ -411,23 +424,22 @@ struct Compiler {
                     if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
                 if (nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req))) {
                     // K2: the leaf's hits are materialised once per batch (union, max per doc) and scanned as one list
-                    UnionJob job;
-                    job.store_path = l.path + TO_ANCHOR_ID_SCORE;
-                    key_s(job.key, job.store_path);
-                    for (auto& [tid, score] : l.hits_scores)
-                        if (tid < ps.num_tokens && ps.global_len[tid]) {
-                            job.terms.push_back({tid, score});
-                            job.key += std::to_string(tid) + ":";
-                            key_f(job.key, score);
-                            job.input_postings += ps.len[tid];
-                        }
+                    const std::string ukey = leaf_union_key(l);
                     const UnionJob* done = nullptr;
                     if (unions) {
-                        auto it = unions->find(job.key);
+                        auto it = unions->find(ukey);
                         if (it != unions->end()) done = &it->second;
                     }
                     info.glen = 0;
                     if (!done) {
+                        UnionJob job;
+                        job.key = ukey;
+                        job.store_path = l.path + TO_ANCHOR_ID_SCORE;
+                        for (auto& [tid, score] : l.hits_scores)
+                            if (tid < ps.num_tokens && ps.global_len[tid]) {
+                                job.terms.push_back({tid, score});
+                                job.input_postings += ps.len[tid];
+                            }
                         cq.union_requests.push_back(std::move(job));  // compiled again after the jobs ran
                         info.len_known = true;
                     } else {
@@ -502,9 +514,8 @@ struct Compiler {
         if (b.expression) parse_expression(*b.expression, cb);
     }
 
-    // BoostToAnchor + ApplyAnchorBoost (plan_steps.rs:174-219): matched terms -> text ids -> value ids of the 1:n object ->
-    // boost value and anchor of each value id (boost.rs:432-468), applied to the leaf's hits by anchor (boost.rs:255-281).
-    void emit_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b, std::vector<DOp>& ops, uint32_t& sp) {
+    // matched terms -> text ids -> value ids of the 1:n object -> (anchor, boost value) of every boosted value id (boost.rs:432-468)
+    std::vector<std::pair<uint32_t, float>> resolve_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b) {
         std::vector<uint32_t> ids;
         auto cit = idx.columns.find(part.path);
         const bool tokenized = cit != idx.columns.end() && cit->second.tokenize;
@@ -536,6 +547,28 @@ struct Compiler {
             const uint32_t *rb, *re;
             if (to_anchor.host_row(vid, &rb, &re)) pairs.push_back({*rb, v});
         }
+        return pairs;
+    }
+
+    // BoostToAnchor + ApplyAnchorBoost (plan_steps.rs:174-219): matched terms -> text ids -> value ids of the 1:n object ->
+    // boost value and anchor of each value id (boost.rs:432-468), applied to the leaf's hits by anchor (boost.rs:255-281).
+    void emit_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b, std::vector<DOp>& ops, uint32_t& sp) {
+        const std::string cache_key = part.key() + "|" + b.path;
+        std::shared_ptr<const std::vector<std::pair<uint32_t, float>>> cached;
+        if (boost_cache) {
+            std::lock_guard<std::mutex> g(boost_cache->mu);
+            auto it = boost_cache->map.find(cache_key);
+            if (it != boost_cache->map.end()) cached = it->second;
+        }
+        if (!cached) {
+            auto fresh = std::make_shared<std::vector<std::pair<uint32_t, float>>>(resolve_boost_1n(part, l, b));
+            cached = fresh;
+            if (boost_cache) {
+                std::lock_guard<std::mutex> g(boost_cache->mu);
+                boost_cache->map.emplace(cache_key, cached);
+            }
+        }
+        const std::vector<std::pair<uint32_t, float>>& pairs = *cached;  // (anchor, boost value) in value-id order
         bool several = false;
         for (size_t i = 1; i < pairs.size(); ++i) {
             if (pairs[i].first < pairs[i - 1].first) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
@@ -564,7 +597,7 @@ struct Compiler {
                 RangeJob job;
                 job.key = key;
                 job.store_path = l.path + TO_ANCHOR_ID_SCORE;
-                posting_store(l.path);
+                job.union_key = leaf_union_key(l);
                 for (auto& h : l.hits_scores) job.tokens.push_back(h.first);
                 for (size_t j = 0; j < anchors.size(); ++j) {
                     job.lo.push_back(anchors[j]);
@@ -1648,8 +1681,9 @@ void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& tabl
 }
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts,
-                            const RangeTable* ranges) {
+                            const RangeTable* ranges, Boost1nCache* boost_cache) {
     Compiler c(idx, req, fuzzy);
+    c.boost_cache = boost_cache;
     c.unions = unions;
     c.counts = counts;
     c.ranges = ranges;

@@ -165,10 +165,16 @@ struct RangeJob {
     std::string key;
     std::string store_path;          // "<field>.textindex.to_anchor_id_score"
     std::vector<uint32_t> tokens;    // the leaf's posting lists
+    std::string union_key;           // key of the leaf's union job when it asks to be materialised (the merged list is scanned instead)
     std::vector<uint32_t> lo, hi;    // doc ranges [lo, hi)
     std::vector<uint64_t> counts;    // result: leaf postings inside each range, summed over the shards
 };
 using RangeTable = std::map<std::string, RangeJob>;
+// (anchor, boost value) lists of 1:n field boosts resolved on the host, shared by the requests and compilation passes of one batch
+struct Boost1nCache {
+    std::mutex mu;
+    std::unordered_map<std::string, std::shared_ptr<const std::vector<std::pair<uint32_t, float>>>> map;
+};
 constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union jobs have run
 constexpr int kStatusNeedsCounts = -2; // internal: the compiled query IS a count pre-pass; compile again with its results
 constexpr int kStatusNeedsRanges = -3; // internal: compile again once the requested range jobs have run
@@ -402,8 +408,8 @@ struct CompiledQuery {
 };
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr,
-                            const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr);
-void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, hipStream_t st);
+                            const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr, Boost1nCache* boost_cache = nullptr);
+void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 
 // ------------------------------------------------------------------ results

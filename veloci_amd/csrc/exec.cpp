@@ -348,13 +348,22 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
 }  // namespace
 
 // Range jobs (k_range_hits): how many postings of a leaf fall into each requested doc range; summed over the shards.
-void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, hipStream_t st) {
+void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st) {
     std::vector<UList> ulists;
     std::vector<RangeTask> tasks;
     for (auto& kv : table) {
         RangeJob& job = kv.second;
         const PostingStore& ps = idx.postings.at(job.store_path);
         const uint32_t lb = uint32_t(ulists.size());
+        auto uit = job.union_key.empty() ? unions.end() : unions.find(job.union_key);
+        if (uit != unions.end()) {  // the leaf was materialised: its merged list holds exactly the leaf's hits
+            if (uit->second.len) {
+                UList u{};
+                u.docs = uit->second.d_docs;
+                u.len = uit->second.len;
+                ulists.push_back(u);
+            }
+        } else
         for (uint32_t tid : job.tokens) {
             if (tid >= ps.len.size() || !ps.len[tid]) continue;
             UList u{};
@@ -527,12 +536,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     pb->queries.reserve(n);
     pb->slot.assign(n, UINT32_MAX);
     pb->queries.resize(n);
+    Boost1nCache boost_cache;  // resolved 1:n boost lists, shared by the batch's requests and compilation passes
     auto compile_range = [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             if (!reqs[i]) {
                 pb->queries[i].status = ERR_INVALID_ARGUMENT;
                 pb->queries[i].error = "null request";
-            } else pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy);
+            } else pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy, nullptr, nullptr, nullptr, &boost_cache);
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
@@ -540,72 +550,56 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
-    double t_unions = t_pass1;
-    // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits)
-    RangeTable ranges;
-    {
-        std::vector<size_t> need;
-        for (size_t i = 0; i < n; ++i)
-            if (pb->queries[i].status == kStatusNeedsRanges) {
-                need.push_back(i);
-                for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
-            }
-        if (!need.empty()) {
-            if (idx.sharded() && !idx.can_sum_over_shards()) {
-                for (size_t i : need) {
-                    pb->queries[i].status = ERR_UNSUPPORTED;
-                    pb->queries[i].error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
-                }
-            } else {
-                run_range_jobs(idx, ws, ranges, st);
-                for (size_t i : need) {
-                    CompiledQuery& q = pb->queries[i];
-                    q = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy, nullptr, nullptr, &ranges);
-                    if (q.status == kStatusNeedsRanges) {
-                        q.status = ERR_UNSUPPORTED;
-                        q.error = "unsupported on the MI355X query path: boost list changed between compilation passes (internal)";
-                    }
-                }
-            }
-        }
-    }
-    const RangeTable* rangesp = ranges.empty() ? nullptr : &ranges;
-    // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch, compile those queries again
+    // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch
     UnionTable unions;
+    RangeTable ranges;
     std::vector<size_t> again;
+    bool any_ranges = false;
     for (size_t i = 0; i < n; ++i)
-        if (pb->queries[i].status == kStatusNeedsUnion) {
+        if (pb->queries[i].status == kStatusNeedsUnion || pb->queries[i].status == kStatusNeedsRanges) {
             again.push_back(i);
             for (auto& j : pb->queries[i].union_requests) unions.emplace(j.key, j);
+            for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
+            any_ranges = any_ranges || pb->queries[i].status == kStatusNeedsRanges;
         }
+    double t_unions = t_pass1, t_ranges = t_pass1;
     if (!again.empty()) {
-        run_union_jobs(idx, ws, unions, st);
-        {  // merged lengths over all shards (the AND summation order follows them)
+        if (!unions.empty()) {
+            run_union_jobs(idx, ws, unions, st);
+            // merged lengths over all shards (the AND summation order follows them)
             std::vector<uint64_t> lens;
             for (auto& kv : unions) lens.push_back(kv.second.len);
             if (idx.can_sum_over_shards()) idx.sum_over_shards(lens);
             size_t k = 0;
             for (auto& kv : unions) kv.second.global_len = lens[k++];
         }
-        t_unions = now_ms();
+        t_unions = t_ranges = now_ms();
+        // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits,
+        //      on the merged list of a materialised leaf)
+        const bool ranges_ok = !any_ranges || !idx.sharded() || idx.can_sum_over_shards();
+        if (any_ranges && ranges_ok) run_range_jobs(idx, ws, ranges, unions, st);
+        t_ranges = now_ms();
         auto recompile = [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
                 CompiledQuery& q = pb->queries[again[k]];
-                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, &unions, nullptr, rangesp);
-                if (q.status == kStatusNeedsUnion) {
+                if (q.status == kStatusNeedsRanges && !ranges_ok) {
+                    q.status = ERR_UNSUPPORTED;
+                    q.error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
+                    continue;
+                }
+                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, nullptr, ranges.empty() ? nullptr : &ranges, &boost_cache);
+                if (q.status == kStatusNeedsUnion || q.status == kStatusNeedsRanges) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
                 }
             }
         };
-        if (again.size() >= 64) {
-            const size_t nt = 4;
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < nt; ++t) th.emplace_back(recompile, again.size() * t / nt, again.size() * (t + 1) / nt);
-            recompile(0, again.size() / nt);
-            for (auto& t : th) t.join();
+        if (again.size() >= 32) {
+            const size_t parts = std::min<size_t>(8, again.size() / 8);
+            host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
         } else recompile(0, again.size());
     }
+    const RangeTable* rangesp = ranges.empty() ? nullptr : &ranges;
     // ---- ANDs whose summation order / label follow run-time operand sizes: count pre-pass, then the final compilation
     {
         std::vector<size_t> need;
@@ -639,7 +633,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             }
             for (size_t k = 0; k < need.size(); ++k) {
                 CompiledQuery& q = pb->queries[need[k]];
-                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k], rangesp);
+                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k], rangesp, &boost_cache);
                 if (q.status < 0) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: query still needs a pre-pass after the count pre-pass (internal)";
@@ -881,9 +875,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
-        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), %zu range jobs, pack+launch %.3f ms\n", n,
-                     t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_unions, ranges.size(),
-                     now_ms() - t_compiled);
+        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], pack+launch %.3f ms\n", n,
+                     t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
+                     t_ranges - t_unions, ranges.size(), now_ms() - t_compiled);
     return pb;
 }
 
