@@ -2,7 +2,8 @@
 five field leaves with per-leaf anchor-level and 1:n boosts, prefix match on the kanji / kana fields) on a JMdict-like synthetic
 corpus of 166 600 entries (bench_jmdict.rs:373; jmdict.json itself is a git-lfs pointer in the reference), index configuration of
 veloci_bins/src/bin/create_test_index.rs:33-69.  Prints queries/s of batches through the C ABI, single-request p50, and the CPU
-oracle (C++ restatement of the reference algorithm, not the Rust binary) on the same requests, one thread."""
+oracle (C++ restatement of the reference algorithm, not the Rust binary) on the same requests, one thread.
+Lives under tests/ because it links the oracle (test infrastructure); run it as `python tests/bench_jmdict_shape.py`."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -113,5 +114,5 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     main()
