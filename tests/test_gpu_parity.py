@@ -686,6 +686,35 @@ def test_single_requests_split_into_many_spans_merge_exactly(big_corpus):
                 assert_same(req, got, want, exact_scores="boost" not in req)  # (Log10: device log vs glibc, 1e-5)
 
 
+def test_full_size_index_matches_the_oracle():
+    """BASELINE.json's full size on one GPU: the bench's 100 M-doc index (one probe triple, all side stores), every bench request
+    shape once as a single request (many spans) and once inside a batch, against the CPU oracle on the same arrays; plus the
+    index cut into two doc-range shards."""
+    import veloci_amd
+    from veloci_amd import synth
+    from oracle import binding as O
+    from parity import assert_same
+    spec = synth.SynthSpec(num_docs=100_000_000, num_terms=20_000, triples=2, background_terms=0)
+    data, meta = synth.generate(spec)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    a, b = list(meta.triples[0]), list(meta.triples[1])
+    reqs = [synth.req_and(a), synth.req_or(a), synth.req_single(a[0]), synth.req_single(a[2], top=100), synth.req_and_phrase_locality(a),
+            synth.req_and_of_ors([a[0], a[1]], [a[2], b[2]]), dict(synth.req_and(a[1:]), facets=[{"field": "cat"}, {"field": "tags[]", "top": 5}]),
+            {"search_req": {"or": {"queries": [{"search": {"path": "body", "terms": [t]}} for t in a + b]}}, "top": 10},
+            dict(synth.req_or(a[1:]), filter={"search": {"path": "body", "terms": [b[2]]}}, skip=5)]
+    wants = [ora.search_json(json.dumps(r)) for r in reqs]
+    exact = lambda r: "boost" not in r
+    for r, w in zip(reqs, wants):
+        assert_same(r, veloci_amd.search(r, idx), w, exact_scores=exact(r))
+    for r, g, w in zip(reqs, veloci_amd.search_batch(reqs * 8, idx), wants * 8):
+        assert_same(r, g, w, exact_scores=exact(r))
+    for r, g, w in zip(reqs, _search_batch_over_shards(data, reqs, 2), wants):
+        assert not isinstance(g, Exception), (str(g), json.dumps(r))
+        assert_same(r, g, w, exact_scores=exact(r))
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))
