@@ -715,6 +715,82 @@ def test_full_size_index_matches_the_oracle():
         assert_same(r, g, w, exact_scores=exact(r))
 
 
+def test_degenerate_inputs(corpus):
+    """Empty batch, top 0, skip beyond the hits, a one-document index, an index without documents, a shard that holds no posting of
+    the query — against the oracle where it has an answer."""
+    import veloci_amd
+    from veloci_amd import mini_indexer, synth
+    from oracle import binding as O
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    assert veloci_amd.search_batch([], idx) == []
+    a = list(meta.triples[0])
+    for req in (dict(synth.req_and(a), top=0), dict(synth.req_or(a), top=0, skip=3), dict(synth.req_and(a), skip=10**6),
+                dict(synth.req_single(a[0]), top=1, skip=10**7), dict(synth.req_and(a), top=0, facets=[{"field": "cat"}])):
+        assert_same(req, veloci_amd.search(req, idx), ora.search_json(json.dumps(req)))
+    # one document / no document
+    for docs in ([{"title": "lonely word", "tags": ["x"]}], []):
+        d1, info = mini_indexer.build_index(docs, {"title": {"fulltext": {"tokenize": True}}, "tags[]": {"facet": True}})
+        i1 = veloci_amd.Index(d1, device=0)
+        o1 = O.OracleIndex(d1.num_anchors)
+        d1.load_into(o1)
+        for req in ({"search_req": {"search": {"path": "title", "terms": ["lonely"]}}, "facets": [{"field": "tags[]"}]},
+                    {"search_req": {"and": {"queries": [{"search": {"path": "title", "terms": ["lonely"]}}, {"search": {"path": "title", "terms": ["word"]}}]}}},
+                    {"search_req": {"search": {"path": "title", "terms": ["lonly"], "levenshtein_distance": 1}}},
+                    {"search_req": {"search": {"path": "title", "terms": ["absent"]}}}):
+            js = json.dumps(req)
+            try:
+                want = o1.search_json(js)
+            except O.OracleError as e:
+                with pytest.raises(veloci_amd.VelociError) as g:
+                    veloci_amd.search(req, i1)
+                assert str(g.value) == str(e), js
+                continue
+            assert_same(req, veloci_amd.search(req, i1), want)
+    # a shard whose doc range holds none of the sparse probe's postings still merges to the unsharded answer
+    probe = meta.extra_probes[0]  # df 1000 of 300k docs
+    reqs = [synth.req_single(probe), dict(synth.req_and([a[0], probe])), dict(synth.req_or([probe, a[2]]), top=20)]
+    for r, g in zip(reqs, _search_batch_over_shards(data, reqs, 7)):
+        assert not isinstance(g, Exception), (str(g), json.dumps(r))
+        assert_same(r, g, ora.search_json(json.dumps(r)))
+
+
+def test_deep_paging_beyond_one_scan(big_corpus):
+    """top + skip above what one scan ranks (1024): the request runs as a chain of pages, each scan ranking only what lies below
+    the previous page's last key; window, num_hits and facets equal the oracle's.  Through vq_search, vq_search_batch and the
+    flat entry point; the sharded merge path declines."""
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    data, meta, idx, ora = big_corpus
+    a, b = list(meta.triples[0]), list(meta.triples[1])
+    shapes = [synth.req_and(a), synth.req_or(a), synth.req_single(a[1]), synth.req_and_phrase_locality(a),
+              {"search_req": {"or": {"queries": [{"search": {"path": "body", "terms": [t]}} for t in a + b[:2]]}}},
+              dict(synth.req_and(a[:2]), facets=[{"field": "cat", "top": 4}])]
+    reqs = []
+    for i, shape in enumerate(shapes):
+        for top, skip in ((1500, 0), (10, 3000), (2000, 1000), (7, 1024), (1025, 0), (5, 10**7)):
+            if (i + top + skip) % 2 == 0 or skip > 10**6:
+                reqs.append(dict(shape, top=top, skip=skip))
+    wants = [ora.search_json(json.dumps(r)) for r in reqs]
+    for r, w in zip(reqs[::3], wants[::3]):
+        assert_same(r, veloci_amd.search(r, idx), w)
+    for r, g, w in zip(reqs, veloci_amd.search_batch(reqs, idx), wants):
+        assert_same(r, g, w)
+    plain = [(r, w) for r, w in zip(reqs, wants) if "facets" not in r and r["top"] <= 2000]
+    num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat([r for r, _ in plain], idx, stride=2000)
+    assert not status.any()
+    for k, (r, w) in enumerate(plain):
+        assert int(num_hits[k]) == w.num_hits and list(ids[k, :counts[k]]) == list(w.ids), json.dumps(r)
+        assert np.array_equal(scores[k, :counts[k]].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
+    # more ranked hits than 64 scans reach: declined, not truncated
+    with pytest.raises(veloci_amd.VelociError) as e:
+        veloci_amd.search(dict(synth.req_or(a), top=10, skip=70000), idx)
+    assert e.value.kind == "Unsupported" and "ranked hits" in str(e.value)
+    got = _search_batch_over_shards(data, [dict(synth.req_and(a), top=1500), synth.req_and(a)], 2)
+    assert isinstance(got[0], veloci_amd.VelociError) and got[0].kind == "Unsupported" and not isinstance(got[1], Exception)
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))

@@ -256,11 +256,14 @@ void vq_result_free(vq_result* r) { delete r; }
 static int run_batch(const vq_index* index, const vq_request* const* requests, size_t n, vq_result** out, int* status, std::string* first_error) {
     std::vector<const Request*> reqs(n);
     for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
-    auto pb = run_partial(*index->idx, reqs.data(), n);
     std::vector<std::unique_ptr<Result>> results;
     std::vector<int> st;
     std::vector<std::string> errs;
-    finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
+    {
+        auto pb = run_partial(*index->idx, reqs.data(), n);
+        finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
+    }  // (the batch's workspace is free again: deep requests scan on)
+    complete_deep_requests(*index->idx, reqs.data(), n, results, st, errs);
     for (size_t i = 0; i < n; ++i) {
         out[i] = nullptr;
         if (status) status[i] = st[i];
@@ -333,6 +336,21 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
         for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
         // Large batches run as a software pipeline of chunks over the index's two workspaces: while the GPU scans chunk c
         // the host compiles chunk c+1, and chunk c-1's merge + download run on the finish stream.
+        bool any_deep = false;  // top + skip beyond one scan's ranking: such requests page on after their batch (not pipelined)
+        for (size_t i = 0; i < n; ++i)
+            if (reqs[i]) any_deep = any_deep || uint64_t(reqs[i]->top.value_or(10)) + uint64_t(reqs[i]->skip.value_or(0)) > uint64_t(vq::kMaxTopK);
+        if (any_deep) {
+            std::vector<std::unique_ptr<Result>> results;
+            std::vector<int> st;
+            std::vector<std::string> errs;
+            {
+                auto pb = run_partial(*index->idx, reqs.data(), n);
+                finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
+            }
+            complete_deep_requests(*index->idx, reqs.data(), n, results, st, errs);
+            copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
+            return;
+        }
         const size_t nchunks = n >= 512 ? 4 : 1;
         std::vector<std::unique_ptr<PartialBatch>> inflight(nchunks);
         auto bounds = [&](size_t c) { return std::make_pair(n * c / nchunks, n * (c + 1) / nchunks); };
@@ -372,6 +390,16 @@ int vq_search_batch_partial(const vq_index* index, const vq_request* const* requ
 size_t vq_partial_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.bytes) : 0; }
 void* vq_partial_device_ptr(vq_partial_batch* p) { return p ? p->pb->d_partial : nullptr; }
 
+// the sharded path ranks top + skip <= kMaxTopK per request: paging a deep request would need the merged result of every page on all ranks
+static void decline_deep(std::vector<std::unique_ptr<Result>>& results, std::vector<int>& st, std::vector<std::string>& errs) {
+    for (size_t i = 0; i < results.size(); ++i)
+        if (st[i] == 0 && results[i] && results[i]->deep) {
+            st[i] = VQ_ERR_UNSUPPORTED;
+            errs[i] = "unsupported on the MI355X query path: top + skip > " + std::to_string(vq::kMaxTopK) + " on the sharded partial / merge path";
+            results[i].reset();
+        }
+}
+
 int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, vq_result** out, int* status) {
     return guard([&] {
         if (!index || !local || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_merge_partials: null argument");
@@ -379,6 +407,7 @@ int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void
         std::vector<int> st;
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
+        decline_deep(results, st, errs);
         for (size_t i = 0; i < results.size(); ++i) {
             out[i] = nullptr;
             if (status) status[i] = st[i];
@@ -398,6 +427,7 @@ int vq_merge_partials_flat(const vq_index* index, vq_partial_batch* local, const
         std::vector<int> st;
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
+        decline_deep(results, st, errs);
         copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
     });
 }

@@ -1229,11 +1229,17 @@ struct Compiler {
         if (req.explain) unsupported("explain");
         if (req.has_suggest) unsupported("suggest");
         if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
-        cq.top = uint32_t(req.top.value_or(10));  // :146
-        cq.skip = uint32_t(req.skip.value_or(0));
-        const uint64_t want = uint64_t(cq.top) + cq.skip;
-        if (want > uint64_t(kMaxTopK)) unsupported("top + skip > " + std::to_string(kMaxTopK));
-        cq.top_k = uint32_t(std::max<uint64_t>(want, 1));
+        const uint64_t top64 = req.top.value_or(10), skip64 = req.skip.value_or(0);  // :146
+        const uint64_t want = top64 + skip64 < top64 ? ~0ull : top64 + skip64;
+        cq.top = uint32_t(std::min<uint64_t>(top64, kMaxTopK));
+        cq.skip = uint32_t(std::min<uint64_t>(skip64, kMaxTopK));
+        cq.key_upper = req.key_upper;
+        if (want > uint64_t(kMaxTopK)) {  // deep request: rank the best kMaxTopK here, the caller pages on below the last key
+            cq.deep = true;
+            cq.top = uint32_t(kMaxTopK);
+            cq.skip = 0;
+        }
+        cq.top_k = uint32_t(std::max<uint64_t>(uint64_t(cq.top) + cq.skip, 1));
 
         // collect_all_field_request_into_cache (execution_plan.rs:91-106), then the flags set during plan creation
         if (req.phrase_boosts)

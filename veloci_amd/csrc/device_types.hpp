@@ -155,6 +155,7 @@ struct QHeader {
     uint64_t prune_mask;     // the leaf lists of the score tree
     unsigned long long gthr; // written by the kernels: the best top-k threshold any span of this query has reached so far (atomicMax);
                              // every span may drop docs below it — some span alone already holds top_k better ones
+    unsigned long long key_upper;  // only keys BELOW this enter the top-k (~0: no bound): page p of a deep request ranks what lies below the last key of page p-1
     uint32_t seq_tiles;      // k_tile_scan: a dense list is in the cover -> every tile of the span is visited, dense lists are copied from
                              // their bitmap images (their LIST_COVER flag is dropped)
     uint32_t pad2;

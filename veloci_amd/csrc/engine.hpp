@@ -403,6 +403,8 @@ struct CompiledQuery {
     uint32_t top = 10, skip = 0, top_k = 10;
     uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
     uint64_t algorithmic_bytes = 0;
+    uint64_t key_upper = ~0ull;  // QHeader::key_upper
+    bool deep = false;           // top + skip > kMaxTopK: this compilation ranks the first kMaxTopK only; the caller pages on (search_pages)
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
     uint32_t max_spans = 1;  // tiles of the query's doc range (<= 4096): a small batch splits its queries further, up to this (exec.cpp)
 };
@@ -411,6 +413,11 @@ CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const F
                             const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr, Boost1nCache* boost_cache = nullptr);
 void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
+struct Result;
+// Deep requests (top + skip > kMaxTopK) of an unsharded batch: results[i] holds page 0; fetch the following pages (each one scan that
+// ranks only keys below the previous page's last) and cut the requested window.
+void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
+                            std::vector<int>& status, std::vector<std::string>& errors);
 
 // ------------------------------------------------------------------ results
 struct ResultFacet {
@@ -424,6 +431,7 @@ struct Result {
     std::vector<float> scores;
     std::vector<ResultFacet> facets;
     bool has_facets = false;
+    bool deep = false;  // holds the first page of a deep request (see CompiledQuery::deep)
     mutable std::string json;
 };
 

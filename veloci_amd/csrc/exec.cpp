@@ -119,6 +119,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.n_counts = cq.n_counts;
     h.prune_n = cq.prune_n;
     h.seq_tiles = cq.seq_tiles;
+    h.key_upper = cq.key_upper;
     h.prune_mask = cq.prune_mask;
     std::memcpy(h.prune_gbits, cq.prune_gbits, sizeof h.prune_gbits);
     h.simple_n = cq.simple_n;
@@ -881,6 +882,63 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     return pb;
 }
 
+void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
+                            std::vector<int>& status, std::vector<std::string>& errors) {
+    constexpr uint64_t kMaxDeep = 65536;  // ranked hits one request may reach (64 scans)
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] != 0 || !results[i] || !results[i]->deep) continue;
+        const vqreq::Request& R = *reqs[i];
+        Result& out = *results[i];
+        out.deep = false;
+        const uint64_t top = R.top.value_or(10), skip = R.skip.value_or(0);
+        const uint64_t want = top + skip < top ? ~0ull : top + skip;
+        std::vector<uint32_t> ids = std::move(out.ids);  // page 0: the best kMaxTopK
+        std::vector<float> scores = std::move(out.scores);
+        out.ids.clear();
+        out.scores.clear();
+        if (skip >= out.num_hits) continue;  // apply_top_skip (search.rs:230-239): nothing left behind the skipped hits
+        const uint64_t reach = std::min<uint64_t>(want, out.num_hits);
+        if (reach > kMaxDeep) {
+            status[i] = ERR_UNSUPPORTED;
+            errors[i] = "unsupported on the MI355X query path: top + skip reaches more than " + std::to_string(kMaxDeep) + " ranked hits";
+            results[i].reset();
+            continue;
+        }
+        vqreq::Request page = R;
+        page.top = size_t(kMaxTopK);
+        page.skip = 0;
+        page.facets.reset();  // (counted by page 0)
+        bool failed = false;
+        while (ids.size() < reach && ids.size() % size_t(kMaxTopK) == 0 && !ids.empty()) {
+            uint32_t bits;
+            std::memcpy(&bits, &scores.back(), 4);
+            page.key_upper = (uint64_t(order_f32(bits)) << 32) | ids.back();
+            const vqreq::Request* arr[1] = {&page};
+            std::vector<std::unique_ptr<Result>> r;
+            std::vector<int> st;
+            std::vector<std::string> er;
+            {
+                auto pb = run_partial(idx, arr, 1);
+                finish_batch(idx, *pb, nullptr, 1, r, st, er);
+            }
+            if (st[0] != 0) {
+                status[i] = st[0];
+                errors[i] = er[0];
+                results[i].reset();
+                failed = true;
+                break;
+            }
+            if (r[0]->ids.empty()) break;
+            ids.insert(ids.end(), r[0]->ids.begin(), r[0]->ids.end());
+            scores.insert(scores.end(), r[0]->scores.begin(), r[0]->scores.end());
+        }
+        if (failed) continue;
+        const size_t from = size_t(std::min<uint64_t>(skip, ids.size())), to = size_t(std::min<uint64_t>(want, ids.size()));
+        out.ids.assign(ids.begin() + from, ids.begin() + to);
+        out.scores.assign(scores.begin() + from, scores.begin() + to);
+    }
+}
+
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
                   std::vector<int>& status, std::vector<std::string>& errors) {
     const size_t n = pb.queries.size();
@@ -960,6 +1018,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         const uint32_t to = std::min(avail, from + cq.top);
         r->ids.assign(ids + from, ids + to);
         r->scores.assign(scores + from, scores + to);
+        r->deep = cq.deep;
         key_off += cq.top_k;
         if (!cq.facet_out.empty()) r->has_facets = true;
         for (size_t f = 0; f < cq.facet_out.size(); ++f, ++job) {

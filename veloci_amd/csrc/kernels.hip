@@ -130,6 +130,7 @@ struct CandState {
     unsigned long long* thr;   // keys <= thr cannot enter the top-k any more
     uint32_t cap;              // power of two, >= 2 * k
     unsigned long long* gthr = nullptr;  // the query's threshold word in HBM, shared by all of its spans (QHeader::gthr)
+    unsigned long long upper = ~0ull;    // keys at or above this never enter (QHeader::key_upper: pages of a deep request)
 };
 
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, uint32_t src_lane) {
@@ -589,6 +590,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     uint16_t* pre = reinterpret_cast<uint16_t*>(bm + (L + H->n_temps) * WW);
     CandState cs{cand, cand_n, thr, cand_cap,
                  reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blobs) + blob_off[q] + offsetof(QHeader, gthr))};
+    cs.upper = H->key_upper;
     uint32_t tiles_done = 0;
 
     // ---- span of the doc-id space owned by this workgroup
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             while (true) {
                 while (true) {
                     if (pending) {
-                        if (pend_key > *thr) {
+                        if (pend_key > *thr) {  // (pend_key < key_upper was checked when it was set aside)
                             uint32_t pos = atomicAdd(cand_n, 1u);
                             if (pos < cand_cap) {
                                 cand[pos] = pend_key;
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #endif
                     score = sink_stages(sc, score, doc, w, b);
                     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
-                    if (key > *thr) {
+                    if (key > *thr && key < cs.upper) {
                         uint32_t pos = atomicAdd(cand_n, 1u);
                         if (pos < cand_cap) cand[pos] = key;
                         else {
@@ -1329,7 +1331,7 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
         score = sum * nd * nd;
     }
     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
-    bool pending = have && key > *cs.thr;
+    bool pending = have && key > *cs.thr && key < cs.upper;
     while (true) {
         if (pending) {
             if (key > *cs.thr) {
@@ -1505,7 +1507,7 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
         }
     }
     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
-    bool pending = have && key > *cs.thr;
+    bool pending = have && key > *cs.thr && key < cs.upper;
     while (true) {
         if (pending) {
             if (key > *cs.thr) {
@@ -1642,6 +1644,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) bslot[k] = (uint32_t)__popc(~sflags & ((1u << k) - 1u) & 0xFu) * SWW;
     CandState cs{cand, cand_n, thr, cand_cap, reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr))};
+    cs.upper = H->key_upper;
     uint32_t tiles_done = 0;
 
     const uint32_t n_spans = H->n_spans;
@@ -2313,6 +2316,7 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
     uint32_t* bm = lds + 8 + 2 * cand_cap;                                  // [4][kUTW]
     uint16_t* val = reinterpret_cast<uint16_t*>(bm + 4 * kUTW);            // [4][kUT]
     CandState cs{cand, cand_n, thr, cand_cap};
+    cs.upper = H->key_upper;
 
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
@@ -2419,7 +2423,7 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
                             const uint32_t raw = j == 0 ? (s4[u].x & 0xFFFFu) : j == 1 ? (s4[u].x >> 16) : j == 2 ? (s4[u].y & 0xFFFFu) : (s4[u].y >> 16);
                             const float score = posting_value_fast(ts[0], (uint16_t)raw);
                             const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)comp4(d4[u], j);
-                            union_push(pass[u * 4 + j] && key > *thr, key, cs, top_k);
+                            union_push(pass[u * 4 + j] && key > *thr && key < cs.upper, key, cs, top_k);
                         }
                     }
                 }
@@ -2576,7 +2580,7 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
                             const float score = sum * nd * nd;
                             key[j] = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)d;
                             fresh += live ? 1u : 0u;
-                            pend[j] = live && key[j] > thr_reg;
+                            pend[j] = live && key[j] > thr_reg && key[j] < cs.upper;
                         }
                         uint32_t round_fresh;
                         (void)wave_excl_scan_u32(fresh, &round_fresh);

@@ -89,6 +89,9 @@ struct Request {  // src/search/request/mod.rs:15-87
     bool why_found = false;
     bool text_locality = false;
     bool explain = false;
+    // internal, never parsed: only hits ranking BELOW this key are returned (~0: no bound) — page p of a deep request (top + skip beyond
+    // what one scan ranks) asks for what lies below the last key of page p-1
+    uint64_t key_upper = ~0ull;
 };
 
 
