@@ -791,6 +791,32 @@ def test_deep_paging_beyond_one_scan(big_corpus):
     assert isinstance(got[0], veloci_amd.VelociError) and got[0].kind == "Unsupported" and not isinstance(got[1], Exception)
 
 
+def test_wide_nodes_up_to_16_operands(corpus):
+    """The query generator ORs one leaf per (term, field): and / or nodes take up to 16 operands (DOp::child_slot / and_order)."""
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    terms = [t for tri in meta.triples for t in tri] + list(meta.extra_probes) + list(meta.background[:12])
+    leaf = lambda t, **kw: {"search": dict({"path": "body", "terms": [t]}, **kw)}
+    reqs = [
+        {"search_req": {"or": {"queries": [leaf(t) for t in terms[:12]]}}, "top": 20},
+        {"search_req": {"or": {"queries": [leaf(t) for t in terms[:16]]}}, "top": 10, "skip": 3},
+        {"search_req": {"or": {"queries": [leaf(t, boost=1.0 + 0.25 * i) for i, t in enumerate(terms[3:16])]}}},
+        {"search_req": {"and": {"queries": [{"or": {"queries": [leaf(t) for t in terms[:9]]}}, {"or": {"queries": [leaf(t) for t in terms[9:16]]}}]}}, "top": 15},
+        {"search_req": {"or": {"queries": [{"and": {"queries": [leaf(terms[0]), leaf(terms[1])]}}] + [leaf(t) for t in terms[2:14]]}}},
+        {"search_req": {"and": {"queries": [leaf(meta.triples[0][0])] + [{"or": {"queries": [leaf(t), leaf(meta.triples[0][1])]}} for t in terms[6:16]]}}},
+        {"search_req": {"or": {"queries": [leaf(t) for t in terms[:14]]}}, "filter": {"or": {"queries": [leaf(t) for t in terms[4:15]]}}, "facets": [{"field": "cat"}]},
+    ]
+    for req in reqs:
+        assert_same(req, veloci_amd.search(req, idx), ora.search_json(json.dumps(req)))
+    for req, g in zip(reqs, veloci_amd.search_batch(reqs, idx)):
+        assert_same(req, g, ora.search_json(json.dumps(req)))
+    with pytest.raises(veloci_amd.VelociError) as e:
+        veloci_amd.search({"search_req": {"or": {"queries": [leaf(t) for t in terms[:17]]}}}, idx)
+    assert e.value.kind == "Unsupported"  # (declined, never truncated: the evaluation stack holds 16 operands)
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))

@@ -20,7 +20,7 @@ constexpr int kBlock = 64;          // threads per workgroup: ONE wave (no cross
 constexpr int kCandCap = 2048;      // LDS candidate buffer (u64 keys) per workgroup
 constexpr int kMaxTopK = 1024;      // top + skip supported in-kernel
 constexpr int kStackDepth = 16;     // deepest postfix evaluation stack (LDS is sized to the batch's real depth)
-constexpr int kMaxChildren = 8;     // children per AND/OR node
+constexpr int kMaxChildren = 16;    // children per AND/OR node (the query generator ORs one leaf per term and field)
 constexpr int kMaxLists = 64;       // lists per query in one launch
 constexpr int kMaxOps = 160;
 constexpr int kMaxSkipWhen = 4;
@@ -46,7 +46,7 @@ struct DList {  // 48 B
 
 enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2, OP_BOOST1N = 3 };  // OP_BOOST1N: unary, 1:n field boost of the leaf below (list_begin = anchors + f32 values, child_slot[0] = index into cols)
 
-struct DOp {  // 24 B
+struct DOp {  // 40 B
     uint8_t kind;
     uint8_t nchild;
     uint8_t nslots;  // OR: number of distinct term slots (set_op.rs:122-124)

@@ -72,25 +72,27 @@ __device__ __forceinline__ const VQ_CONST T* as_const(const void* p) {
     return (const VQ_CONST T*)(uintptr_t)p;
 }
 
-// A DOp fetched as six dwords through the constant address space (scalar loads), fields decoded with scalar shifts.
+// A DOp fetched as ten dwords through the constant address space (scalar loads), fields decoded with scalar shifts.
 struct KOp {
     uint32_t r0, r1;
-    unsigned long long slots, order;
+    unsigned long long slots[2], order[2];
     __device__ __forceinline__ explicit KOp(const VQ_CONST DOp* p) {
-        static_assert(sizeof(DOp) == 24, "DOp layout");
+        static_assert(sizeof(DOp) == 40 && kMaxChildren == 16, "DOp layout");
         const VQ_CONST uint32_t* w = (const VQ_CONST uint32_t*)p;
         r0 = w[0];
         r1 = w[1];
-        slots = ((unsigned long long)w[3] << 32) | w[2];
-        order = ((unsigned long long)w[5] << 32) | w[4];
+        slots[0] = ((unsigned long long)w[3] << 32) | w[2];
+        slots[1] = ((unsigned long long)w[5] << 32) | w[4];
+        order[0] = ((unsigned long long)w[7] << 32) | w[6];
+        order[1] = ((unsigned long long)w[9] << 32) | w[8];
     }
     __device__ __forceinline__ uint32_t kind() const { return r0 & 0xFFu; }
     __device__ __forceinline__ uint32_t nchild() const { return (r0 >> 8) & 0xFFu; }
     __device__ __forceinline__ uint32_t nslots() const { return (r0 >> 16) & 0xFFu; }
     __device__ __forceinline__ uint32_t list_begin() const { return r1 & 0xFFFFu; }
     __device__ __forceinline__ uint32_t list_count() const { return r1 >> 16; }
-    __device__ __forceinline__ uint32_t child_slot(uint32_t k) const { return (uint32_t)(slots >> (8u * k)) & 0xFFu; }
-    __device__ __forceinline__ uint32_t and_order(uint32_t k) const { return (uint32_t)(order >> (8u * k)) & 0xFFu; }
+    __device__ __forceinline__ uint32_t child_slot(uint32_t k) const { return (uint32_t)((k < 8u ? slots[0] : slots[1]) >> (8u * (k & 7u))) & 0xFFu; }
+    __device__ __forceinline__ uint32_t and_order(uint32_t k) const { return (uint32_t)((k < 8u ? order[0] : order[1]) >> (8u * (k & 7u))) & 0xFFu; }
 };
 
 // ------------------------------------------------------------------------------------ wave helpers
