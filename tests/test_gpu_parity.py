@@ -728,6 +728,14 @@ def test_degenerate_inputs(corpus):
     for req in (dict(synth.req_and(a), top=0), dict(synth.req_or(a), top=0, skip=3), dict(synth.req_and(a), skip=10**6),
                 dict(synth.req_single(a[0]), top=1, skip=10**7), dict(synth.req_and(a), top=0, facets=[{"field": "cat"}])):
         assert_same(req, veloci_amd.search(req, idx), ora.search_json(json.dumps(req)))
+    # facet with top: null reports every counted value (up to 1024 distinct values; beyond that it declines)
+    req = dict(synth.req_and(a[:2]), facets=[{"field": "cat", "top": None}])
+    got, want = veloci_amd.search(req, idx), ora.search_json(json.dumps(req))
+    assert_same(req, got, want)
+    assert len(dict(got.facets)["cat"]) > 10
+    with pytest.raises(veloci_amd.VelociError) as e:
+        veloci_amd.search(dict(synth.req_and(a[:2]), facets=[{"field": "tags[]", "top": None}]), idx)
+    assert e.value.kind == "Unsupported"
     # one document / no document
     for docs in ([{"title": "lonely word", "tags": ["x"]}], []):
         d1, info = mini_indexer.build_index(docs, {"title": {"fulltext": {"tokenize": True}}, "tags[]": {"facet": True}})
