@@ -38,7 +38,7 @@ enum {
     /* VelociError::StringError("Did not found path in indices ...") (src/persistence.rs:454-458) */
     VQ_ERR_INDEX_NOT_FOUND = 3,
     /* request uses a feature outside the GPU hot path (select, why_found, snippet, regex, suggest,
-       token_value, explain): never silently ignored */
+       explain): never silently ignored */
     VQ_ERR_UNSUPPORTED = 4,
     /* HIP runtime failure / no device / extension missing */
     VQ_ERR_DEVICE = 5,

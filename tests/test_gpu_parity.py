@@ -825,6 +825,39 @@ def test_wide_nodes_up_to_16_operands(corpus):
     assert e.value.kind == "Unsupported"  # (declined, never truncated: the evaluation stack holds 16 operands)
 
 
+def test_token_value_boost_shapes_the_term_scores():
+    """RequestSearchPart.token_value (search_field.rs:391-395): a boost column keyed by TERM id (token_values store, built as
+    create/token_values_to_tokens.rs does for the reference's test corpus: "Begeisterung" -> 20 on meanings.ger[]) multiplies /
+    adds into the matched terms' scores before their postings are read."""
+    import veloci_amd
+    from veloci_amd import mini_indexer
+    from oracle import binding as O
+    from parity import assert_same
+    c = refcases.load()["corpora"]["test_all"]
+    docs = refcases.corpus_docs(c)
+    tv = ([{"text": "Begeisterung", "value": 20}, {"text": "welle", "value": 3.5}, {"text": "nothere", "value": 9}, {"text": "der", "value": None}], "meanings.ger[]")
+    data, info = mini_indexer.build_index(docs, c["indices"], token_values=tv)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    ran = 0
+    for term, lev in (("begeisterung", 0), ("begeisterung", 1), ("welle", 0), ("majestät", 1), ("der", 0)):
+        for tvb in ({"path": "meanings.ger[]", "boost_fun": "Multiply", "param": 0}, {"path": "meanings.ger[]", "boost_fun": "Log10", "param": 1},
+                    {"path": "meanings.ger[]", "boost_fun": "Add", "param": 2, "skip_when_score": [10.0]}, {"path": "meanings.ger[]", "expression": "$SCORE * 2"}):
+            leaf = {"path": "meanings.ger[]", "terms": [term], "levenshtein_distance": lev, "token_value": tvb}
+            for req in ({"search_req": {"search": leaf}},
+                        {"search_req": {"or": {"queries": [{"search": leaf}, {"search": {"path": "meanings.eng[]", "terms": ["will"]}}]}}, "top": 20}):
+                want = ora.search_json(json.dumps(req))
+                assert_same(req, veloci_amd.search(req, idx), want, exact_scores=True)
+                ran += 1
+    assert ran == 40
+    with pytest.raises(veloci_amd.VelociError) as e:  # a field without token values: the reference fails on the missing index
+        veloci_amd.search({"search_req": {"search": {"path": "meanings.eng[]", "terms": ["will"], "token_value": {"path": "meanings.eng[]", "boost_fun": "Multiply"}}}}, idx)
+    with pytest.raises(O.OracleError) as eo:
+        ora.search_json(json.dumps({"search_req": {"search": {"path": "meanings.eng[]", "terms": ["will"], "token_value": {"path": "meanings.eng[]", "boost_fun": "Multiply"}}}}))
+    assert str(e.value) == str(eo.value)
+
+
 def test_random_requests_on_synthetic_corpus_match_the_oracle(corpus):
     """Random trees over the 300k-doc synthetic corpus: dense lists (bitmap images), several spans per query, OR pruning, count pre-passes."""
     _random_synthetic(corpus, n_requests=240, seed=int(os.environ.get("VQ_TEST_SEED", "991")))

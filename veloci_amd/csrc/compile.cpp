@@ -202,7 +202,6 @@ struct Compiler {
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
         const RequestSearchPart& p = l.part;
         if (p.is_regex) unsupported("is_regex");
-        if (p.token_value) unsupported("token_value");
         if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
         if (p.options && p.options->explain) unsupported("explain");
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
@@ -280,6 +279,37 @@ struct Compiler {
             if (l.hits_scores.size() > top_n_search) l.hits_scores.resize(top_n_search);
         }
     }
+    // token_value (search_field.rs:391-395): add_boost (boost.rs:470-504) over the matched TERMS — the boost column is keyed by term id
+    // ("<path>.textindex.token_values.boost_valid_to_value", create/token_values_to_tokens.rs) and shapes the term scores before any
+    // posting is read.  Host arithmetic (glibc log10f / log2f, as the reference links them).
+    void apply_token_value(const RequestBoostPart& tv, Leaf& l) {
+        const std::string path = tv.path + TEXTINDEX + TOKEN_VALUES + BOOST_VALID_TO_VALUE;
+        auto bit = idx.boost.find(path);
+        if (bit == idx.boost.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + path);
+        DColBoost cb{};
+        fill_boost_params(cb, tv);
+        for (auto& h : l.hits_scores) {
+            bool skip = false;
+            for (uint32_t s = 0; s < cb.nskip; ++s) skip = skip || std::fabs(cb.skip[s] - h.second) < 0.00001f;
+            float v;
+            if (skip || !bit->second.host_value(h.first, &v)) continue;
+            const float vp = v + cb.param;
+            float score = h.second;
+            switch (cb.fun) {  // apply_boost, boost.rs:283-377
+                case BF_LOG10: score *= std::log10(vp); break;
+                case BF_LOG2: score *= std::log2(vp); break;
+                case BF_MULTIPLY: score *= vp; break;
+                case BF_ADD: score += vp; break;
+                case BF_REPLACE: score = vp; break;
+                default: break;
+            }
+            if (cb.expr_op != EX_NONE) {
+                const float a = cb.expr_lkind == 0 ? v : cb.expr_lval, b = cb.expr_rkind == 0 ? v : cb.expr_rval;
+                score += cb.expr_op == EX_DIV ? a / b : cb.expr_op == EX_MUL ? a * b : cb.expr_op == EX_ADD ? a + b : a - b;
+            }
+            h.second = score;
+        }
+    }
     Leaf& field_result(const RequestSearchPart& part) {
         Leaf& l = leaf(part);
         if (!l.computed) {
@@ -289,6 +319,7 @@ struct Compiler {
                 for (auto& h : l.hits_scores) ids.push_back(h.first);
                 term_id_hits[l.path][part.terms[0]] = ids;
             }
+            if (part.token_value) apply_token_value(*part.token_value, l);  // :391-395
             l.computed = true;
         }
         return l;

@@ -41,6 +41,7 @@ extern const char* const ANCHOR_TO_TEXT_ID;
 extern const char* const BOOST_VALID_TO_VALUE;
 extern const char* const VALUE_ID_TO_ANCHOR;
 extern const char* const TEXTINDEX;
+extern const char* const TOKEN_VALUES;
 
 // ------------------------------------------------------------------ builder-side (host copies of what the caller hands over)
 struct HostFst {

@@ -18,6 +18,7 @@ const char* const PARENT_TO_VALUE_ID = ".parent_to_value_id";
 const char* const TEXT_ID_TO_ANCHOR = ".text_id_to_anchor";
 const char* const ANCHOR_TO_TEXT_ID = ".anchor_to_text_id";
 const char* const BOOST_VALID_TO_VALUE = ".boost_valid_to_value";
+const char* const TOKEN_VALUES = ".token_values";
 const char* const VALUE_ID_TO_ANCHOR = ".value_id_to_anchor";
 const char* const TEXTINDEX = ".textindex";
 
@@ -328,7 +329,8 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         c.values.alloc(bc.bits.size() * 4 + 16);
         c.values.upload(bc.bits.data(), bc.bits.size() * 4);
         idx->device_bytes += c.values.bytes;
-        if (path.find("[]") != std::string::npos) {
+        // host copies: 1:n boost columns (keys are value ids) and token_values columns (keys are term ids) are resolved on the host
+        if (path.find("[]") != std::string::npos || path.find(".token_values") != std::string::npos) {
             c.host_bits = bc.bits;
             c.host_present.assign(bc.present.begin(), bc.present.end());
         }

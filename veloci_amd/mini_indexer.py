@@ -209,8 +209,10 @@ def _multi_store(pairs, sort_and_dedup):
     return rows
 
 
-def build_index(docs, indices=""):
-    """docs: list of JSON objects (one anchor each).  Returns (IndexData, info) with info = {path: {"terms": [...], "identity": bool}}."""
+def build_index(docs, indices="", token_values=None):
+    """docs: list of JSON objects (one anchor each).  Returns (IndexData, info) with info = {path: {"terms": [...], "identity": bool}}.
+    token_values: optional (entries, path) with entries = [{"text": .., "value": ..}] — per-term boost values of field `path`
+    (add_token_values_to_tokens, create/token_values_to_tokens.rs:26-75)."""
     cfg = parse_config(indices)
     num_docs = len(docs)
 
@@ -391,4 +393,18 @@ def build_index(docs, indices=""):
             data.add_key_value_store(path + ".value_id_to_parent", *csr_from_lists([r[-1:] for r in rows]))
         if d["parent_to_value"] is not None:
             data.add_key_value_store(path + ".parent_to_value_id", *csr_from_lists(_multi_store(d["parent_to_value"], False)))
+    if token_values is not None:
+        # every entry's text is looked up exactly (levenshtein 0, ignore_case false) in the field's dictionary; the value is stored
+        # under the term id in "<path>.textindex.token_values.boost_valid_to_value" (a direct single-value boost store)
+        entries, tv_path = token_values
+        ids = term_id.get(tv_path, {})
+        hits = {}
+        for e in entries:
+            if e.get("value") is not None and e["text"] in ids:
+                hits[ids[e["text"]]] = np.float32(e["value"])
+        n = (max(hits) + 1) if hits else 0
+        vals, present = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        for k, v in hits.items():
+            vals[k], present[k] = v, 1
+        data.add_boost(tv_path + ".textindex.token_values.boost_valid_to_value", vals, present)
     return data, info
