@@ -257,8 +257,9 @@ def test_generic_kernel_also_matches_for_simple_queries():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}],
-                         ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan"])
+@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}],
+                         ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
+                              "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results."""
     import os

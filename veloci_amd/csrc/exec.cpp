@@ -479,10 +479,13 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
         stack_depth = std::max(stack_depth, cq.stack_depth);
     }
     desc_cap = align_up(desc_cap, 16);
+    uint32_t list_table = 2;
+    for (size_t i = 0; i < n; ++i) list_table = std::max<uint32_t>(list_table, uint32_t(cqs[i]->lists.size()));
+    list_table = (list_table + 1u) & ~1u;
     const uint32_t cand_cap = 256;  // the candidate area doubles as the counter array (<= 256 counters)
     for (size_t i = 0; i < n; ++i)
         lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(cqs[i]->lists.size()) + cqs[i]->n_temps, uint32_t(cqs[i]->lists.size()), cqs[i]->tile_words,
-                                                            stack_depth, cand_cap, uint32_t(desc_cap)));
+                                                            stack_depth, cand_cap, uint32_t(desc_cap), false, list_table));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     const size_t o_off = align_up(blob_off[n], 256), o_span = o_off + align_up((n + 1) * 4, 256), o_qmap = o_span + align_up((n + 1) * 4, 256),
                  o_cnt = o_qmap + align_up(n * 4, 256), total = o_cnt + align_up(size_t(counts_off[n]) * 8, 256);
@@ -496,7 +499,7 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
     VQ_HIP(hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, st));
     launch_tile_scan(st, span_base[n], lds_bytes, dev, reinterpret_cast<const uint32_t*>(dev + o_off), reinterpret_cast<const uint32_t*>(dev + o_span),
                      reinterpret_cast<const uint32_t*>(dev + o_qmap), uint32_t(n), stack_depth, cand_cap, uint32_t(desc_cap), nullptr,
-                     reinterpret_cast<unsigned long long*>(dev + o_cnt), nullptr);
+                     reinterpret_cast<unsigned long long*>(dev + o_cnt), nullptr, false, list_table);
     VQ_HIP(hipGetLastError());
     std::vector<uint64_t> cnt(counts_off[n]);
     VQ_HIP(hipMemcpyAsync(cnt.data(), dev + o_cnt, cnt.size() * 8, hipMemcpyDeviceToHost, st));
@@ -838,9 +841,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     desc_cap = uint32_t(align_up(desc_cap, 16));
     uint32_t cand_cap = 256;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
     while (cand_cap < 2 * max_top_k) cand_cap <<= 1;
+    const uint32_t list_table = (std::max<uint32_t>(max_lists, 2) + 1u) & ~1u;  // k_tile_scan sizes its per-list LDS arrays to the launch's longest list table
+    static const bool tile_queue = std::getenv("VQ_NO_QUEUE") == nullptr;  // k_tile_scan: survivors of several tiles share a scoring round
     for (size_t i = 0; i < n; ++i)
         if (pb->queries[i].status == 0 && !pb->queries[i].simple_flags)
-            lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap));
+            lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap, tile_queue && !pb->queries[i].simple_n, list_table));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
@@ -863,7 +868,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, reinterpret_cast<const uint32_t*>(dup + up_qmap_g), n_generic,
                      stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
-                     reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
+                     reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist), tile_queue, list_table);
     if (pb->profiled) {
         VQ_HIP(hipEventRecord(ws.ev1, st));
         std::lock_guard<std::mutex> g(idx.profile_mutex);

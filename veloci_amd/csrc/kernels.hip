@@ -356,9 +356,29 @@ __device__ __forceinline__ float tree_score_simple(const ScoreCtx& c, uint32_t w
     return sum * nd * nd;
 }
 
+// Where a hit's list memberships and posting indices come from.
+struct TileHit {  // a doc of the tile being scanned: the tile bitmaps and their prefix popcounts
+    const ScoreCtx& c;
+    uint32_t w, b;
+    __device__ __forceinline__ bool present(uint32_t li) const { return (c.bm[li * c.WW + w] >> b) & 1u; }
+    __device__ __forceinline__ uint32_t index(uint32_t li) const {
+        const uint32_t word = c.bm[li * c.WW + w];
+        return c.cur[li] + c.cnt_lo[li] + (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & ((1u << b) - 1u));
+    }
+};
+constexpr uint32_t kQueueCap = 96;       // k_tile_scan: survivors wait here until 64 of them make a full scoring round (< 64 waiting + 32 new)
+constexpr uint32_t kQueueMaxLists = 16;  // queries with more lists score each tile's survivors at once
+struct QueuedHit {  // a doc queued by an earlier tile: memberships as a mask, posting indices captured when it was queued
+    unsigned long long mask;
+    const uint32_t* qidx;  // [L][kQueueCap]
+    uint32_t slot;
+    __device__ __forceinline__ bool present(uint32_t li) const { return (mask >> li) & 1ull; }
+    __device__ __forceinline__ uint32_t index(uint32_t li) const { return qidx[li * kQueueCap + slot]; }
+};
+
 // any tree: postfix interpreter; stack slot index is uniform across lanes
-__device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
-    const uint32_t below = (1u << b) - 1u;
+template <class HitT>
+__device__ float tree_score_generic(const ScoreCtx& c, const HitT& hit) {
     uint32_t sp = 0;
     uint32_t pmask = 0;  // bit s: stack slot s holds a present value
     for (uint32_t o = 0; o < c.n_ops; ++o) {
@@ -368,13 +388,11 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
         if (op.kind() == OP_LEAF) {
             for (uint32_t j = 0; j < op.list_count(); ++j) {
                 const uint32_t li = op.list_begin() + j;
-                const uint32_t word = c.bm[li * c.WW + w];
-                if ((word >> b) & 1u) {
+                if (hit.present(li)) {
                     float v = 0.0f;
                     const uint32_t lflags = c.klists[li].flags;
                     if (lflags & LIST_HAS_SCORES) {
-                        const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
-                        const uint32_t idx = c.cur[li] + c.cnt_lo[li] + rank;
+                        const uint32_t idx = hit.index(li);
                         const uint16_t* sp16 = c.klists[li].scores;
                         if (lflags & LIST_F32) v = as_global(reinterpret_cast<const float*>(sp16))[idx];
                         else v = posting_value(c.klists[li].term_score, as_global(sp16)[idx]);
@@ -387,10 +405,8 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
             const uint32_t top = sp - 1u;
             if ((pmask >> top) & 1u) {
                 const uint32_t li = op.list_begin();
-                const uint32_t word = c.bm[li * c.WW + w];
-                if ((word >> b) & 1u) {
-                    const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & below);
-                    const float v = as_global(reinterpret_cast<const float*>(c.klists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
+                if (hit.present(li)) {
+                    const float v = as_global(reinterpret_cast<const float*>(c.klists[li].scores))[hit.index(li)];
                     c.fstack[top * kBlock] = apply_boost_value(c.fstack[top * kBlock], c.cols[op.child_slot(0)], v);
                 }
             }
@@ -430,32 +446,31 @@ __device__ float tree_score_generic(const ScoreCtx& c, uint32_t w, uint32_t b) {
 }
 
 // sink stages in the reference's order: column boosts, phrase groups, term boosts, text locality, facets
-__device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint32_t w, uint32_t b) {
+template <class HitT>
+__device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const HitT& hit) {
     for (uint32_t k = 0; k < c.n_col; ++k) score = apply_col_boost(score, c.cols[k], doc);
     for (uint32_t g = 0; g < c.n_groups; ++g) {
         bool in = false;
-        for (uint32_t j = 0; j < c.groups[g].list_count; ++j) in = in || ((c.bm[(c.groups[g].list_begin + j) * c.WW + w] >> b) & 1u);
+        for (uint32_t j = 0; j < c.groups[g].list_count; ++j) in = in || hit.present(c.groups[g].list_begin + j);
         if (in) score *= c.groups[g].mult;
     }
     for (uint32_t t = 0; t < c.n_tboost; ++t)
-        if ((c.bm[c.tboosts[t].list * c.WW + w] >> b) & 1u) score *= c.tboosts[t].mult;
+        if (hit.present(c.tboosts[t].list)) score *= c.tboosts[t].mult;
     if (c.n_locf) {  // boost.rs:11-87: 2*c*c per field with c > 1, the MINIMUM over fields (:25)
         float best = 0.0f;
         bool have = false;
         for (uint32_t f = 0; f < c.n_locf; ++f) {
             if (c.locf[f].list_count == kLocPrecomputed) {  // field whose text ids are not anchors: (anchor, 2*c*c) resolved by the query compiler
                 const uint32_t li = c.locf[f].list_begin;
-                const uint32_t word = c.bm[li * c.WW + w];
-                if ((word >> b) & 1u) {
-                    const uint32_t rank = (uint32_t)c.pre[li * c.WW + w] + (uint32_t)__popc(word & ((1u << b) - 1u));
-                    const float bv = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[c.cur[li] + c.cnt_lo[li] + rank];
+                if (hit.present(li)) {
+                    const float bv = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[hit.index(li)];
                     if (!have || bv < best) best = bv;
                     have = true;
                 }
                 continue;
             }
             uint32_t cnt = 0;
-            for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += (c.bm[(uint32_t)c.loc_idx[c.locf[f].list_begin + j] * c.WW + w] >> b) & 1u;
+            for (uint32_t j = 0; j < c.locf[f].list_count; ++j) cnt += hit.present((uint32_t)c.loc_idx[c.locf[f].list_begin + j]) ? 1u : 0u;
             if (cnt > 1u) {
                 float bv = 2.0f * (float)cnt * (float)cnt;
                 if (!have || bv < best) best = bv;
@@ -478,6 +493,36 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint3
     return score;
 }
 
+// Score queue entries [0, count) (count <= 64: one per lane) and feed the top-k.
+__device__ void tile_queue_flush(uint32_t count, const ScoreCtx& sc, const uint32_t* qdoc, const unsigned long long* qmask, const uint32_t* qidx,
+                                 const CandState& cs, uint32_t top_k) {
+    const uint32_t lane = threadIdx.x;
+    const bool have = lane < count;
+    unsigned long long key = 0ull;
+    if (have) {
+        const QueuedHit qh{qmask[lane], qidx, lane};
+        const uint32_t doc = qdoc[lane];
+        float score = tree_score_generic(sc, qh);
+        score = sink_stages(sc, score, doc, qh);
+        key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+    }
+    bool pending = have && key > *cs.thr && key < cs.upper;
+    while (true) {
+        if (pending) {
+            if (key > *cs.thr) {
+                const uint32_t pos = atomicAdd(cs.n, 1u);
+                if (pos < cs.cap) {
+                    cs.cand[pos] = key;
+                    pending = false;
+                }
+            } else pending = false;
+        }
+        const int need = __syncthreads_or(pending ? 1 : 0);
+        if (!need) break;
+        cand_prune(cs, top_k);
+    }
+}
+
 // ------------------------------------------------------------------------------------ k_tile_scan
 // LDS map (u32 units):
 //   misc[8]: thr(2) cand_n hits_acc pad
@@ -489,17 +534,16 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, uint3
 //   rootw[WW]  bm[(L+T)*WW] (list bitmaps, then the presence program's temporaries)  pre[L*WW] (u16)
 constexpr uint32_t kLdsMisc = 0;
 constexpr uint32_t kLdsCur = 8;
-constexpr uint32_t kLdsNxt = kLdsCur + 2 * kMaxLists;
-constexpr uint32_t kLdsNxtNew = kLdsNxt + 2 * kMaxLists;
-constexpr uint32_t kLdsCntLo = kLdsNxtNew + kMaxLists;
-constexpr uint32_t kLdsCntHi = kLdsCntLo + kMaxLists;
-constexpr uint32_t kLdsSurv = kLdsCntHi + kMaxLists;  // compacted survivor codes, u16[kSurvCap]
 constexpr uint32_t kSurvCap = 256;
-constexpr uint32_t kLdsDesc = kLdsSurv + kSurvCap / 2;
+// the per-list arrays are sized to the launch's longest list table `ml` (even): cur[2][ml] nxt[2][ml] nxt_new[ml] cnt_lo[ml] cnt_hi[ml],
+// then the compacted survivor codes u16[kSurvCap], then the descriptor
+__host__ __device__ constexpr uint32_t lds_desc_off(uint32_t ml) { return kLdsCur + 7u * ml + kSurvCap / 2u; }
 
-size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap) {
-    size_t u32s = kLdsDesc + desc_cap / 4 + 2 * (size_t)cand_cap + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_bitmaps * tile_words +
+size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, bool queue, uint32_t ml) {
+    size_t u32s = lds_desc_off(ml) + desc_cap / 4 + 2 * (size_t)cand_cap + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_bitmaps * tile_words +
                   ((size_t)n_lists * tile_words + 1) / 2;
+    // survivor queue (queries of <= kQueueMaxLists lists): qmask u64[kQueueCap], qdoc u32[kQueueCap], qidx u32[n_lists][kQueueCap]
+    if (queue && n_lists <= kQueueMaxLists) u32s = ((u32s + 1) & ~size_t(1)) + (size_t)kQueueCap * (3 + n_lists);
     return u32s * 4 + 16;
 }
 
@@ -525,7 +569,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                                                       const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                       uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap,
                                                       unsigned long long* __restrict__ span_keys,
-                                                      unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
+                                                      unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist, uint32_t queue_on, uint32_t ml) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -548,6 +592,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const uint32_t span = blockIdx.x - span_base[ql];
 
     // ---- stage the query descriptor into LDS: every later phase reads it from there, not from HBM
+    const uint32_t kLdsDesc = lds_desc_off(ml);  // (ml: list-table size of the launch, even, >= every query's n_lists)
     uint32_t* desc = lds + kLdsDesc;
     const uint8_t* gblob8 = blobs + __builtin_amdgcn_readfirstlane(blob_off[q]);  // (in SGPRs: the interpreter's scalar reads go here)
     {
@@ -580,11 +625,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds + kLdsMisc);
     uint32_t* cand_n = lds + kLdsMisc + 2;
     uint32_t* hits_acc = lds + kLdsMisc + 3;
-    uint32_t* cur2 = lds + kLdsCur;  // [2][kMaxLists]
-    uint32_t* nxt2 = lds + kLdsNxt;  // [2][kMaxLists]
-    uint32_t* nxt_new = lds + kLdsNxtNew;
-    uint32_t* cnt_lo = lds + kLdsCntLo;
-    uint32_t* cnt_hi = lds + kLdsCntHi;
+    uint32_t* cur2 = lds + kLdsCur;       // [2][ml]
+    uint32_t* nxt2 = cur2 + 2u * ml;      // [2][ml]
+    uint32_t* nxt_new = nxt2 + 2u * ml;
+    uint32_t* cnt_lo = nxt_new + ml;
+    uint32_t* cnt_hi = cnt_lo + ml;
+    uint16_t* const surv_list = reinterpret_cast<uint16_t*>(cnt_hi + ml);
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kLdsDesc + desc_cap / 4);
     uint32_t* stack = lds + kLdsDesc + desc_cap / 4 + 2 * cand_cap + tid;  // this thread's column
     uint32_t* rootw = lds + kLdsDesc + desc_cap / 4 + 2 * cand_cap + stack_depth * kBlock;
@@ -594,6 +640,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                  reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blobs) + blob_off[q] + offsetof(QHeader, gthr))};
     cs.upper = H->key_upper;
     uint32_t tiles_done = 0;
+    // survivor queue: the few docs per tile that the pruning leaves wait until 64 of them make a full scoring round (a round costs the
+    // same for 1 and for 64 docs); their list memberships and posting indices are captured when they are queued
+    const bool use_queue = queue_on && L <= kQueueMaxLists && !H->n_counts && !H->simple_n;  // uniform
+    uint32_t* const qbase = lds + ((((uint32_t)(reinterpret_cast<uint32_t*>(pre) - lds) + (L * WW + 1u) / 2u) + 1u) & ~1u);
+    unsigned long long* const qmask = reinterpret_cast<unsigned long long*>(qbase);
+    uint32_t* const qdoc = qbase + 2u * kQueueCap;
+    uint32_t* const qidx = qdoc + kQueueCap;  // [L][kQueueCap]
+    uint32_t qlen = 0;
+    unsigned long long score_lists = 0ull;  // lists whose postings carry a value (wave-uniform: kept in SGPRs)
+    if (use_queue) {
+        for (uint32_t i = 0; i < L; ++i)
+            if (lists[i].flags & LIST_HAS_SCORES) score_lists |= 1ull << i;
+        score_lists = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(uint32_t)(score_lists >> 32)) << 32) |
+                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)score_lists);
+    }
 
     // ---- span of the doc-id space owned by this workgroup
     const uint32_t n_spans = H->n_spans;
@@ -631,8 +692,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     VQ_STAMP_AT(0)
 
     while (true) {
-        uint32_t* cur = cur2 + par * kMaxLists;
-        uint32_t* nxt = nxt2 + par * kMaxLists;
+        uint32_t* cur = cur2 + par * ml;
+        uint32_t* nxt = nxt2 + par * ml;
         // ---- P0: next tile = the tile holding the smallest pending doc of the cover lists (LDS only), or simply the next one
         uint32_t head = 0xFFFFFFFFu;
         if (seq_tiles) head = seq_pos;
@@ -793,8 +854,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         // cursors of the NEXT tile go to the other parity: nobody reads them before the next barrier,
         // and the score gathers below still see this tile's cursors
         if (tid < L) {
-            cur2[(par ^ 1u) * kMaxLists + tid] = cur[tid] + cnt_hi[tid];
-            nxt2[(par ^ 1u) * kMaxLists + tid] = nxt_new[tid];
+            cur2[(par ^ 1u) * ml + tid] = cur[tid] + cnt_hi[tid];
+            nxt2[(par ^ 1u) * ml + tid] = nxt_new[tid];
         }
 
         // ---- P3: presence program (three-address code over bitmaps; the last op writes the root words).
@@ -927,7 +988,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             // ---- P5: score the surviving docs, run the sink stages, feed the top-k.  Few survivors (AND):
             //      compact them so that every lane scores at most ceil(S/64); many (OR): each lane walks its own words.
             const bool compact = S <= kSurvCap;
-            uint16_t* surv_list = reinterpret_cast<uint16_t*>(lds + kLdsSurv);
             if (compact) {
                 uint32_t pos = my_excl2;
                 for (uint32_t k = 0; k < WPL; ++k) {
@@ -944,6 +1004,40 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 
             ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
                         bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists};
+            if (compact && use_queue) {
+                for (uint32_t base = 0; base < S; base += 32u) {  // uniform
+                    const uint32_t nb = S - base < 32u ? S - base : 32u;
+                    if (lane < nb) {
+                        const uint32_t code = surv_list[base + lane];
+                        const uint32_t w = code >> 5, b = code & 31u, p = qlen + lane;
+                        unsigned long long m = 0ull;
+                        for (uint32_t li = 0; li < L; ++li) {  // uniform
+                            const uint32_t word = bm[li * WW + w];
+                            if ((word >> b) & 1u) {
+                                m |= 1ull << li;
+                                if ((score_lists >> li) & 1ull)
+                                    qidx[li * kQueueCap + p] = cur[li] + cnt_lo[li] + (uint32_t)pre[li * WW + w] + (uint32_t)__popc(word & ((1u << b) - 1u));
+                            }
+                        }
+                        qdoc[p] = tile_lo + (w << 5) + b;
+                        qmask[p] = m;
+                    }
+                    qlen += nb;
+                    __syncthreads();
+                    if (qlen >= 64u) {  // uniform
+                        tile_queue_flush(64u, sc, qdoc, qmask, qidx, cs, top_k);
+                        const uint32_t rem = qlen - 64u;  // < 64: move it to the front (disjoint source and destination)
+                        if (lane < rem) {
+                            qdoc[lane] = qdoc[64u + lane];
+                            qmask[lane] = qmask[64u + lane];
+                            for (uint32_t li = 0; li < L; ++li)
+                                if ((score_lists >> li) & 1ull) qidx[li * kQueueCap + lane] = qidx[li * kQueueCap + 64u + lane];
+                        }
+                        __syncthreads();
+                        qlen = rem;
+                    }
+                }
+            } else {
             uint32_t it_a = compact ? lane : 0u;
             uint32_t it_r = compact ? 0u : rootw[w0];
             bool pending = false;
@@ -977,12 +1071,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #ifdef VQ_STAMP
                     const unsigned long long _ts0 = __builtin_amdgcn_s_memtime();
 #endif
-                    float score = sc.simple_n ? tree_score_simple(sc, w, b) : tree_score_generic(sc, w, b);
+                    const TileHit th{sc, w, b};
+                    float score = sc.simple_n ? tree_score_simple(sc, w, b) : tree_score_generic(sc, th);
 #ifdef VQ_STAMP
                     _acc[13] += 1ull;                                      // scoring rounds of lane 0
                     _acc[14] += __builtin_amdgcn_s_memtime() - _ts0;       // ticks inside the score tree
 #endif
-                    score = sink_stages(sc, score, doc, w, b);
+                    score = sink_stages(sc, score, doc, th);
                     const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
                     if (key > *thr && key < cs.upper) {
                         uint32_t pos = atomicAdd(cand_n, 1u);
@@ -1001,6 +1096,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #endif
                 cand_prune(cs, top_k);
             }
+            }
             VQ_STAMP_AT(5)
         }
         par ^= 1u;
@@ -1014,7 +1110,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         }
         return;
     }
-    // ---- span done: publish the local top-k (as a set) and the hit count
+    // ---- span done: score what is still queued, publish the local top-k (as a set) and the hit count
+    if (qlen) {  // uniform
+        __syncthreads();
+        ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
+                    bm, pre, cur2, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists};
+        tile_queue_flush(qlen, sc, qdoc, qmask, qidx, cs, top_k);
+    }
     cand_prune(cs, top_k);
     {
         const uint32_t n = *cand_n;
@@ -1225,10 +1327,10 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
 // ------------------------------------------------------------------------------------ launchers
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                       const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys,
-                      unsigned long long* num_hits, uint32_t* hist) {
+                      unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml) {
     if (!total_spans) return;
     hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, stack_depth, cand_cap,
-                       desc_cap, span_keys, num_hits, hist);
+                       desc_cap, span_keys, num_hits, hist, queue ? 1u : 0u, ml);
 }
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {
