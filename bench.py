@@ -8,7 +8,7 @@ A step is one batch of --batch (default 1024) 3-term AND queries, top 10, execut
 documents and sharded by doc-id range over the N ranks (strong scaling); per-shard top-k are merged
 after one RCCL all-gather per batch.  Rank 0 prints ONE JSON line.
 
-roofline   : dominant kernel k_tile_scan; achieved = algorithmic bytes (6 B per posting of the three
+roofline   : dominant kernel k_scan_simple (3-term AND; other workloads name theirs); achieved = algorithmic bytes (6 B per posting of the three
              lists + 8 B per returned hit) per launch / mean launch time measured with HIP
              events on the launch stream inside the library (vq_profile_read).
 cpu_baseline: the CPU oracle (C++ restatement of the reference algorithm, `kind: port`) timed on this
