@@ -232,7 +232,8 @@ def main():
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
                        "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},
             "p50_latency_ms_single_query": (round(p50, 3) if p50 == p50 else None),
-            "roofline": {"bound": "hbm", "kernel": {"and": "k_scan_simple", "or": "k_scan_simple", "single": "k_scan_union"}.get(args.workload, "k_tile_scan"), "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": {"and": "k_scan_simple", "or": "k_scan_simple", "single": "k_scan_union", "config3": "k_scan_simple<rich>", "and_of_ors": "k_scan_simple<rich>",
+                                                    "mix": "k_scan_simple (plain + rich launches)", "config4": "k_scan_simple<rich> (+ k_dict_scan, k_union pre-passes)"}.get(args.workload, "k_tile_scan"), "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches),
                          "note": "achieved = algorithmic bytes (6 B per posting + 8 B per returned hit, SURVEY.md 8d) / mean launch time; the kernel reads dense "
