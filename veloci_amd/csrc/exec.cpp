@@ -78,9 +78,19 @@ void HostPool::run(size_t parts, const std::function<void(size_t)>& fn) {
     cv_done_.wait(lk, [&] { return pending_ == 0; });
     fn_ = nullptr;
 }
+// host threads per index for request compilation (the caller counts as one): VQ_HOST_THREADS, else the machine's, at most 16 (a GPU's share of
+// the host on an 8-GPU node)
+static size_t host_threads() {
+    static const size_t n = [] {
+        const char* e = std::getenv("VQ_HOST_THREADS");
+        size_t v = e ? size_t(std::atoi(e)) : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+        return std::min<size_t>(std::max<size_t>(v, 1), 64);
+    }();
+    return n;
+}
 static HostPool& host_pool(const Index& idx) {
     std::lock_guard<std::mutex> g(idx.pool_mu);
-    if (!idx.pool) idx.pool = std::make_unique<HostPool>(7);
+    if (!idx.pool) idx.pool = std::make_unique<HostPool>(host_threads() - 1);
     return *idx.pool;
 }
 
@@ -550,7 +560,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
-        const size_t parts = std::min<size_t>(8, n / 16);
+        const size_t parts = std::min<size_t>(2 * host_threads(), n / 16);  // (parts are pulled dynamically: uneven requests balance out)
         host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
@@ -599,7 +609,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             }
         };
         if (again.size() >= 32) {
-            const size_t parts = std::min<size_t>(8, again.size() / 8);
+            const size_t parts = std::min<size_t>(2 * host_threads(), again.size() / 8);
             host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
         } else recompile(0, again.size());
     }
