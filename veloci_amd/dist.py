@@ -75,6 +75,8 @@ class ShardedSearcher:
             # is 0, which the C ABI reads as "use the index's own streams".)
             self.stream = torch.cuda.Stream()
             self.fin_stream = torch.cuda.Stream()  # all-gather + merge of batch c overlap the scan of batch c+1
+            self._events = [torch.cuda.Event() for _ in range(4)]
+            self._ev = 0
             index.set_streams(self.stream.cuda_stream, self.fin_stream.cuda_stream)
         if self.collective:
             index.set_allreduce(self._sum_over_ranks)
@@ -93,7 +95,8 @@ class ShardedSearcher:
         from .search import PartialBatch
         pb = PartialBatch(self.index, requests)
         if self.stream is not None:  # the collective (finish stream) must wait for this batch's scan, not for the next one's
-            pb.scanned = torch.cuda.Event()
+            self._ev = (self._ev + 1) % len(self._events)  # (at most two partials are in flight: four events never collide)
+            pb.scanned = self._events[self._ev]
             pb.scanned.record(self.stream)
         return pb
 
@@ -136,22 +139,23 @@ class ShardedSearcher:
         batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
         subs = batch.split(chunks if chunks is not None else (4 if batch.n >= 512 else 1))
 
-        def finish(pb):
+        n = batch.n  # every chunk writes its rows of one set of output arrays
+        out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, stride), np.uint32), np.zeros((n, stride), np.float32), np.zeros(n, np.int32))
+
+        def finish(pb, offset):
             if not self.collective:
-                out = pb.merge_flat(None, 1, stride)
+                pb.merge_flat(None, 1, stride, out, offset)
             else:
                 gathered = self._gather(pb)
-                out = pb.merge_flat(gathered.data_ptr(), self.world, stride)
+                pb.merge_flat(gathered.data_ptr(), self.world, stride, out, offset)
             pb.close()
-            return out
 
-        outs, inflight = [], []
+        inflight, offset = [], 0
         for sb in subs:
             if len(inflight) >= 2:
-                outs.append(finish(inflight.pop(0)))
-            inflight.append(self._partial(sb))
+                finish(*inflight.pop(0))
+            inflight.append((self._partial(sb), offset))
+            offset += sb.n
         while inflight:
-            outs.append(finish(inflight.pop(0)))
-        if len(outs) == 1:
-            return outs[0]
-        return tuple(np.concatenate([o[i] for o in outs]) for i in range(5))
+            finish(*inflight.pop(0))
+        return out

@@ -188,17 +188,18 @@ class PartialBatch:
                 results.append(_take_result(self.L, C.c_void_p(outs[i])))
         return results
 
-    def merge_flat(self, gathered_device_ptr=None, num_shards=1, stride=10):
+    def merge_flat(self, gathered_device_ptr=None, num_shards=1, stride=10, out=None, offset=0):
+        """out: (num_hits, counts, ids, scores, status) arrays of a larger batch; this partial's rows start at `offset` (a pipeline of
+        chunks fills one set of arrays instead of concatenating per-chunk ones)."""
         n = self.n
-        num_hits = np.zeros(n, np.uint64)
-        counts = np.zeros(n, np.uint32)
-        ids = np.zeros((n, stride), np.uint32)
-        scores = np.zeros((n, stride), np.float32)
-        status = np.zeros(n, np.int32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        if out is None:
+            out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, stride), np.uint32), np.zeros((n, stride), np.float32), np.zeros(n, np.int32))
+            offset = 0
+        num_hits, counts, ids, scores, status = out
+        at = lambda a, row: C.c_void_p(a.ctypes.data + row * a.strides[0])
         _lib.check(self.L.vq_merge_partials_flat(self.index.h, self.h, C.c_void_p(gathered_device_ptr) if gathered_device_ptr else None, num_shards, stride,
-                                                 p(num_hits), p(counts), p(ids), p(scores), p(status)))
-        return num_hits, counts, ids, scores, status
+                                                 at(num_hits, offset), at(counts, offset), at(ids, offset), at(scores, offset), at(status, offset)))
+        return out
 
     def close(self):
         if getattr(self, "h", None):
