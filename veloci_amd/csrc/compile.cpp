@@ -1603,10 +1603,15 @@ struct Compiler {
             const char* e = std::getenv("VQ_TILE_LDS_KB");
             return size_t(e ? std::atoi(e) : 12) * 1024;
         }();
-        static const uint64_t span_postings = [] {
+        // postings per span.  Every span warms its own threshold up (until it adopts the query's shared one), so long spans prune
+        // better; short spans fill the chip more evenly.  Measured optimum (100 M docs, 256-query launches): 256 Ki postings, 128 Ki
+        // for the rich simple kernel and plain simple ANDs (no threshold-driven pruning to warm up; the tail of the launch weighs more).  VQ_SPAN_POSTINGS overrides.
+        static const uint64_t span_env = [] {
             const char* e = std::getenv("VQ_SPAN_POSTINGS");
-            return uint64_t(e ? std::atoll(e) : 65536);
+            return uint64_t(e ? std::atoll(e) : 0);
         }();
+        const bool and_like = ((cq.simple_flags >> 18) & 1u) || (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND);  // rich, or a plain simple AND
+        const uint64_t span_postings = span_env ? span_env : (and_like ? 131072 : 262144);
         uint32_t ww = ww_max;  // W = 32 * ww docs
         const size_t TL = size_t(L) + cq.n_temps;
         while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;

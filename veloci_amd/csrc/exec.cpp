@@ -669,15 +669,17 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint64_t algo_bytes = 0;
     {   // a small batch (one query = the latency case) would leave most of the chip idle with spans sized for streaming efficiency:
         // split its queries further until the launch holds about one wave per SIMD of every CU
-        static const uint64_t target = [] {
+        static const uint64_t target1 = [] {
             const char* e = std::getenv("VQ_SPAN_TARGET");
             return uint64_t(e ? std::atoll(e) : 2048);
         }();
+        // (one request: 2048 spans — its merge is serial in the span count; more requests merge in parallel: up to one wave per slot)
+        const uint64_t target = std::min<uint64_t>(target1 + 64 * uint64_t(n - 1), std::max<uint64_t>(target1, 5120));
         uint64_t have = 0;
         for (size_t i = 0; i < n; ++i)
             if (pb->queries[i].status == 0) have += pb->queries[i].n_spans;
-        if (have && have * 2 <= target) {
-            const uint64_t f = target / have;
+        if (have && have * 3 <= target * 2) {
+            const uint64_t f = (target + have - 1) / have;
             for (size_t i = 0; i < n; ++i) {
                 CompiledQuery& cq = pb->queries[i];
                 if (cq.status == 0) cq.n_spans = uint32_t(std::max<uint64_t>(cq.n_spans, std::min<uint64_t>(uint64_t(cq.n_spans) * f, cq.max_spans)));
