@@ -851,7 +851,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             desc_cap = std::max(desc_cap, uint32_t(d));
         }
     desc_cap = uint32_t(align_up(desc_cap, 16));
-    uint32_t cand_cap = 256;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
+    static const uint32_t cand_min = [] {
+        const char* e = std::getenv("VQ_CAND_CAP");  // (a small buffer is pruned — and its threshold raised — sooner: 64 beats 256 by 2-7 %)
+        return uint32_t(e ? std::max(32, std::atoi(e)) : 64);
+    }();
+    uint32_t cand_cap = cand_min;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
     while (cand_cap < 2 * max_top_k) cand_cap <<= 1;
     const uint32_t list_table = (std::max<uint32_t>(max_lists, 2) + 1u) & ~1u;  // k_tile_scan sizes its per-list LDS arrays to the launch's longest list table
     static const bool tile_queue = std::getenv("VQ_NO_QUEUE") == nullptr;  // k_tile_scan: survivors of several tiles share a scoring round
