@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r01h
+O=gpurun_out/r01i
 S=/tmp/prof_scratch
 rm -rf $S && mkdir -p $O $S
 python3 bench.py > $O/bench_and.json 2> $O/bench_and.log
