@@ -28,6 +28,13 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.vq_version()
 
 
+def test_integration_guide_binds_every_declared_symbol():
+    """INTEGRATION.md shows the reference-side (Rust) extern block a maintainer would add: it must cover the whole header."""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        bound = set(re.findall(r"pub fn (vq_[a-z0-9_]+)", f.read()))
+    assert bound == set(header_symbols()), bound ^ set(header_symbols())
+
+
 def test_request_parse_serde_semantics():
     import veloci_amd
     # unknown keys are ignored (tests/all/tests.rs:528 of the reference passes "firstCharExactMatch")
