@@ -1627,7 +1627,11 @@ struct Compiler {
         cq.tile_words = ww;
         cq.stack_depth = std::max<uint32_t>(max_depth, 1);
         uint64_t spans = (cq.total_len + span_postings - 1) / span_postings;
-        if (!cq.facets.empty()) spans = (cq.total_len + 4095) / 4096;  // every hit walks its facet rows: per-hit work, not per-posting streaming
+        static const uint64_t facet_span = [] {
+            const char* e = std::getenv("VQ_FACET_SPAN_POSTINGS");
+            return uint64_t(e ? std::atoll(e) : 4096);
+        }();
+        if (!cq.facets.empty()) spans = (cq.total_len + facet_span - 1) / facet_span;  // every hit walks its facet rows: per-hit work, not per-posting streaming
         const uint64_t tiles = std::max<uint64_t>((range + (uint64_t(ww) << 5) - 1) / (uint64_t(ww) << 5), 1);
         {  // k_tile_scan pays a latency-bound round trip per visited tile (score gathers, facet rows): at most ~16 visited tiles per span
             uint64_t cover_len = 0;
