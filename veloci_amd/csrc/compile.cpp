@@ -1501,6 +1501,7 @@ struct Compiler {
                 DFacet f{};
                 f.offsets = kv.csr_off.as<uint64_t>();
                 f.values = kv.csr_values.as<uint32_t>();
+                f.direct = kv.csr_direct.p ? kv.csr_direct.as<uint32_t>() : nullptr;
                 f.key_base = kv.csr_key_base;
                 f.num_keys = kv.csr_num_keys;
                 // value ids beyond the dictionary (texts longer than do_not_store_text_longer_than) are counted too and render as ""

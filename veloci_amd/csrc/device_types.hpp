@@ -108,6 +108,7 @@ struct DLocField {  // one text field with >= 2 query terms (boost.rs:34-87)
 struct DFacet {  // facet.rs:31-73 fast path: anchor -> value ids, counted into a histogram
     const uint64_t* offsets;  // CSR over [key_base, key_base + num_keys]
     const uint32_t* values;
+    const uint32_t* direct;   // != null: no anchor has more than one value — direct[row] is the value id or 0xFFFFFFFF
     uint32_t key_base, num_keys;
     uint32_t hist_off;    // u32 index into the batch's histogram area
     uint32_t num_values;  // histogram length == dictionary size of the facet field

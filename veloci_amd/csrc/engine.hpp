@@ -142,7 +142,8 @@ using FuzzyTable = std::map<std::string, FuzzyProbe>;
 std::string fuzzy_key(const vqreq::RequestSearchPart& p);
 bool needs_dictionary_scan(const vqreq::RequestSearchPart& p);
 void collect_fuzzy_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
-void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st);
+struct Workspace;
+void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStream_t st);
 void score_fuzzy_probe(const Index& idx, FuzzyProbe& probe);
 
 // A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the
@@ -219,6 +220,8 @@ struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device ima
     bool facet_csr = false;
     uint32_t csr_key_base = 0, csr_num_keys = 0;
     uint32_t csr_max_value = 0;  // largest value id of the CSR (text ids of texts too long for the dictionary lie beyond it)
+    DevBuf csr_direct;  // u32 [csr_num_keys], only when no anchor has more than one value: the value id or 0xFFFFFFFF (one gather per hit
+                        // instead of two offsets + the value)
     DevBuf csr_off;     // u64 [csr_num_keys + 1]
     DevBuf csr_values;  // u32
 
@@ -280,6 +283,7 @@ struct Workspace {  // scratch of one in-flight batch
     DevBuf d_hist_sum;
     DevBuf d_down;      // results
     DevBuf d_union_docs[2], d_union_vals[2], d_union_max, d_union_meta;  // materialised leaves (k_union), level 1 / level 2
+    DevBuf d_probe_desc, d_probe_counts, d_probe_ids;                    // dictionary scans (k_dict_scan): kept, so that no hipFree synchronises the device mid-pipeline
 };
 
 struct Profile {
@@ -336,6 +340,8 @@ struct Index {
     mutable std::map<std::string, std::unique_ptr<KVStore>> composed_facets;
     const KVStore& composed_facet(const std::vector<std::string>& steps) const;
     hipStream_t own_stream = nullptr, own_fin_stream = nullptr;
+    hipStream_t pre_stream = nullptr;  // dictionary scans, union / range / count pre-passes: every one ends in a host synchronisation, so they need no
+                                       // ordering with the scan stream — and on their own stream the pre-passes of batch c+1 overlap the scan of batch c
     hipStream_t stream = nullptr;      // scans + span merges
     hipStream_t fin_stream = nullptr;  // shard merge, facet selection, result download (== stream when the caller set one)
     mutable std::mutex profile_mutex;

@@ -196,7 +196,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
 
 // Answer every dictionary scan of a batch with k_dict_scan launches (grid.y = probe), then bring the match
 // sets back sorted ascending (== FST stream order, which is what the reference's callback order is).
-void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
+void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStream_t st) {
     std::vector<FuzzyProbe*> todo;
     for (auto& kv : table)
         if (kv.second.status == 0) todo.push_back(&kv.second);
@@ -214,10 +214,10 @@ void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
             std::vector<uint64_t> out_off(c1 - c0 + 1, 0);
             uint32_t max_terms = 0;
             for (size_t i = c0; i < c1; ++i) out_off[i - c0 + 1] = out_off[i - c0] + cap[active[i]];
-            DevBuf d_probes, d_counts, d_ids;
-            d_probes.alloc(probes.size() * sizeof(DictProbe));
-            d_counts.alloc(probes.size() * 4 + 16);
-            d_ids.alloc(out_off.back() * 4 + 16);
+            DevBuf &d_probes = ws.d_probe_desc, &d_counts = ws.d_probe_counts, &d_ids = ws.d_probe_ids;
+            d_probes.ensure(probes.size() * sizeof(DictProbe));
+            d_counts.ensure(probes.size() * 4 + 16);
+            d_ids.ensure(out_off.back() * 4 + 16);
             for (size_t i = c0; i < c1; ++i) {
                 const FuzzyProbe& fp = *todo[active[i]];
                 const Dictionary& d = idx.dict.at(fp.path);
@@ -242,6 +242,14 @@ void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
             std::vector<uint32_t> counts(probes.size());
             VQ_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
             VQ_HIP(hipStreamSynchronize(st));
+            for (size_t i = c0; i < c1; ++i) {  // all match sets in one go: asynchronous copies, one synchronisation
+                FuzzyProbe& fp = *todo[active[i]];
+                const uint32_t cnt = counts[i - c0];
+                if (cnt > cap[active[i]]) continue;
+                fp.matches.resize(cnt);
+                if (cnt) VQ_HIP(hipMemcpyAsync(fp.matches.data(), d_ids.as<uint32_t>() + out_off[i - c0], size_t(cnt) * 4, hipMemcpyDeviceToHost, st));
+            }
+            VQ_HIP(hipStreamSynchronize(st));
             for (size_t i = c0; i < c1; ++i) {
                 FuzzyProbe& fp = *todo[active[i]];
                 const uint32_t cnt = counts[i - c0];
@@ -250,8 +258,6 @@ void run_fuzzy_probes(const Index& idx, FuzzyTable& table, hipStream_t st) {
                     overflow.push_back(active[i]);
                     continue;
                 }
-                fp.matches.resize(cnt);
-                if (cnt) VQ_HIP(hipMemcpy(fp.matches.data(), d_ids.as<uint32_t>() + out_off[i - c0], size_t(cnt) * 4, hipMemcpyDeviceToHost));
                 std::sort(fp.matches.begin(), fp.matches.end());
             }
         }
@@ -545,7 +551,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     FuzzyTable fuzzy;
     for (size_t i = 0; i < n; ++i)
         if (reqs[i]) collect_fuzzy_probes(idx, *reqs[i], fuzzy);
-    if (!fuzzy.empty()) run_fuzzy_probes(idx, fuzzy, st);
+    static const bool pre_own = std::getenv("VQ_PRE_ON_SCAN_STREAM") == nullptr;
+    hipStream_t pst = pre_own && idx.pre_stream ? idx.pre_stream : st;  // the pre-passes' stream (see Index::pre_stream)
+    if (!fuzzy.empty()) run_fuzzy_probes(idx, ws, fuzzy, pst);
     const double t_probes = now_ms();
     pb->queries.reserve(n);
     pb->slot.assign(n, UINT32_MAX);
@@ -579,7 +587,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     double t_unions = t_pass1, t_ranges = t_pass1;
     if (!again.empty()) {
         if (!unions.empty()) {
-            run_union_jobs(idx, ws, unions, st);
+            run_union_jobs(idx, ws, unions, pst);
             // merged lengths over all shards (the AND summation order follows them)
             std::vector<uint64_t> lens;
             for (auto& kv : unions) lens.push_back(kv.second.len);
@@ -591,7 +599,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits,
         //      on the merged list of a materialised leaf)
         const bool ranges_ok = !any_ranges || !idx.sharded() || idx.can_sum_over_shards();
-        if (any_ranges && ranges_ok) run_range_jobs(idx, ws, ranges, unions, st);
+        if (any_ranges && ranges_ok) run_range_jobs(idx, ws, ranges, unions, pst);
         t_ranges = now_ms();
         auto recompile = [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
@@ -625,7 +633,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             }
         if (!need.empty()) {
             std::vector<QueryCounts> counts;
-            run_count_queries(idx, ws, cqs, counts, st);
+            run_count_queries(idx, ws, cqs, counts, pst);
             if (idx.sharded()) {  // result sizes are sums over the shards
                 std::vector<uint64_t> flat;
                 for (auto& c : counts) {

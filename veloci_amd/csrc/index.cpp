@@ -52,6 +52,7 @@ Index::~Index() {
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
     if (own_fin_stream) (void)hipStreamDestroy(own_fin_stream);
+    if (pre_stream) (void)hipStreamDestroy(pre_stream);
 }
 
 bool Index::is_anchor_identity(const std::string& textindex_path) const {
@@ -115,6 +116,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     idx->columns = b.columns;
     VQ_HIP(hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking));
     VQ_HIP(hipStreamCreateWithFlags(&idx->own_fin_stream, hipStreamNonBlocking));
+    VQ_HIP(hipStreamCreateWithFlags(&idx->pre_stream, hipStreamNonBlocking));
     idx->stream = idx->own_stream;
     idx->fin_stream = idx->own_fin_stream;
     for (auto& w : idx->ws) {
@@ -294,6 +296,16 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             s.csr_key_base = uint32_t(nb);
             s.csr_num_keys = uint32_t(ne - nb);
             for (uint64_t e = first; e < first + nvals; ++e) s.csr_max_value = std::max(s.csr_max_value, k.values[e]);
+            bool single = true;  // scalar fields: at most one value per anchor -> a direct column
+            for (size_t r = 0; r + 1 < off.size() && single; ++r) single = off[r + 1] - off[r] <= 1;
+            if (single && s.csr_num_keys) {
+                std::vector<uint32_t> direct(s.csr_num_keys, 0xFFFFFFFFu);
+                for (size_t r = 0; r + 1 < off.size(); ++r)
+                    if (off[r + 1] > off[r]) direct[r] = k.values[first + off[r]];
+                s.csr_direct.alloc(direct.size() * 4 + 16);
+                s.csr_direct.upload(direct.data(), direct.size() * 4);
+                idx->device_bytes += s.csr_direct.bytes;
+            }
         }
         idx->kv.emplace(path, std::move(s));
     }

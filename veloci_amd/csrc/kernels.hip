@@ -483,6 +483,11 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const
         const DFacet& fa = c.facets[f];
         if (doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
             const uint32_t row = doc - fa.key_base;
+            if (fa.direct) {  // uniform: a scalar field
+                const uint32_t v = as_global(fa.direct)[row];
+                if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
+                continue;
+            }
             const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
             for (unsigned long long e = e0; e < e1; ++e) {
                 const uint32_t v = as_global(fa.values)[e];
@@ -1602,6 +1607,11 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
             const DFacet& fa = R.facets[f];
             if (doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
                 const uint32_t row = doc - fa.key_base;
+                if (fa.direct) {  // uniform: a scalar field
+                    const uint32_t v = as_global(fa.direct)[row];
+                    if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
+                    continue;
+                }
                 const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
                 for (unsigned long long e = e0; e < e1; ++e) {
                     const uint32_t v = as_global(fa.values)[e];
