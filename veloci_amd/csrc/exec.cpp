@@ -905,9 +905,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
-        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], pack+launch %.3f ms\n", n,
+        std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], spans generic/simple/and/rich/union %u/%u/%u/%u/%u, pack+launch %.3f ms\n", n,
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
-                     t_ranges - t_unions, ranges.size(), now_ms() - t_compiled);
+                     t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense, now_ms() - t_compiled);
     return pb;
 }
 
