@@ -1578,6 +1578,14 @@ struct Compiler {
             }
         }
 
+        {  // one materialised leaf, nothing else that shapes presence or score: k_scan_leaf_f32 streams the list (facets counted per entry)
+            static const bool off = std::getenv("VQ_FORCE_GENERIC") != nullptr || std::getenv("VQ_NO_LEAF_F32") != nullptr;
+            if (!off && !cq.simple_flags && count_reqs.empty() && cq.ops.size() == 1 && cq.ops[0].kind == OP_LEAF && cq.ops[0].list_count == 1 &&
+                (cq.lists[cq.ops[0].list_begin].flags & LIST_F32) && cq.fops.empty() && cq.groups.empty() && cq.tboosts.empty() && cq.cols.empty() && cq.locf.empty() &&
+                cq.facets.empty())  // (with facets the rich kernel is faster: its 64-hit rounds put less pressure on the histogram's hot counters
+                                    //  than every span adding at once — an LDS-privatised histogram would lift that)
+                cq.simple_flags = 1u << 19;
+        }
         if (!cq.simple_flags) detect_rich_simple();
         if (!cq.simple_flags) compute_prune_table();
         if (!cq.simple_flags && count_reqs.empty()) {  // k_tile_scan: a dense cover list means every tile gets visited anyway: walk them in order
@@ -1646,7 +1654,12 @@ struct Compiler {
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);
         cq.n_spans = uint32_t(spans);
+        if ((cq.simple_flags >> 19) & 1u) {  // spans are slices of the list's ENTRIES: even work whatever the doc distribution
+            const uint64_t len = cq.lists[cq.ops[0].list_begin].len;
+            cq.n_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(len / (cq.facets.empty() ? 16384 : 4096), 1), 4096));
+        }
         cq.max_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 4096));
+        if ((cq.simple_flags >> 19) & 1u) cq.max_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(cq.lists[cq.ops[0].list_begin].len / 64, 1), 4096));
     }
 };
 

@@ -752,7 +752,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_w = up_span_w + tbl;
     const size_t up_span_r = up_qmap_w + tbl;   // rich simple queries (DSimple2): k_scan_simple<2, true>
     const size_t up_qmap_r = up_span_r + tbl;
-    const size_t up_jobs = up_qmap_r + tbl;
+    const size_t up_span_f = up_qmap_r + tbl;   // one materialised leaf: k_scan_leaf_f32
+    const size_t up_qmap_f = up_span_f + tbl;
+    const size_t up_jobs = up_qmap_f + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
@@ -762,6 +764,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t scatter_wide = 0, scatter_simple = 0;  // id (scattered) lists per query: they alone need an LDS tile in k_scan_simple
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, n_rich = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0, spans_rich = 0;
     uint32_t scatter_rich = 0;
+    uint32_t n_leaf = 0, spans_leaf = 0;
     {
         size_t off = 0;
         uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
@@ -784,6 +787,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t* mw = reinterpret_cast<uint32_t*>(hup + up_qmap_w);
         uint32_t* sr = reinterpret_cast<uint32_t*>(hup + up_span_r);
         uint32_t* mr = reinterpret_cast<uint32_t*>(hup + up_qmap_r);
+        uint32_t* sf = reinterpret_cast<uint32_t*>(hup + up_span_f);
+        uint32_t* mf = reinterpret_cast<uint32_t*>(hup + up_qmap_f);
+        uint32_t accf = 0;
         uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0;
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
@@ -796,7 +802,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             static const bool union_or = std::getenv("VQ_UNION_OR") != nullptr;
             const bool rich = (cq.simple_flags >> 18) & 1u;
             const bool dense = !rich && union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
-            if (rich) {
+            if ((cq.simple_flags >> 19) & 1u) {
+                sf[n_leaf] = accf;
+                mf[n_leaf++] = qi;
+                accf += cq.n_spans;
+            } else if (rich) {
                 scatter_rich = std::max<uint32_t>(scatter_rich, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)) + cq.simple2.n_side);
                 sr[n_rich] = accr;
                 mr[n_rich++] = qi;
@@ -829,6 +839,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         spans_wide = accw;
         sr[n_rich] = accr;
         spans_rich = accr;
+        sf[n_leaf] = accf;
+        spans_leaf = accf;
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -873,6 +885,10 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
     pb->profiled = idx.profile.enabled;
     if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
+    launch_scan_leaf_f32(st, spans_leaf, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_f), reinterpret_cast<const uint32_t*>(dup + up_qmap_f),
+                         n_leaf, cand_cap, ws.d_span_keys.as<unsigned long long>(), reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits),
+                         reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
+    VQ_HIP(hipGetLastError());
     launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_r),
                        reinterpret_cast<const uint32_t*>(dup + up_qmap_r), n_rich, cand_cap, ws.d_span_keys.as<unsigned long long>(),
                        reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
@@ -907,7 +923,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (timing_enabled())
         std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], spans generic/simple/and/rich/union %u/%u/%u/%u/%u, pack+launch %.3f ms\n", n,
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
-                     t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense, now_ms() - t_compiled);
+                     t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense + spans_leaf, now_ms() - t_compiled);
     return pb;
 }
 

@@ -2729,4 +2729,99 @@ void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const
                        num_hits);
 }
 
+
+// ====================================================================================================
+// k_scan_leaf_f32 — a query that is ONE materialised leaf (k_union output: doc ids + final f32 values) with no filter and no
+// score-shaping sink stage: every entry is a hit, its value is its score.  One wave per span of the LIST (entries, not doc ids:
+// perfectly even work), entries streamed from the end of the slice (under "score desc, id desc" later entries win ties, so a
+// descending walk never pushes on a tie); facets, if any, are counted for every entry.  This is the fuzzy / prefix single-term
+// request ("search as you type"), which the tile kernels served at a few G entries/s through their bitmap machinery.
+// ====================================================================================================
+__global__ __launch_bounds__(64) void k_scan_leaf_f32(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                      const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                      uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
+                                                      unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t ql;
+    {
+        uint32_t lo = 0, hi = nq;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (span_base[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        ql = lo;
+    }
+    const uint32_t q = qmap[ql];
+    const uint32_t span = blockIdx.x - span_base[ql];
+    const uint8_t* blob = blobs + blob_off[q];
+    const QHeader* H = reinterpret_cast<const QHeader*>(blob);
+    const DList& L = reinterpret_cast<const DList*>(blob + H->off_lists)[reinterpret_cast<const DOp*>(blob + H->off_ops)[0].list_begin];
+    const DFacet* facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
+    const uint32_t n_facets = H->n_facets, top_k = H->top_k, n_spans = H->n_spans;
+    const VQ_GLOBAL uint32_t* docs = as_global(L.docs);
+    const VQ_GLOBAL uint32_t* vals = as_global(reinterpret_cast<const uint32_t*>(L.scores));
+
+    unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t* cand_n = lds + 2;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + 8);
+    CandState cs{cand, cand_n, thr, cand_cap, reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr))};
+    cs.upper = H->key_upper;
+    if (lane == 0) {
+        *thr = 0ull;
+        *cand_n = 0;
+    }
+    __syncthreads();
+    // this span's slice of the list: entries [lo, hi)
+    const uint32_t lo = (uint32_t)((unsigned long long)L.len * span / n_spans), hi = (uint32_t)((unsigned long long)L.len * (span + 1) / n_spans);
+    uint32_t round = 0;
+    for (uint32_t top = hi; top > lo; top = top - lo > 64u ? top - 64u : lo) {  // uniform; descending
+        const uint32_t base = top - lo > 64u ? top - 64u : lo;
+        const uint32_t i = base + lane;
+        const bool have = i < top;
+        uint32_t doc = 0, bits = 0;
+        if (have) {
+            doc = docs[i];
+            bits = vals[i];
+        }
+        if ((round++ & 7u) == 0u && lane == 0) {  // adopt the threshold other spans of the query have published
+            const unsigned long long g = *reinterpret_cast<volatile unsigned long long*>(cs.gthr);
+            if (g > *thr) *thr = g;
+        }
+        for (uint32_t f = 0; f < n_facets; ++f) {  // persistence.rs:164-175 count_values_for_ids: every hit counts
+            const DFacet& fa = facets[f];
+            if (have && doc >= fa.key_base && doc - fa.key_base < fa.num_keys) {
+                const uint32_t row = doc - fa.key_base;
+                if (fa.direct) {
+                    const uint32_t v = as_global(fa.direct)[row];
+                    if (v < fa.num_values) atomicAdd(&hist[fa.hist_off + v], 1u);
+                } else {
+                    const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+                    for (unsigned long long e = e0; e < e1; ++e) {
+                        const uint32_t v = as_global(fa.values)[e];
+                        if (v < fa.num_values) atomicAdd(&hist[fa.hist_off + v], 1u);
+                    }
+                }
+            }
+        }
+        const unsigned long long key = ((unsigned long long)order_f32(bits) << 32) | (unsigned long long)doc;
+        const bool pend = have && key > *thr && key < cs.upper;
+        if (__ballot(pend)) union_push(pend, key, cs, top_k);  // uniform
+    }
+    cand_prune(cs, top_k);
+    {
+        const uint32_t cn = *cand_n;
+        unsigned long long* out = span_keys + (size_t)H->keys_base + (size_t)span * top_k;
+        for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
+    }
+    if (lane == 0 && hi > lo) atomicAdd(&num_hits[q], (unsigned long long)(hi - lo));
+}
+void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
+                          uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
+    if (!total_spans) return;
+    hipLaunchKernelGGL(k_scan_leaf_f32, dim3(total_spans), dim3(64), (8 + 2 * (size_t)cand_cap) * 4 + 16, st, blobs, blob_off, span_base, qmap, nq, cand_cap,
+                       span_keys, num_hits, hist);
+}
+
 }  // namespace vq

@@ -42,6 +42,8 @@ size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_w
 
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                       const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml);
+void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
+                          uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
 size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter);
 uint32_t debug_div100_mismatches();
 void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
