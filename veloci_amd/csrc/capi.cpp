@@ -351,7 +351,11 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
             return;
         }
-        const size_t nchunks = n >= 512 ? 4 : 1;
+        static const size_t chunks_env = [] {
+            const char* e = std::getenv("VQ_FLAT_CHUNKS");
+            return size_t(e ? std::max(1, std::atoi(e)) : 0);
+        }();
+        const size_t nchunks = n >= 512 ? (chunks_env ? chunks_env : 4) : 1;
         std::vector<std::unique_ptr<PartialBatch>> inflight(nchunks);
         auto bounds = [&](size_t c) { return std::make_pair(n * c / nchunks, n * (c + 1) / nchunks); };
         auto finish = [&](size_t c) {
