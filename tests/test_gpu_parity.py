@@ -781,8 +781,11 @@ def test_deep_paging_beyond_one_scan(big_corpus):
         for top, skip in ((1500, 0), (10, 3000), (2000, 1000), (7, 1024), (1025, 0), (5, 10**7)):
             if (i + top + skip) % 2 == 0 or skip > 10**6:
                 reqs.append(dict(shape, top=top, skip=skip))
+    # fewer hits than top + skip asks for: the LAST page is partial (5000 hits: four full pages and 904 more)
+    reqs += [synth.req_single(meta.extra_probes[0], top=6000), dict(synth.req_single(meta.extra_probes[0], top=2000), skip=4500),
+             dict(synth.req_single(meta.extra_probes[0], top=10, boost=[{"path": "pop", "boost_fun": "Multiply", "param": 1.0}]), skip=4995)]
     wants = [ora.search_json(json.dumps(r)) for r in reqs]
-    for r, w in zip(reqs[::3], wants[::3]):
+    for r, w in zip(reqs[::3] + reqs[-3:], wants[::3] + wants[-3:]):
         assert_same(r, veloci_amd.search(r, idx), w)
     for r, g, w in zip(reqs, veloci_amd.search_batch(reqs, idx), wants):
         assert_same(r, g, w)
@@ -944,11 +947,14 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
     def tree(d):
         if d >= 2 or rng.random() < 0.35:
             return leaf()
-        return {("and" if rng.random() < 0.5 else "or"): {"queries": [tree(d + 1) for _ in range(int(rng.integers(2, 5)))]}}
+        wide = d >= 1 and rng.random() < 0.15  # the query generator's one-leaf-per-term-and-field nodes: up to 8 operands here, all leaves
+        return {("and" if rng.random() < 0.5 else "or"): {"queries": [tree(d + 1) for _ in range(int(rng.integers(5, 9) if wide else rng.integers(2, 5)))]}}
 
     reqs = []
     for _ in range(n_requests):
         req = {"search_req": tree(0), "top": int(rng.choice([1, 10, 40]))}
+        if rng.random() < 0.06:  # deep paging: beyond what one scan ranks
+            req["top"], req["skip"] = int(rng.choice([10, 1200])), int(rng.choice([0, 1100, 2500]))
         if rng.random() < 0.25:
             req["filter"] = tree(1)
         if rng.random() < 0.3:
@@ -970,6 +976,8 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
     declined = 0
     for req, g in zip(reqs, got):
         if shards > 1 and isinstance(g, veloci_amd.VelociError) and g.kind == "Unsupported":
+            if req.get("top", 10) + req.get("skip", 0) > 1024:
+                continue  # deep paging is declined on the sharded merge path
             declined += 1
             continue
         assert not isinstance(g, Exception), (str(g), json.dumps(req))

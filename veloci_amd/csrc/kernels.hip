@@ -1258,15 +1258,20 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     }
     cand_prune(cs, top_k, true);  // final ranking: (score desc, id desc); empty slots (0) last
     const uint32_t n = *cs.n;
+    uint32_t mine = 0;
     for (uint32_t i = threadIdx.x; i < top_k; i += kBlock) {
         const unsigned long long k = i < n ? cand[i] : 0ull;
         res_ids[H->part_keys_off + i] = (uint32_t)(k & 0xFFFFFFFFull);
         res_scores[H->part_keys_off + i] = __uint_as_float(unorder_f32((uint32_t)(k >> 32)));
+        mine += k != 0ull ? 1u : 0u;
     }
-    // number of real hits in the top-k window = min(total hits, top_k): keys are unique and non-zero
+    // number of real hits in the top-k window: the non-empty keys (unique, non-zero, sorted first).  min(total hits, top_k) without a
+    // key bound; fewer when only keys below QHeader::key_upper were ranked (a later page of a deep request)
+    uint32_t ranked;
+    (void)wave_excl_scan_u32(mine, &ranked);
     if (threadIdx.x == 0) {
         res_hits[q] = hits;
-        res_n[q] = hits < (unsigned long long)top_k ? (uint32_t)hits : top_k;
+        res_n[q] = ranked;
     }
 }
 
