@@ -434,11 +434,14 @@ def _random_request(rng, info, depth=0):
         if d >= 2 or rng.random() < 0.4:
             return leaf()
         kind = "and" if rng.random() < 0.4 else "or"
-        return {kind: {"queries": [tree(d + 1) for _ in range(int(rng.integers(2, 4)))]}}
+        wide = d >= 1 and rng.random() < 0.1  # (one leaf per term and field, as the query generator writes them)
+        return {kind: {"queries": [tree(d + 1) for _ in range(int(rng.integers(5, 8) if wide else rng.integers(2, 4)))]}}
 
     req = {"search_req": tree(0), "top": int(rng.choice([1, 3, 10, 50]))}
     if rng.random() < 0.2:
         req["skip"] = int(rng.integers(0, 3))
+    if rng.random() < 0.04:  # deep paging (beyond one scan's 1024 ranked hits)
+        req["top"], req["skip"] = int(rng.choice([5, 1500])), int(rng.choice([0, 1030]))
     if rng.random() < 0.25:
         req["filter"] = tree(1)
     if rng.random() < 0.3:
