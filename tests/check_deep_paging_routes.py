@@ -1,6 +1,6 @@
 """One-off check: deep paging through every kernel route (plain / rich / leaf-f32 / generic) against the oracle."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, veloci_amd
 from veloci_amd import synth
 from oracle import binding as O
