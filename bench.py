@@ -4,19 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step is one batch of --batch (default 1024) 3-term AND queries, top 10, executed through the C ABI
-(`vq_search_batch` / the sharded partial + merge path).  The index is fixed at --docs (default 1e8)
-documents and sharded by doc-id range over the N ranks (strong scaling); per-shard top-k are merged
-after one RCCL all-gather per batch.  Rank 0 prints ONE JSON line.
+(`vq_search_batch_flat` / the sharded partial + merge path).  The index is fixed at --docs (default 1e8)
+documents and sharded by doc-id range over the N ranks (strong scaling); per-shard top-k are merged after
+one RCCL all-gather per batch.  `--gpus N` without a launcher starts the N ranks itself (a child
+`torch.distributed.run`, spawned before anything touches the GPU).  Rank 0 prints ONE JSON line.
 
-roofline   : dominant kernel k_scan_simple (3-term AND; other workloads name theirs); achieved = algorithmic bytes (6 B per posting of the three
-             lists + 8 B per returned hit) per launch / mean launch time measured with HIP
-             events on the launch stream inside the library (vq_profile_read).
-cpu_baseline: the CPU oracle (C++ restatement of the reference algorithm, `kind: port`) timed on this
-             host on a bounded sample of the same workload (rank 0, N=1 only).
+roofline    : per kernel, from HIP events the library records around every launch on its stream inside the timed
+              region (vq_profile_json).  `achieved` = bytes THIS data layout has to move per launch (bitmap words of
+              dense lists, 4 B per id of scattered lists, 6 B per streamed posting, per-hit gathers as counted by the
+              kernels, 8 B per key) / mean launch time — a real fraction of the HBM peak, <= 1.  The SURVEY.md 8(d)
+              posting-streaming accounting (6 B per posting of every list) is kept as `algorithmic_equiv`; it exceeds
+              the peak where the layout reads dense lists as bitmaps, and says how fast a design that streams postings
+              would have to read to keep up.
+cpu_baseline: the CPU oracle (C++ restatement of the reference algorithm, `kind: port`) timed on this host on a
+              bounded sample of the same workload (rank 0, N=1 only).
+configs     : (N=1) the same accounting for BASELINE configs #2 (1 M docs, and the 100 M-doc index), #3 and #4,
+              a few steps each, so that every named shape has a driver-run line; --no-extra skips them.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,12 +33,240 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0        # measured float4 copy on MI355X (same guide): what a streaming kernel can reach
+
+WORKLOADS = {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan", "config2": "single-term scan over df 1e3 / 1e5 / 1e6 (config #2)",
+             "config3": "3-term AND + 2 phrase pairs + text locality",
+             "and_of_ors": "AND(OR,OR) + Log10 boost + phrase + locality", "mix": "40% AND / 40% OR / 20% AND(OR,OR)+boost+phrase+locality",
+             "config4": "lev-2 fuzzy term + facets (cat, tags[])", "or8": "flat OR over 8 terms", "and_of_or4": "AND of two 4-term ORs"}
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start one rank per GPU as a child torch.distributed.run (nothing in this
+    process has touched the GPU; it only waits for the child and passes its exit code on)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting", args.gpus, "ranks:", " ".join(cmd[2:8]))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def edited_terms(pool, count, seed=4):
+    """vocabulary terms with 1-2 random edits each (SURVEY.md 8d config #4); distinct"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    alphabet = "abcdefghijklmnopqrstuvwxyz"
+
+    def edit(w):
+        w = list(w)
+        for _ in range(int(rng.integers(1, 3))):
+            op = int(rng.integers(0, 3))
+            pos = int(rng.integers(0, len(w)))
+            if op == 0 and len(w) > 3:
+                del w[pos]
+            elif op == 1:
+                w.insert(pos, alphabet[int(rng.integers(0, 26))])
+            else:
+                w[pos] = alphabet[int(rng.integers(0, 26))]
+        return "".join(w)
+
+    out, seen = [], set()
+    while len(out) < count:
+        t = edit(pool[int(rng.integers(0, len(pool)))])
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    return out
+
+
+def make_requests(workload, meta, batch, probes=1024):
+    from veloci_amd import synth
+    tri = lambda i: list(meta.triples[i % len(meta.triples)])
+    if workload == "and":
+        return [synth.req_and(tri(i), top=10) for i in range(batch)]
+    if workload == "or":
+        return [synth.req_or(tri(i), top=10) for i in range(batch)]
+    if workload == "single":
+        return [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(batch)]
+    if workload == "config2":
+        return [synth.req_single(meta.extra_probes[i % len(meta.extra_probes)], top=10) for i in range(batch)]
+    if workload == "config4":
+        pool = [t for tr in meta.triples for t in tr] + list(meta.background)
+        qterms = edited_terms(pool, min(probes, batch))
+        return [{"search_req": {"search": {"path": "body", "terms": [qterms[i % len(qterms)]], "levenshtein_distance": 2}}, "top": 10,
+                 "facets": [{"field": "cat"}, {"field": "tags[]"}]} for i in range(batch)]
+    if workload in ("or8", "and_of_or4"):
+        # shapes of the reference's query generator (one term expanded over several fields, src/query_generator.rs): a flat OR over 8
+        # leaves, and an AND of two 4-leaf ORs
+        def terms8(i):
+            t = []
+            for j in range(3):
+                t += tri(i + j)
+            return t[:8]
+        leaf = lambda t: {"search": {"path": "body", "terms": [t]}}
+        if workload == "or8":
+            return [{"search_req": {"or": {"queries": [leaf(t) for t in terms8(i)]}}, "top": 10} for i in range(batch)]
+        return [{"search_req": {"and": {"queries": [{"or": {"queries": [leaf(t) for t in terms8(i)[:4]]}}, {"or": {"queries": [leaf(t) for t in terms8(i)[4:]]}}]}},
+                 "top": 10} for i in range(batch)]
+
+    def and_of_ors(i):
+        a, b = tri(i), tri(i + 1)
+        return synth.req_and_of_ors([a[0], a[1]], [a[2], b[2]], top=10)
+    if workload == "config3":
+        return [synth.req_and_phrase_locality(tri(i), top=10) for i in range(batch)]
+    if workload == "and_of_ors":
+        return [and_of_ors(i) for i in range(batch)]
+    if workload == "mix":
+        return [synth.req_and(tri(i), top=10) if i % 5 in (0, 1) else synth.req_or(tri(i), top=10) if i % 5 in (2, 3) else and_of_ors(i) for i in range(batch)]
+    raise ValueError(workload)
+
+
+def spec_for(workload, docs, terms, triples):
+    from veloci_amd import synth
+    rich = workload in ("config3", "and_of_ors", "mix")  # these need the phrase pairs, token->text lists and the boost column
+    fuzzy = workload == "config4"
+    extra = (1000, 100_000, min(1_000_000, docs)) if workload == "config2" else ()
+    return synth.SynthSpec(num_docs=docs, num_terms=terms, triples=triples, with_t2t=rich, with_facets=fuzzy, with_boost=rich, with_phrase=rich,
+                           background_terms=2000 if fuzzy else 0, extra_probe_dfs=extra)
+
+
+def kernel_table(prof):
+    """vq_profile_json -> {kernel: per-launch time, layout-true GB/s and fraction of the HBM peak, the 8(d) figure beside it}"""
+    out = {}
+    for name, k in prof.get("kernels", {}).items():
+        n = max(k["launches"], 1)
+        ms = k["ms"] / n
+        lay, alg = k["layout_bytes"] / n, k["algorithmic_bytes"] / n
+        gbps = lay / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        agbps = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"launch_ms": round(ms, 4), "launches": k["launches"], "queries_per_launch": round(k["queries"] / n, 1), "scan": k["scan"],
+                     "layout_bytes_per_launch": int(lay), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                     "algorithmic_equiv_GBps": round(agbps, 1)}
+    return out
+
+
+def dominant(table):
+    best = None
+    for name, k in table.items():
+        if best is None or k["launch_ms"] * k["launches"] > table[best]["launch_ms"] * table[best]["launches"]:
+            best = name
+    return best
+
+
+class Bench:
+    """One staged index (shard) and the searchers over it."""
+
+    def __init__(self, args, workload, docs, terms, triples, rank, world, local_rank, dist_on):
+        import veloci_amd
+        from veloci_amd import dist as vdist
+        from veloci_amd import synth
+        self.args, self.rank, self.world, self.dist_on = args, rank, world, dist_on
+        t0 = time.time()
+        self.lo, self.hi = vdist.shard_range(docs, rank, world)
+        self.spec = spec_for(workload, docs, terms, triples)
+        self.data, self.meta = synth.generate(self.spec, doc_lo=self.lo, doc_hi=self.hi, device=f"cuda:{local_rank}")
+        t_gen = time.time() - t0
+        if dist_on:
+            vdist.all_reduce_global_lens(self.data)
+        t0 = time.time()
+        self.index = veloci_amd.Index(self.data, device=local_rank, doc_lo=self.lo, doc_hi=self.hi)
+        postings = int(self.data.token_to_anchor_score["body.textindex.to_anchor_id_score"][0][-1])
+        if rank == 0:
+            log(f"{workload}: docs={docs} shard=[{self.lo},{self.hi}) postings/shard={postings} gen={t_gen:.1f}s load={time.time() - t0:.1f}s "
+                f"hbm={self.index.device_bytes / 1e9:.2f} GB")
+        self.searcher = vdist.ShardedSearcher(self.index, always_collective=True) if dist_on else None
+        self.docs = docs
+
+    def run(self, workload, batch_size, steps, warmup, latency=True, chunks=None):
+        """-> (qps, ms_per_step, p50 single-query latency ms, kernel table, first hit counts, requests as dicts)"""
+        import numpy as np
+        import torch
+        import veloci_amd
+        reqs_json = make_requests(workload, self.meta, batch_size, self.args.probes)
+        reqs = [veloci_amd.Request(r) for r in reqs_json]
+        batch = veloci_amd.RequestBatch(reqs)
+        index, searcher = self.index, self.searcher
+
+        def step():
+            # flat C-ABI entry points: no per-result Python objects inside the timed region
+            if searcher is not None:
+                num_hits, counts, ids, scores, status = searcher.search_batch_flat(batch, stride=10, chunks=chunks)
+            else:
+                num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(batch, index, stride=10)
+            assert not status.any(), f"request failed: status {status[status != 0][:4]}"
+            return num_hits
+
+        def sync():
+            torch.cuda.synchronize()
+            if self.dist_on:
+                import torch.distributed as dist
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        hits = None
+        for _ in range(warmup):
+            hits = step()
+        index.profile_enable(True)
+        index.profile_json(reset=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hits = step()
+        sync()
+        dt = time.perf_counter() - t0
+        prof = index.profile_json(reset=True)
+        index.profile_enable(False)
+        if self.dist_on:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if self.args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        lat = []
+        for i in range(50 if latency else 0):  # single-query latency (p50) through the same path
+            a = time.perf_counter()
+            if searcher is not None:
+                searcher.search_batch([reqs[i % len(reqs)]])
+            else:
+                veloci_amd.search_batch([reqs[i % len(reqs)]], index)
+            lat.append((time.perf_counter() - a) * 1e3)
+        p50 = float(np.median(lat[10:])) if lat else None
+        return batch_size * steps / dt, dt / steps * 1e3, p50, kernel_table(prof), [int(x) for x in hits[:3]], reqs_json
+
+
+def roofline_object(table, docs, triples, batch, workload, world):
+    name = dominant({k: v for k, v in table.items() if v["scan"]} or table)
+    k = table[name]
+    roof = {"bound": "hbm", "kernel": name, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac"],
+            "peak_measured_copy": HBM_COPY_GBPS, "frac_of_measured_copy": round(k["GBps"] / HBM_COPY_GBPS, 4), "traffic": None,
+            "bytes_min_this_layout_per_launch": k["layout_bytes_per_launch"], "launch_ms": k["launch_ms"], "launches": k["launches"],
+            "queries_per_launch": k["queries_per_launch"],
+            "algorithmic_equiv": {"GBps": k["algorithmic_equiv_GBps"], "frac": round(k["algorithmic_equiv_GBps"] / HBM_PEAK_GBPS, 4),
+                                  "note": "SURVEY.md 8(d) accounting: 6 B per posting of every list + 8 B per returned hit, as if postings were streamed"},
+            "note": "achieved = bytes this layout must move (bitmap words of dense lists, 4 B per id of scattered lists, 6 B per streamed posting, "
+                    "2-4 B per gathered score / value as counted by the kernel, 8 B per key) / mean launch time from HIP events inside the timed region"}
+    # HBM traffic from PMC passes is taken offline (rocprofv3 cannot wrap a region of this process): reported only when a committed
+    # profile was taken on exactly this configuration, and labelled as such
+    for fn in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                tr = json.load(f)
+            c = tr["config"]
+            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (docs, triples, batch, workload, world):
+                roof["traffic_profiled_offline"] = {"bytes_per_launch": tr["traffic_bytes_per_launch"], "source": f"profiles/{fn}",
+                                                    "how": tr.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    return roof
 
 
 def main():
@@ -38,26 +275,31 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=100_000_000)
-    ap.add_argument("--triples", type=int, default=32, help="distinct (a,b,c) probe triples; the query stream cycles over them")
+    ap.add_argument("--triples", type=int, default=32, help="distinct (a,b,c) probe triples; the query stream cycles over them (256: no query repeats inside a launch)")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
+    ap.add_argument("--probes", type=int, default=1024, help="config4: distinct fuzzy probe terms per batch")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="and", choices=["and", "or", "single", "config3", "and_of_ors", "mix", "config4", "or8", "and_of_or4"],
-                    help="and = the headline metric; or / single = extra shapes; config3 = AND + 2 phrase pairs + text locality; "
-                         "and_of_ors = AND(OR,OR) + Log10 boost + phrase + locality; mix = 40%% and / 40%% or / 20%% and_of_ors (BASELINE configs #3 / #5); "
-                         "config4 = lev-2 fuzzy term + facets on cat and tags[] (use --docs 10000000 --terms 1000000)")
+    ap.add_argument("--workload", default="and", choices=sorted(WORKLOADS),
+                    help="and = the headline metric; config2 / config3 / config4 = BASELINE configs (config4: use --docs 10000000 --terms 1000000); the rest are extra shapes")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of BASELINE configs #2-#4 behind the headline (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-query latency loop (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np  # noqa: F401
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -75,182 +317,58 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    import veloci_amd
-    from veloci_amd import dist as vdist
-    from veloci_amd import synth
-
-    # ---- synthetic index shard (deterministic; shard == slice of the unsharded index)
-    t0 = time.time()
-    lo, hi = vdist.shard_range(args.docs, rank, world)
-    rich = args.workload in ("config3", "and_of_ors", "mix")  # these need the phrase pairs, token->text lists and the boost column
-    fuzzy = args.workload == "config4"
-    spec = synth.SynthSpec(num_docs=args.docs, num_terms=args.terms, triples=args.triples, with_t2t=rich, with_facets=fuzzy, with_boost=rich,
-                           with_phrase=rich, background_terms=2000 if fuzzy else 0)
-    data, meta = synth.generate(spec, doc_lo=lo, doc_hi=hi, device=f"cuda:{local_rank}")
-    t_gen = time.time() - t0
-    if dist_on:
-        vdist.all_reduce_global_lens(data)
-    t0 = time.time()
-    index = veloci_amd.Index(data, device=local_rank, doc_lo=lo, doc_hi=hi)
-    t_load = time.time() - t0
-    postings = int(data.token_to_anchor_score["body.textindex.to_anchor_id_score"][0][-1])
-    if rank == 0:
-        log(f"docs={args.docs} shard=[{lo},{hi}) postings/shard={postings} gen={t_gen:.1f}s load={t_load:.1f}s hbm={index.device_bytes / 1e9:.2f} GB")
-
-    if args.workload == "and":
-        reqs_json = [synth.req_and(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
-    elif args.workload == "or":
-        reqs_json = [synth.req_or(list(meta.triples[i % len(meta.triples)]), top=10) for i in range(args.batch)]
-    elif args.workload == "config4":
-        # 100 distinct query terms: vocabulary terms with posting lists, 1-2 random edits each
-        rng = np.random.default_rng(4)
-        pool = [t for tri in meta.triples for t in tri] + list(meta.background)
-        alphabet = "abcdefghijklmnopqrstuvwxyz"
-        def edit(w):
-            w = list(w)
-            for _ in range(int(rng.integers(1, 3))):
-                op = int(rng.integers(0, 3))
-                pos = int(rng.integers(0, len(w)))
-                if op == 0 and len(w) > 3:
-                    del w[pos]
-                elif op == 1:
-                    w.insert(pos, alphabet[int(rng.integers(0, 26))])
-                else:
-                    w[pos] = alphabet[int(rng.integers(0, 26))]
-            return "".join(w)
-        qterms = [edit(pool[int(rng.integers(0, len(pool)))]) for _ in range(100)]
-        reqs_json = [{"search_req": {"search": {"path": "body", "terms": [qterms[i % len(qterms)]], "levenshtein_distance": 2}}, "top": 10,
-                      "facets": [{"field": "cat"}, {"field": "tags[]"}]} for i in range(args.batch)]
-    elif args.workload in ("or8", "and_of_or4"):
-        # shapes of the reference's query generator (one term expanded over several fields, src/query_generator.rs): a flat OR over 8
-        # leaves, and an AND of two 4-leaf ORs
-        def terms8(i):
-            t = []
-            for j in range(3):
-                t += list(meta.triples[(i + j) % len(meta.triples)])
-            return t[:8]
-        leaf = lambda t: {"search": {"path": "body", "terms": [t]}}
-        if args.workload == "or8":
-            reqs_json = [{"search_req": {"or": {"queries": [leaf(t) for t in terms8(i)]}}, "top": 10} for i in range(args.batch)]
-        else:
-            reqs_json = [{"search_req": {"and": {"queries": [{"or": {"queries": [leaf(t) for t in terms8(i)[:4]]}}, {"or": {"queries": [leaf(t) for t in terms8(i)[4:]]}}]}},
-                          "top": 10} for i in range(args.batch)]
-    elif args.workload == "single":
-        reqs_json = [synth.req_single(meta.triples[i % len(meta.triples)][i // len(meta.triples) % 3], top=10) for i in range(args.batch)]
-    else:
-        tri = lambda i: list(meta.triples[i % len(meta.triples)])
-        def and_of_ors(i):
-            a, b = tri(i), tri(i + 1)
-            return synth.req_and_of_ors([a[0], a[1]], [a[2], b[2]], top=10)
-        if args.workload == "config3":
-            reqs_json = [synth.req_and_phrase_locality(tri(i), top=10) for i in range(args.batch)]
-        elif args.workload == "and_of_ors":
-            reqs_json = [and_of_ors(i) for i in range(args.batch)]
-        else:
-            reqs_json = [synth.req_and(tri(i), top=10) if i % 5 in (0, 1) else synth.req_or(tri(i), top=10) if i % 5 in (2, 3) else and_of_ors(i)
-                         for i in range(args.batch)]
-    reqs = [veloci_amd.Request(r) for r in reqs_json]
-    batch = veloci_amd.RequestBatch(reqs)
-    searcher = vdist.ShardedSearcher(index, always_collective=True) if dist_on else None
+    bench = Bench(args, args.workload, args.docs, args.terms, args.triples, rank, world, local_rank, dist_on)
     bench_chunks = int(os.environ["VQ_BENCH_CHUNKS"]) if os.environ.get("VQ_BENCH_CHUNKS") else None  # None: the searcher's default
-
-    class Row:  # what the bench looks at of a result
-        def __init__(self, nh):
-            self.num_hits = int(nh)
-
-    def step():
-        # flat C-ABI entry points: no per-result Python objects inside the timed region
-        if searcher is not None:
-            num_hits, counts, ids, scores, status = searcher.search_batch_flat(batch, stride=10, chunks=bench_chunks)
-        else:
-            num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(batch, index, stride=10)
-        assert not status.any()
-        return [Row(x) for x in num_hits[:3]]
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist_on:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        res = step()
-    index.profile_enable(True)
-    index.profile_read(reset=True)
-    sync()
-    t0 = time.perf_counter()
-    step_times = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        res = step()
-        step_times.append(time.perf_counter() - ts)
-    t_loop = time.perf_counter() - t0
-    sync()
-    dt = time.perf_counter() - t0
-    if rank == 0 and os.environ.get("VQ_TIMING"):
-        log("step times ms:", [round(x * 1e3, 2) for x in step_times], "loop", round(t_loop * 1e3, 2), "with final sync", round(dt * 1e3, 2))
-    scan_ms, launches, algo_bytes = index.profile_read(reset=True)
-    index.profile_enable(False)
-    if dist_on:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_q = args.batch * args.steps
-    qps = total_q / dt
-
-    # single-query latency (p50) through the same path
-    lat = []
-    for i in range(0 if args.no_latency else 50):
-        a = time.perf_counter()
-        if searcher is not None:
-            searcher.search_batch([reqs[i % len(reqs)]])
-        else:
-            veloci_amd.search_batch([reqs[i % len(reqs)]], index)
-        lat.append((time.perf_counter() - a) * 1e3)
-    p50 = float(np.median(lat[10:])) if lat else float('nan')
+    qps, ms_step, p50, table, first_hits, reqs_json = bench.run(args.workload, args.batch, args.steps, args.warmup, latency=not args.no_latency, chunks=bench_chunks)
 
     out = None
     if rank == 0:
-        per_launch_ms = scan_ms / max(launches, 1)
-        per_launch_bytes = algo_bytes / max(launches, 1)
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        peak = 8000.0
+        spec = bench.spec
         out = {
             "metric": "queries/sec, 3-term AND on 100M-doc index (p50 latency and HBM fraction alongside)",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 doc ids + f16->f32 scores", "data": "synthetic",
-            "config": {"workload": f"{args.docs}-doc synthetic index, " + {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan",
-                                                                              "config3": "3-term AND + 2 phrase pairs + text locality",
-                                                                              "and_of_ors": "AND(OR,OR) + Log10 boost + phrase + locality",
-                                                                              "mix": "40% AND / 40% OR / 20% AND(OR,OR)+boost+phrase+locality",
-                                                                              "config4": "lev-2 fuzzy term + facets (cat, tags[])", "or8": "flat OR over 8 terms",
-                                                                              "and_of_or4": "AND of two 4-term ORs"}[args.workload] +
-                       f" (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
+            "config": {"workload": f"{args.docs}-doc synthetic index, {WORKLOADS[args.workload]} (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
-                       "sharding": f"doc-range x{world}", "first_hit_counts": [int(r.num_hits) for r in res[:3]]},
-            "p50_latency_ms_single_query": (round(p50, 3) if p50 == p50 else None),
-            "roofline": {"bound": "hbm", "kernel": {"and": "k_scan_simple", "or": "k_scan_simple", "single": "k_scan_union", "config3": "k_scan_simple<rich>", "and_of_ors": "k_scan_simple<rich>",
-                                                    "mix": "k_scan_simple (plain + rich launches)", "config4": "k_scan_simple<rich> (+ k_dict_scan, k_union pre-passes)"}.get(args.workload, "k_tile_scan"), "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "launch_ms": round(per_launch_ms, 4), "launches": int(launches),
-                         "note": "achieved = algorithmic bytes (6 B per posting + 8 B per returned hit, SURVEY.md 8d) / mean launch time; the kernel reads dense "
-                                 "lists as bitmap images, so it moves fewer HBM bytes than that (see traffic) and frac can exceed 1"},
+                       "sharding": f"doc-range x{world}", "first_hit_counts": first_hits},
+            "p50_latency_ms_single_query": (round(p50, 3) if p50 is not None else None),
+            "roofline": roofline_object(table, args.docs, args.triples, args.batch, args.workload, world),
+            "kernels": table,
         }
-        # HBM traffic per launch from the committed PMC passes (profiles/r01_traffic.json), when they were taken on this configuration
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tr = json.load(f)
-            c = tr["config"]
-            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (args.docs, args.triples, args.batch, args.workload, world):
-                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-        except (OSError, KeyError, ValueError):
-            pass
         if world == 1 and not args.no_cpu and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(data, meta, reqs_json, args)
+            out["cpu_baseline"] = cpu_baseline(bench.data, bench.meta, reqs_json, args)
+
+    # ---- BASELINE configs #2 - #4, a few steps each (N=1): the other named shapes, same accounting
+    if rank == 0 and world == 1 and not dist_on and not args.no_extra and args.workload == "and":
+        extras = {}
+
+        def short(name, b, workload, steps=4, **kw):
+            try:
+                q, ms, p, tab, fh, _ = b.run(workload, args.batch, steps, 1, **kw)
+                extras[name] = {"value": round(q, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "p50_latency_ms_single_query": round(p, 3) if p is not None else None,
+                                "workload": f"{b.docs}-doc index, {WORKLOADS[workload]}, batches of {args.batch}", "first_hit_counts": fh,
+                                "dominant_kernel": dominant({k: v for k, v in tab.items() if v["scan"]} or tab), "kernels": tab}
+            except Exception as ex:  # noqa: BLE001 — an extra line must never take the headline down
+                extras[name] = {"error": repr(ex)[:300]}
+
+        short("config2_100m_docs", bench, "single")
+        del bench
+        import gc
+        gc.collect()
+        for name, workload, docs, terms, triples in (("config2_1m_docs", "config2", 1_000_000, 100_000, 1),
+                                                     ("config3_10m_docs", "config3", 10_000_000, 1_000_000, 32),
+                                                     ("config4_10m_docs", "config4", 10_000_000, 1_000_000, 32)):
+            try:
+                b = Bench(args, workload, docs, terms, triples, 0, 1, local_rank, False)
+            except Exception as ex:  # noqa: BLE001
+                extras[name] = {"error": repr(ex)[:300]}
+                continue
+            short(name, b, workload)
+            del b
+            gc.collect()
+        out["configs"] = extras
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
@@ -260,13 +378,15 @@ def main():
 
 
 def cpu_baseline(data, meta, reqs_json, args):
-    """CPU oracle on a bounded sample: the first two probe triples' posting lists, the same AND requests."""
+    """CPU oracle on a bounded sample: the first probe triples' posting lists, the same AND requests; >= 1000 measured queries in the
+    all-core mode (one independent query per thread: how the reference is driven by its server threads), single-thread p50 beside it."""
+    import numpy as np
     from oracle import binding as O
     from veloci_amd.index import IndexData
     t0 = time.time()
     path = "body.textindex.to_anchor_id_score"
     offsets, anchors, scores, _ = data.token_to_anchor_score[path]
-    n_tri = min(2, len(meta.triples))
+    n_tri = min(4, len(meta.triples))
     keep = set()
     for tri in meta.triples[:n_tri]:
         for t in tri:
@@ -285,28 +405,32 @@ def cpu_baseline(data, meta, reqs_json, args):
     ora = O.OracleIndex(data.num_anchors)
     sample.load_into(ora)
     sample_reqs = [json.dumps(r) for r in reqs_json[:n_tri]]
-    # calibrate, then spend about --cpu-seconds in total over the two modes
-    secs, lat, _ = ora.bench(sample_reqs, repeat=1, threads=1)
-    per_q = secs / len(sample_reqs)
-    # host cores of this job's share of the box (one GPU's share is 16 cores on this pool)
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))  # the host cores this job may use
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
-    rep1 = max(1, int(args.cpu_seconds * 0.4 / max(per_q, 1e-6) / len(sample_reqs)))
+    cores = max(1, cores)
+    # single thread: a few queries for the latency (the budget goes to the all-core throughput run)
+    secs, lat, _ = ora.bench(sample_reqs, repeat=1, threads=1)
+    per_q = secs / len(sample_reqs)
+    rep1 = max(1, int(args.cpu_seconds * 0.25 / max(per_q, 1e-6) / len(sample_reqs)))
     secs1, lat1, _ = ora.bench(sample_reqs, repeat=rep1, threads=1)
-    # all-core mode does not scale linearly (allocation + memory bound): calibrate it on its own
+    # all cores: calibrate (it does not scale linearly: allocation + memory bound), then >= 1000 queries or the budget, whichever is more
     repc = max(1, cores // len(sample_reqs))
     secsc, _, _ = ora.bench(sample_reqs, repeat=repc, threads=cores)
-    repn = max(repc, int(args.cpu_seconds * 0.6 / max(secsc, 1e-6) * repc))
+    per_rep = secsc / repc
+    repn = max(int(np.ceil(1000 / len(sample_reqs))), int(args.cpu_seconds * 0.75 / max(per_rep, 1e-6)))
+    if repn * per_rep > 4 * args.cpu_seconds:  # a slow host: stay bounded, say so in `sample`
+        repn = max(repc, int(4 * args.cpu_seconds / max(per_rep, 1e-6)))
     secsn, latn, _ = ora.bench(sample_reqs, repeat=repn, threads=cores)
     qps_n = len(sample_reqs) * repn / secsn
-    log(f"cpu baseline: setup {time.time() - t0:.1f}s, 1 thread {len(sample_reqs) * rep1 / secs1:.2f} q/s, {cores} threads {qps_n:.2f} q/s")
+    log(f"cpu baseline: setup {time.time() - t0:.1f}s, 1 thread {len(sample_reqs) * rep1 / secs1:.2f} q/s, {cores} threads {qps_n:.2f} q/s over {len(sample_reqs) * repn} queries")
     return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "measured_queries": len(sample_reqs) * repn, "p50_ms_all_cores": round(float(np.median(latn)) / 1e6, 3), "p95_ms_all_cores": round(float(np.percentile(latn, 95)) / 1e6, 3),
             "single_thread_qps": round(len(sample_reqs) * rep1 / secs1, 3), "single_thread_p50_ms": round(float(np.median(lat1)) / 1e6, 3),
             "sample": f"C++ restatement of the reference algorithm (oracle/, not the Rust binary); {n_tri} of the {len(meta.triples)} probe triples, "
-                      f"{len(sample_reqs) * (rep1 + repn)} 3-term AND queries on the full {data.num_anchors}-doc lists, one independent query per thread"}
+                      f"{len(sample_reqs) * repn} 3-term AND queries on the full {data.num_anchors}-doc lists with one independent query per thread on {cores} threads "
+                      f"(+ {len(sample_reqs) * rep1} on one thread for the latency)"}
 
 
 if __name__ == "__main__":

@@ -202,8 +202,13 @@ int vq_search_batch_partial(const vq_index*, const vq_request* const* requests, 
  * for the same requests).  Resident in HBM: `device_ptr` can be handed to RCCL. */
 size_t vq_partial_bytes(const vq_partial_batch*);
 void* vq_partial_device_ptr(vq_partial_batch*);
+/* The batch's facet histograms (u32 counts over value ids; 0 bytes without facet requests) live behind the all-gathered part
+ * and are NOT part of it: the caller sums them over the shards in place with an all-reduce (ncclSum on `vq_partial_hist_bytes / 4`
+ * u32 — SURVEY.md 8e: facet counts are additive) before `vq_merge_partials*`.  With one shard nothing needs to be done. */
+size_t vq_partial_hist_bytes(const vq_partial_batch*);
+void* vq_partial_hist_device_ptr(vq_partial_batch*);
 /* Merge `num_shards` gathered packed buffers (device memory, shard-major,
- * each `vq_partial_bytes` long) into final results. */
+ * each `vq_partial_bytes` long) into final results; facet counts are read from `local`'s (already summed) histograms. */
 int vq_merge_partials(const vq_index*, vq_partial_batch* local, const void* gathered_device,
                       uint32_t num_shards, vq_result** out, int* status);
 /* Same merge with flat output (see vq_search_batch_flat). */
@@ -217,8 +222,21 @@ void vq_partial_free(vq_partial_batch*);
  * dominant scan kernel accumulated since the last call with reset != 0. */
 int vq_profile_read(const vq_index*, int reset, double* scan_kernel_ms, uint64_t* scan_launches,
                     uint64_t* algorithmic_bytes);
-/* Enable (1) / disable (0) the HIP-event bracketing used by vq_profile_read. */
+/* Enable (1) / disable (0) the HIP-event bracketing used by vq_profile_read / vq_profile_json. */
 int vq_profile_enable(vq_index*, int on);
+/* Per-kernel accounting since the last reset, as JSON (thread-local string, valid until the next call on this thread):
+ * {"batches": n, "kernels": {"<kernel>": {"ms", "launches", "layout_bytes", "algorithmic_bytes", "queries", "scan"}}}.
+ * ms = device time between HIP events recorded around the launch on its stream; layout_bytes = the bytes THIS data layout has to
+ * move for those launches (bitmap words of dense lists, 4 B per id of scattered lists, 6 B per streamed posting, the bytes of
+ * per-hit gathers as counted by the kernels, 8 B per key written) — the roofline numerator; algorithmic_bytes = SURVEY.md 8(d)'s
+ * posting-streaming accounting, kept for comparison. */
+const char* vq_profile_json(const vq_index*, int reset);
+
+/* ------------------------------------------------------------- self-checks (tests) */
+
+/* Number of f16 inputs for which the kernels' fast `a / 100.0f` differs from the correctly rounded division (must be 0);
+ * 0xFFFFFFFF when no device is available. */
+uint32_t vq_debug_div100_mismatches(void);
 
 const char* vq_version(void);
 

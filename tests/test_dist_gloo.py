@@ -30,7 +30,7 @@ def _order_f32(bits):
 
 
 def _pack(results, top_k, hist_sizes):
-    """Same layout as the device partial: [u64 hits[nq]][u64 keys[nq*top_k]][u32 hist[...]]."""
+    """Same split as the device partial: ([u64 hits[nq]][u64 keys[nq*top_k]], [u32 hist[...]])."""
     nq = len(results)
     hits = np.zeros(nq, np.uint64)
     keys = np.zeros(nq * top_k, np.uint64)
@@ -45,8 +45,10 @@ def _pack(results, top_k, hist_sizes):
             for v, c in entries:
                 h[names[v]] = c
             hist.append(h)
-    buf = np.concatenate([hits.view(np.uint8), keys.view(np.uint8)] + [h.view(np.uint8) for h in hist])
-    return torch.from_numpy(buf.copy())
+    # the all-gathered part (hit counts, keys) and the all-reduced part (facet histograms) — DESIGN.md §6
+    buf = np.concatenate([hits.view(np.uint8), keys.view(np.uint8)])
+    hbuf = np.concatenate([h.view(np.uint8) for h in hist]) if hist else np.zeros(0, np.uint8)
+    return torch.from_numpy(buf.copy()), torch.from_numpy(hbuf.copy())
 
 
 def _worker(rank, world, port, out_path):
@@ -76,9 +78,10 @@ def _worker(rank, world, port, out_path):
     reqs = [synth.req_and([a, b, c], top=top_k), synth.req_or([a, b], top=top_k), synth.req_single(meta.extra_probes[0], top=top_k)]
     reqs[1]["facets"] = [{"field": "cat", "top": 16}]
     res = [ora.search_json(json.dumps(r)) for r in reqs]
-    local = _pack(res, top_k, cats)
+    local, local_hist = _pack(res, top_k, cats)
     gathered = vdist.gather_partials(local)
     assert gathered.numel() == world * local.numel()
+    summed_hist = vdist.reduce_histograms(local_hist.clone())  # one all-reduce: every rank ends up with the global counts
 
     if rank == 0:
         full, _ = synth.generate(spec, device="cpu")
@@ -105,7 +108,7 @@ def _worker(rank, world, port, out_path):
             k = g[p, nq * 8:nq * 8 + nq * top_k * 8].view(np.uint64).reshape(nq, top_k)
             for q in range(nq):
                 keys[q] += [int(x) for x in k[q] if x]
-            hist += g[p, nq * 8 + nq * top_k * 8:].view(np.uint32)
+        hist += summed_hist.numpy().view(np.uint32)
         problems = []
         for q in range(nq):
             merged = sorted(keys[q], reverse=True)[:top_k]

@@ -234,9 +234,8 @@ def test_two_shards_merge_equals_unsharded(corpus):
     p0 = veloci_amd.PartialBatch(s0, reqs)
     p1 = veloci_amd.PartialBatch(s1, reqs)
     assert p0.nbytes == p1.nbytes
-    from veloci_amd.dist import device_view
-    g = torch.cat([device_view(p0.device_ptr, p0.nbytes).clone(), device_view(p1.device_ptr, p1.nbytes).clone()])
-    torch.cuda.synchronize()
+    from veloci_amd.dist import exchange_local
+    g = exchange_local([p0, p1])
     res = p0.merge(g.data_ptr(), 2)
     p1.merge(None, 1)  # releases the shard's workspace
     for r, got in zip(reqs, res):
@@ -719,6 +718,39 @@ def test_full_size_index_matches_the_oracle():
         assert_same(r, g, w, exact_scores=exact(r))
 
 
+def test_config4_real_shape_matches_the_oracle():
+    """BASELINE configs[3] at its own scale: 10 M docs, a 1 M-term dictionary, lev-2 fuzzy single-term requests (100 vocabulary terms with
+    1-2 random edits, the bench's generator) with facets on `cat` and `tags[]` — k_dict_scan over a multi-block grid, CSR offsets at
+    T = 1e6, unions of many posting lists (two-level when > 64), facet rows of leaves with ~1e6 hits — against the oracle, single and batched."""
+    import veloci_amd
+    from veloci_amd import synth
+    from oracle import binding as O
+    from parity import assert_same
+    import bench
+    spec = synth.SynthSpec(num_docs=10_000_000, num_terms=1_000_000, triples=4, with_t2t=False, with_phrase=False, with_boost=False, with_facets=True,
+                           background_terms=2000)
+    data, meta = synth.generate(spec)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    pool = [t for tr in meta.triples for t in tr] + list(meta.background)
+    qterms = bench.edited_terms(pool, 100)
+    reqs = [{"search_req": {"search": {"path": "body", "terms": [t], "levenshtein_distance": 2}}, "top": 10, "facets": [{"field": "cat"}, {"field": "tags[]"}]}
+            for t in qterms]
+    wants = [ora.search_json(json.dumps(r)) for r in reqs]
+    assert sum(w.num_hits > 0 for w in wants) >= 50 and max(w.num_hits for w in wants) >= 500_000  # the shape is exercised
+    for r, w in list(zip(reqs, wants))[:25]:
+        assert_same(r, veloci_amd.search(r, idx), w)
+    for r, g, w in zip(reqs, veloci_amd.search_batch(reqs, idx), wants):
+        assert_same(r, g, w)
+    # the same probes inside trees: an AND of two fuzzy leaves, and a fuzzy leaf under a filter
+    tree = [{"search_req": {"and": {"queries": [{"search": {"path": "body", "terms": [qterms[i]], "levenshtein_distance": 2}},
+                                                 {"search": {"path": "body", "terms": [qterms[i + 1]], "levenshtein_distance": 2}}]}}, "top": 10}
+            for i in range(0, 20, 2)]
+    for r, g in zip(tree, veloci_amd.search_batch(tree, idx)):
+        assert_same(r, g, ora.search_json(json.dumps(r)))
+
+
 def test_degenerate_inputs(corpus):
     """Empty batch, top 0, skip beyond the hits, a one-document index, an index without documents, a shard that holds no posting of
     the query — against the oracle where it has an answer."""
@@ -920,8 +952,8 @@ def _search_batch_over_shards(data, reqs, shards):
         t.join()
     assert not errs, errs
     assert len({pb.nbytes for pb in pbs}) == 1
-    g = torch.cat([device_view(pb.device_ptr, pb.nbytes).clone() for pb in pbs])
-    torch.cuda.synchronize()
+    from veloci_amd.dist import exchange_local
+    g = exchange_local(pbs)
     got = pbs[0].merge(g.data_ptr(), shards, raise_on_error=False)
     for pb in pbs[1:]:
         pb.merge(None, 1, raise_on_error=False)

@@ -17,8 +17,9 @@ SYMBOLS = [
     "vq_index_free", "vq_index_set_stream", "vq_index_set_streams", "vq_index_set_allreduce", "vq_index_device_bytes", "vq_request_parse", "vq_request_free", "vq_result_num_hits",
     "vq_result_execution_time_ns", "vq_result_len", "vq_result_ids", "vq_result_scores", "vq_result_num_facets", "vq_result_facet_field",
     "vq_result_facet_len", "vq_result_facet_value", "vq_result_facet_count", "vq_result_to_json", "vq_result_free", "vq_search", "vq_search_json",
-    "vq_search_batch", "vq_search_batch_flat", "vq_search_batch_partial", "vq_partial_bytes", "vq_partial_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
-    "vq_profile_read", "vq_profile_enable", "vq_version",
+    "vq_search_batch", "vq_search_batch_flat", "vq_search_batch_partial", "vq_partial_bytes", "vq_partial_device_ptr", "vq_partial_hist_bytes",
+    "vq_partial_hist_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
+    "vq_profile_read", "vq_profile_enable", "vq_profile_json", "vq_debug_div100_mismatches", "vq_version",
 ]
 
 
@@ -90,6 +91,10 @@ def lib():
         "vq_search_batch_partial": (i, [vp, C.POINTER(vp), sz, C.POINTER(vp)]),
         "vq_partial_bytes": (sz, [vp]),
         "vq_partial_device_ptr": (vp, [vp]),
+        "vq_partial_hist_bytes": (sz, [vp]),
+        "vq_partial_hist_device_ptr": (vp, [vp]),
+        "vq_profile_json": (cp, [vp, i]),
+        "vq_debug_div100_mismatches": (u32, []),
         "vq_merge_partials": (i, [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(i)]),
         "vq_merge_partials_flat": (i, [vp, vp, vp, u32, sz, vp, vp, vp, vp, vp]),
         "vq_partial_free": (None, [vp]),

@@ -391,8 +391,10 @@ int vq_search_batch_partial(const vq_index* index, const vq_request* const* requ
         *out = h;
     });
 }
-size_t vq_partial_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.bytes) : 0; }
+size_t vq_partial_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.off_hist) : 0; }
 void* vq_partial_device_ptr(vq_partial_batch* p) { return p ? p->pb->d_partial : nullptr; }
+size_t vq_partial_hist_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.total_hist) * 4 : 0; }
+void* vq_partial_hist_device_ptr(vq_partial_batch* p) { return p && p->pb->d_partial ? p->pb->d_partial + p->pb->layout.off_hist : nullptr; }
 
 // the sharded path ranks top + skip <= kMaxTopK per request: paging a deep request would need the merged result of every page on all ranks
 static void decline_deep(std::vector<std::unique_ptr<Result>>& results, std::vector<int>& st, std::vector<std::string>& errs) {
@@ -445,20 +447,46 @@ int vq_profile_enable(vq_index* i, int on) {
         i->idx->profile.enabled = on != 0;
     });
 }
+static bool is_scan_kernel(int k) { return k >= K_SCAN_LEAF_F32 && k <= K_TILE_SCAN; }
 int vq_profile_read(const vq_index* i, int reset, double* scan_kernel_ms, uint64_t* scan_launches, uint64_t* algorithmic_bytes) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_profile_read: null index");
         std::lock_guard<std::mutex> g(i->idx->profile_mutex);
         Profile& p = i->idx->profile;
-        if (scan_kernel_ms) *scan_kernel_ms = p.scan_ms;
-        if (scan_launches) *scan_launches = p.scan_launches;
-        if (algorithmic_bytes) *algorithmic_bytes = p.algorithmic_bytes;
-        if (reset) {
-            p.scan_ms = 0;
-            p.scan_launches = 0;
-            p.algorithmic_bytes = 0;
-        }
+        double ms = 0;
+        uint64_t algo = 0;
+        for (int k = 0; k < K_COUNT_; ++k)
+            if (is_scan_kernel(k)) {
+                ms += p.k[k].ms;
+                algo += p.k[k].algorithmic_bytes;
+            }
+        if (scan_kernel_ms) *scan_kernel_ms = ms;
+        if (scan_launches) *scan_launches = p.batches;
+        if (algorithmic_bytes) *algorithmic_bytes = algo;
+        if (reset) p = Profile{p.enabled};
     });
+}
+const char* vq_profile_json(const vq_index* i, int reset) {
+    thread_local std::string out;
+    out = "{}";
+    if (!i) return out.c_str();
+    std::lock_guard<std::mutex> g(i->idx->profile_mutex);
+    Profile& p = i->idx->profile;
+    out = "{\"batches\":" + std::to_string(p.batches) + ",\"kernels\":{";
+    bool first = true;
+    for (int k = 0; k < K_COUNT_; ++k) {
+        const KernelProfile& kp = p.k[k];
+        if (!kp.launches) continue;
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s\"%s\":{\"ms\":%.6f,\"launches\":%llu,\"layout_bytes\":%llu,\"algorithmic_bytes\":%llu,\"queries\":%llu,\"scan\":%s}",
+                      first ? "" : ",", kKernelNames[k], kp.ms, (unsigned long long)kp.launches, (unsigned long long)kp.layout_bytes,
+                      (unsigned long long)kp.algorithmic_bytes, (unsigned long long)kp.queries, is_scan_kernel(k) ? "true" : "false");
+        out += buf;
+        first = false;
+    }
+    out += "}}";
+    if (reset) p = Profile{p.enabled};
+    return out.c_str();
 }
 
 #ifdef VQ_STAMP

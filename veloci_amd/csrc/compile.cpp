@@ -1660,6 +1660,42 @@ struct Compiler {
         }
         cq.max_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 4096));
         if ((cq.simple_flags >> 19) & 1u) cq.max_spans = uint32_t(std::min<uint64_t>(std::max<uint64_t>(cq.lists[cq.ops[0].list_begin].len / 64, 1), 4096));
+        compute_layout_bytes(root.cover_len);
+    }
+
+    // Bytes this data layout has to move for the query, as far as they are known before it runs (KernelProfile::layout_bytes; the
+    // per-hit gathers are counted by the kernels): a list read as a bitmap image costs its words over the visited tiles plus one rank
+    // directory entry per tile, a scattered list 4 B per id, a streamed posting list 6 B per posting, a materialised leaf 8 B per entry.
+    void compute_layout_bytes(uint64_t cover_len) {
+        const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
+        const bool simple = cq.simple_flags != 0;
+        const uint64_t tile_docs = simple ? 16384 : uint64_t(cq.tile_words) << 5;
+        const uint64_t tiles = std::max<uint64_t>((range + tile_docs - 1) / tile_docs, 1);
+        const bool seq = simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
+        const uint64_t visited = seq ? tiles : std::min<uint64_t>(std::max<uint64_t>(cover_len, 1), tiles);
+        auto bitmap_cost = [&]() { return visited * (tile_docs / 8 + 4); };
+        uint64_t b = 8ull * cq.top_k;
+        if ((cq.simple_flags >> 19) & 1u) b += 8ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_leaf_f32
+        else if (simple && !((cq.simple_flags >> 18) & 1u) && cq.simple_n == 1 && std::getenv("VQ_NO_UNION") == nullptr)
+            b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
+        else if (simple) {
+            std::vector<bool> seen(cq.lists.size(), false);
+            const bool rich = (cq.simple_flags >> 18) & 1u;
+            for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                const uint32_t li = rich ? cq.simple2.leaf_list[k] : cq.ops[k].list_begin;
+                seen[li] = true;
+                b += ((cq.simple_flags >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[li].len;
+            }
+            for (uint32_t li = 0; li < cq.lists.size(); ++li)
+                if (!seen[li]) b += 4ull * cq.lists[li].len;  // side lists
+        } else {
+            for (auto& l : cq.lists) {
+                const bool as_bitmap = (l.flags & LIST_BITMAP) && !(l.flags & LIST_COVER);
+                b += as_bitmap ? bitmap_cost() : 4ull * l.len;
+            }
+        }
+        for (auto& f : cq.facets) b += 4ull * f.num_values;
+        cq.layout_bytes = b;
     }
 };
 

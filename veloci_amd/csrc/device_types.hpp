@@ -159,7 +159,8 @@ struct QHeader {
     unsigned long long key_upper;  // only keys BELOW this enter the top-k (~0: no bound): page p of a deep request ranks what lies below the last key of page p-1
     uint32_t seq_tiles;      // k_tile_scan: a dense list is in the cover -> every tile of the span is visited, dense lists are copied from
                              // their bitmap images (their LIST_COVER flag is dropped)
-    uint32_t pad2;
+    uint32_t stat_off;       // u64 index (relative to the `num_hits` base the kernels get) of this query's gathered-bytes counter: bytes the
+                             // scan read by per-hit gathers (f16 scores 2 B, f32 values / boost columns / facet values 4 B, CSR offset pairs 16 B)
     uint32_t prune_gbits[16];
     uint32_t n_counts;       // != 0: count pre-pass — only the presence program runs, PRES_COUNT counters are added to
                              // counts[part_keys_off + c] (the buffer passed as `num_hits`); nothing is scored
@@ -171,10 +172,12 @@ struct QHeader {
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):
-//   [u64 num_hits[nq]] [u64 keys[total_keys]] [u32 hist[total_hist]]
+//   [u64 num_hits[nq]] [u64 gathered_bytes[nq]] [u64 keys[total_keys]] [u32 hist[total_hist]]
+// Everything in front of `off_hist` is exchanged by an all-gather; the histograms may be summed over the shards by an all-reduce
+// instead (vq_partial_hist_*), SURVEY.md §8e.
 struct PartialLayout {
     uint64_t nq, total_keys, total_hist;
-    uint64_t off_hits, off_keys, off_hist, bytes;
+    uint64_t off_hits, off_stats, off_keys, off_hist, bytes;
 };
 
 // 64-bit ranking key: (order-preserving f32 bits << 32) | doc  — larger == better under

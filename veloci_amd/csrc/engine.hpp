@@ -272,25 +272,56 @@ struct PinnedBuf {  // page-locked host staging
 
 constexpr int kWorkspaces = 2;  // batches in flight per index (host compile of one overlaps the scan of the other)
 
+// Kernels the profiler accounts separately (vq_profile_json): the pre-passes, one entry per scan class, the merges.
+enum KernelId : int {
+    K_DICT_SCAN = 0, K_UNION_COUNT, K_UNION_WRITE, K_RANGE_HITS, K_COUNT_PREPASS, K_SCAN_LEAF_F32, K_SCAN_RICH, K_SCAN_AND, K_SCAN_SIMPLE, K_SCAN_UNION,
+    K_SCAN_WIDE, K_TILE_SCAN, K_MERGE_SPANS, K_FINALIZE, K_FACET_SELECT, K_LOCALITY, K_BOOST1N, K_COUNT_
+};
+extern const char* const kKernelNames[K_COUNT_];
+
+struct TimedLaunch {  // one profiled launch of a batch: events [begin, end] on the launch stream
+    int kernel;
+    uint32_t ev_begin, ev_end;
+    uint64_t layout_bytes, algorithmic_bytes, queries;
+};
+
 struct Workspace {  // scratch of one in-flight batch
     std::mutex mu;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the scan launch (profiling)
+    std::vector<hipEvent_t> ev_pool;          // profiling: created on first use
+    uint32_t ev_used = 0;
+    std::vector<TimedLaunch> timed;           // launches of the batch in flight (profiling)
     hipEvent_t ev_done = nullptr;             // scan + span merge finished: the finish stream waits on it
     PinnedBuf h_up, h_down;
     DevBuf d_up;        // blobs + blob_off + span_base + facet jobs
     DevBuf d_span_keys;
     DevBuf d_partial;
-    DevBuf d_hist_sum;
     DevBuf d_down;      // results
     DevBuf d_union_docs[2], d_union_vals[2], d_union_max, d_union_meta;  // materialised leaves (k_union), level 1 / level 2
     DevBuf d_probe_desc, d_probe_counts, d_probe_ids;                    // dictionary scans (k_dict_scan): kept, so that no hipFree synchronises the device mid-pipeline
 };
 
+struct KernelProfile {
+    double ms = 0;
+    uint64_t launches = 0;
+    uint64_t layout_bytes = 0;       // bytes THIS layout has to move for the launches (bitmap words of dense lists, 4 B per id of scattered lists,
+                                     // 6 B per streamed posting, gathered bytes counted by the kernels, 8 B per returned key): roofline numerator
+    uint64_t algorithmic_bytes = 0;  // SURVEY.md 8(d) accounting (6 B per posting of every list ...): what a posting-streaming design would move
+    uint64_t queries = 0;
+};
 struct Profile {
     bool enabled = false;
-    double scan_ms = 0;
-    uint64_t scan_launches = 0;
-    uint64_t algorithmic_bytes = 0;
+    KernelProfile k[K_COUNT_];
+    uint64_t batches = 0;
+};
+// RAII bracket of one launch (or a few back-to-back launches of one kernel) with two events of the workspace's pool
+struct LaunchTimer {
+    Workspace* ws = nullptr;
+    hipStream_t st = nullptr;
+    size_t slot = 0;
+    LaunchTimer(bool on, Workspace& w, hipStream_t s, int kernel, uint64_t layout_bytes = 0, uint64_t algorithmic_bytes = 0, uint64_t queries = 0);
+    ~LaunchTimer();
+    LaunchTimer(const LaunchTimer&) = delete;
+    LaunchTimer& operator=(const LaunchTimer&) = delete;
 };
 
 // A few persistent host threads for the per-request work of a batch (query compilation): spawning threads per chunk costs more
@@ -410,6 +441,7 @@ struct CompiledQuery {
     uint32_t top = 10, skip = 0, top_k = 10;
     uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
     uint64_t algorithmic_bytes = 0;
+    uint64_t layout_bytes = 0;   // static part of KernelProfile::layout_bytes for this query (set when the kernel route is known)
     uint64_t key_upper = ~0ull;  // QHeader::key_upper
     bool deep = false;           // top + skip > kMaxTopK: this compilation ranks the first kMaxTopK only; the caller pages on (search_pages)
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
@@ -448,6 +480,7 @@ struct PartialBatch {
     std::unique_lock<std::mutex> lock;    // holds the workspace until the batch is finished
     std::vector<CompiledQuery> queries;   // status != 0: failed at compile time
     std::vector<uint32_t> slot;           // slot[i]: position of request i among the device queries, or UINT32_MAX
+    std::vector<uint8_t> qclass;          // profiling: KernelId of the scan that serves device query q
     uint32_t nq_dev = 0;
     PartialLayout layout{};
     // device addresses inside the workspace

@@ -31,6 +31,28 @@ void PinnedBuf::ensure(size_t n) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+const char* const kKernelNames[K_COUNT_] = {"k_dict_scan", "k_union<count>", "k_union<write>", "k_range_hits", "k_tile_scan<count pre-pass>", "k_scan_leaf_f32",
+                                            "k_scan_simple<2,rich>", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
+                                            "k_merge_spans", "k_finalize", "k_facet_select", "k_locality", "k_boost1n"};
+
+LaunchTimer::LaunchTimer(bool on, Workspace& w, hipStream_t s, int kernel, uint64_t layout_bytes, uint64_t algorithmic_bytes, uint64_t queries) {
+    if (!on) return;
+    if (w.ev_pool.empty()) {
+        w.ev_pool.resize(96, nullptr);
+        for (auto& e : w.ev_pool) VQ_HIP(hipEventCreate(&e));
+    }
+    if (w.ev_used + 2 > w.ev_pool.size()) return;  // (more launches than events: the rest of the batch goes untimed)
+    ws = &w;
+    st = s;
+    slot = w.timed.size();
+    w.timed.push_back(TimedLaunch{kernel, w.ev_used, w.ev_used + 1, layout_bytes, algorithmic_bytes, queries});
+    w.ev_used += 2;
+    VQ_HIP(hipEventRecord(w.ev_pool[w.timed[slot].ev_begin], st));
+}
+LaunchTimer::~LaunchTimer() {
+    if (ws) (void)hipEventRecord(ws->ev_pool[ws->timed[slot].ev_end], st);
+}
+
 HostPool::HostPool(size_t workers) {
     for (size_t i = 0; i < workers; ++i) threads_.emplace_back([this] { worker(); });
 }
@@ -96,7 +118,7 @@ static HostPool& host_pool(const Index& idx) {
 
 // serialise one compiled query into `dst` (host), whose device address will be `dev`
 static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst, const uint8_t* dev, uint32_t keys_base, uint32_t part_keys_off,
-                        const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off, size_t* desc_bytes_out = nullptr) {
+                        const std::vector<uint32_t>& hist_off, const std::vector<uint32_t>& fac_out_off, size_t* desc_bytes_out = nullptr, uint32_t stat_off = 0) {
     size_t off = align_up(sizeof(QHeader), 16);
     QHeader h{};
     auto section = [&](size_t bytes) {
@@ -148,6 +170,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.doc_lo = idx.doc_lo;
     h.doc_hi = idx.doc_hi;
     h.part_keys_off = part_keys_off;
+    h.stat_off = stat_off;
     h.blob_bytes = uint32_t(off);
     if (!dst) return off;
 
@@ -237,7 +260,15 @@ void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStr
             }
             VQ_HIP(hipMemsetAsync(d_counts.p, 0, probes.size() * 4, st));
             VQ_HIP(hipMemcpyAsync(d_probes.p, probes.data(), probes.size() * sizeof(DictProbe), hipMemcpyHostToDevice, st));
-            launch_dict_scan(st, d_probes.as<DictProbe>(), uint32_t(probes.size()), max_terms);
+            {
+                uint64_t dict_bytes = 0;  // every probe reads its dictionary once: offsets + code points (16 B per padded term)
+                for (size_t i = c0; i < c1; ++i) {
+                    const Dictionary& d = idx.dict.at(todo[active[i]]->path);
+                    dict_bytes += d.d_off.bytes + d.d_low.bytes;
+                }
+                LaunchTimer timer(idx.profile.enabled, ws, st, K_DICT_SCAN, dict_bytes, dict_bytes, c1 - c0);
+                launch_dict_scan(st, d_probes.as<DictProbe>(), uint32_t(probes.size()), max_terms);
+            }
             VQ_HIP(hipGetLastError());
             std::vector<uint32_t> counts(probes.size());
             VQ_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
@@ -290,7 +321,7 @@ struct UnionTaskH {
     float max_value = std::numeric_limits<float>::infinity();
 };
 
-void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals, DevBuf& maxes, DevBuf& meta, hipStream_t st) {
+void run_union_level(bool timed, Workspace& ws, std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals, DevBuf& maxes, DevBuf& meta, hipStream_t st) {
     if (tasks.empty()) return;
     std::vector<UList> ulists;
     std::vector<UTask> utasks;
@@ -323,7 +354,11 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
     VQ_HIP(hipMemcpyAsync(m + o_lists, ulists.data(), ulists.size() * sizeof(UList), hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(m + o_tasks, utasks.data(), utasks.size() * sizeof(UTask), hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(m + o_st, span_task.data(), n_spans * 4, hipMemcpyHostToDevice, st));
+    uint64_t in_bytes = 0;
+    for (auto& u : ulists) in_bytes += uint64_t(u.len) * ((u.flags & 1u) ? 8u : 6u);
+    uint64_t out_bytes = 0;
     auto launch = [&](bool write) {
+        LaunchTimer timer(timed, ws, st, write ? K_UNION_WRITE : K_UNION_COUNT, in_bytes + (write ? out_bytes : 0), in_bytes + (write ? out_bytes : 0), tasks.size());
         launch_union(st, write, uint32_t(n_spans), reinterpret_cast<const UList*>(m + o_lists), reinterpret_cast<const UTask*>(m + o_tasks),
                      reinterpret_cast<const uint32_t*>(m + o_st), reinterpret_cast<uint32_t*>(m + o_cnt), reinterpret_cast<const uint64_t*>(m + o_off),
                      docs.as<uint32_t>(), vals.as<float>(), maxes.as<uint32_t>());
@@ -346,6 +381,7 @@ void run_union_level(std::vector<UnionTaskH>& tasks, DevBuf& docs, DevBuf& vals,
         tasks[t].len = uint32_t(len);
         cursor += (len + 8 + 3) / 4 * 4;  // 8 sentinel entries behind every list, starts stay 16-byte aligned
     }
+    out_bytes = cursor * 8;
     docs.ensure(cursor * 4 + 64);
     vals.ensure(cursor * 4 + 64);
     maxes.ensure(tasks.size() * 4 + 64);
@@ -398,8 +434,11 @@ void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const Un
         uint8_t* m = ws.d_union_meta.as<uint8_t>();
         VQ_HIP(hipMemcpyAsync(m, ulists.data(), ulists.size() * sizeof(UList), hipMemcpyHostToDevice, st));
         VQ_HIP(hipMemcpyAsync(m + o_tasks, tasks.data(), tasks.size() * sizeof(RangeTask), hipMemcpyHostToDevice, st));
-        launch_range_hits(st, uint32_t(tasks.size()), reinterpret_cast<const UList*>(m), reinterpret_cast<const RangeTask*>(m + o_tasks),
-                          reinterpret_cast<unsigned long long*>(m + o_cnt));
+        {
+            LaunchTimer timer(idx.profile.enabled, ws, st, K_RANGE_HITS, 0, 0, tasks.size());
+            launch_range_hits(st, uint32_t(tasks.size()), reinterpret_cast<const UList*>(m), reinterpret_cast<const RangeTask*>(m + o_tasks),
+                              reinterpret_cast<unsigned long long*>(m + o_cnt));
+        }
         VQ_HIP(hipGetLastError());
         VQ_HIP(hipMemcpyAsync(counts.data(), m + o_cnt, tasks.size() * 8, hipMemcpyDeviceToHost, st));
         VQ_HIP(hipStreamSynchronize(st));
@@ -444,7 +483,7 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
             l2.push_back(std::move(top));
         }
     }
-    run_union_level(l1, ws.d_union_docs[0], ws.d_union_vals[0], ws.d_union_max, ws.d_union_meta, st);
+    run_union_level(idx.profile.enabled, ws, l1, ws.d_union_docs[0], ws.d_union_vals[0], ws.d_union_max, ws.d_union_meta, st);
     for (auto& t : l1) {
         const uint32_t* d = ws.d_union_docs[0].as<uint32_t>() + t.out_off;
         const float* v = ws.d_union_vals[0].as<float>() + t.out_off;
@@ -464,7 +503,7 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
         }
     }
     if (!l2.empty()) {
-        run_union_level(l2, ws.d_union_docs[1], ws.d_union_vals[1], ws.d_union_max, ws.d_union_meta, st);  // (level 1 has synchronised)
+        run_union_level(idx.profile.enabled, ws, l2, ws.d_union_docs[1], ws.d_union_vals[1], ws.d_union_max, ws.d_union_meta, st);  // (level 1 has synchronised)
         for (auto& t : l2) {
             t.job->max_value = t.max_value;
             t.job->d_docs = ws.d_union_docs[1].as<uint32_t>() + t.out_off;
@@ -513,9 +552,14 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
     std::memcpy(host.data() + o_span, span_base.data(), (n + 1) * 4);
     std::memcpy(host.data() + o_qmap, qmap.data(), n * 4);
     VQ_HIP(hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, st));
-    launch_tile_scan(st, span_base[n], lds_bytes, dev, reinterpret_cast<const uint32_t*>(dev + o_off), reinterpret_cast<const uint32_t*>(dev + o_span),
-                     reinterpret_cast<const uint32_t*>(dev + o_qmap), uint32_t(n), stack_depth, cand_cap, uint32_t(desc_cap), nullptr,
-                     reinterpret_cast<unsigned long long*>(dev + o_cnt), nullptr, false, list_table);
+    {
+        uint64_t id_bytes = 0;  // presence only: the doc ids of every list
+        for (size_t i = 0; i < n; ++i) id_bytes += 4ull * cqs[i]->total_len;
+        LaunchTimer timer(idx.profile.enabled, ws, st, K_COUNT_PREPASS, id_bytes, id_bytes, n);
+        launch_tile_scan(st, span_base[n], lds_bytes, dev, reinterpret_cast<const uint32_t*>(dev + o_off), reinterpret_cast<const uint32_t*>(dev + o_span),
+                         reinterpret_cast<const uint32_t*>(dev + o_qmap), uint32_t(n), stack_depth, cand_cap, uint32_t(desc_cap), nullptr,
+                         reinterpret_cast<unsigned long long*>(dev + o_cnt), nullptr, false, list_table);
+    }
     VQ_HIP(hipGetLastError());
     std::vector<uint64_t> cnt(counts_off[n]);
     VQ_HIP(hipMemcpyAsync(cnt.data(), dev + o_cnt, cnt.size() * 8, hipMemcpyDeviceToHost, st));
@@ -546,6 +590,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipSetDevice(idx.device));
     Workspace& ws = *pb->ws;
     hipStream_t st = idx.stream;
+    ws.timed.clear();
+    ws.ev_used = 0;
+    pb->profiled = idx.profile.enabled;
 
     // ---- dictionary scans (fuzzy / prefix leaves) of the whole batch, then compile
     FuzzyTable fuzzy;
@@ -674,7 +721,6 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     std::vector<std::vector<uint32_t>> hist_offs, fac_out_offs;
     std::vector<FacetJob> jobs;
     uint32_t fac_out_total = 0;
-    uint64_t algo_bytes = 0;
     {   // a small batch (one query = the latency case) would leave most of the chip idle with spans sized for streaming efficiency:
         // split its queries further until the launch holds about one wave per SIMD of every CU
         static const uint64_t target1 = [] {
@@ -718,7 +764,6 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         max_lists = std::max<uint32_t>(max_lists, uint32_t(cq.lists.size()));
         max_ww = std::max(max_ww, cq.tile_words);
         stack_depth = std::max(stack_depth, cq.stack_depth);
-        algo_bytes += cq.algorithmic_bytes;
     }
     if (total_span_keys > 0xFFFFFFFFull || total_hist > 0xFFFFFFFFull || total_spans > 0x7FFFFFFFull)
         throw VelociError(ERR_UNSUPPORTED, "batch too large for 32-bit workspace offsets: split the batch");
@@ -733,8 +778,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     lay.total_keys = total_keys;
     lay.total_hist = total_hist;
     lay.off_hits = 0;
-    lay.off_keys = align_up(size_t(nq) * 8, 16);
-    lay.off_hist = lay.off_keys + align_up(size_t(total_keys) * 8, 16);
+    lay.off_stats = align_up(size_t(nq) * 8, 16);
+    lay.off_keys = lay.off_stats + align_up(size_t(nq) * 8, 16);
+    lay.off_hist = align_up(lay.off_keys + size_t(total_keys) * 8, 256);  // == bytes of the all-gathered part
     lay.bytes = align_up(lay.off_hist + size_t(total_hist) * 4, 256);
 
     // ---- upload area: [blobs][blob_off][span_base][facet jobs]
@@ -765,6 +811,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, n_rich = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0, spans_rich = 0;
     uint32_t scatter_rich = 0;
     uint32_t n_leaf = 0, spans_leaf = 0;
+    uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
     {
         size_t off = 0;
         uint32_t* hbo = reinterpret_cast<uint32_t*>(hup + up_blob_off);
@@ -773,7 +820,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             CompiledQuery& cq = pb->queries[i];
             if (cq.status != 0) continue;
             hbo[qi] = uint32_t(off);
-            off += pack_blob(cq, idx, hup + off, dup + off, keys_base[qi], part_keys_off[qi], hist_offs[qi], fac_out_offs[qi]);
+            off += pack_blob(cq, idx, hup + off, dup + off, keys_base[qi], part_keys_off[qi], hist_offs[qi], fac_out_offs[qi], nullptr,
+                             pb->profiled ? uint32_t((lay.off_stats - lay.off_hits) / 8 + qi) : 0u);  // 0: the kernels count nothing
             ++qi;
         }
         hbo[nq] = uint32_t(off);
@@ -802,35 +850,46 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             static const bool union_or = std::getenv("VQ_UNION_OR") != nullptr;
             const bool rich = (cq.simple_flags >> 18) & 1u;
             const bool dense = !rich && union_enabled && cq.simple_flags && (cq.simple_n == 1 || (union_or && cq.ops.back().kind == OP_OR));
+            int kclass;
             if ((cq.simple_flags >> 19) & 1u) {
+                kclass = K_SCAN_LEAF_F32;
                 sf[n_leaf] = accf;
                 mf[n_leaf++] = qi;
                 accf += cq.n_spans;
             } else if (rich) {
+                kclass = K_SCAN_RICH;
                 scatter_rich = std::max<uint32_t>(scatter_rich, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)) + cq.simple2.n_side);
                 sr[n_rich] = accr;
                 mr[n_rich++] = qi;
                 accr += cq.n_spans;
             } else if (dense) {
+                kclass = K_SCAN_UNION;
                 union_has_or = union_has_or || cq.simple_n > 1;
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
             } else if (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND) {
+                kclass = K_SCAN_AND;
                 scatter_wide = std::max<uint32_t>(scatter_wide, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)));
                 sw[n_wide] = accw;
                 mw[n_wide++] = qi;
                 accw += cq.n_spans;
             } else if (cq.simple_flags) {
+                kclass = K_SCAN_SIMPLE;
                 scatter_simple = std::max<uint32_t>(scatter_simple, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)));
                 ss[n_simple] = accs;
                 ms[n_simple++] = qi;
                 accs += cq.n_spans;
             } else {
+                kclass = K_TILE_SCAN;
                 sg[n_generic] = accg;
                 mg[n_generic++] = qi;
                 accg += cq.n_spans;
             }
+            pb->qclass.push_back(uint8_t(kclass));
+            cls_layout[kclass] += cq.layout_bytes;
+            cls_algo[kclass] += cq.algorithmic_bytes;
+            cls_q[kclass] += 1;
             ++qi;
         }
         sg[n_generic] = accg;
@@ -883,41 +942,47 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         if (pb->queries[i].status == 0 && !pb->queries[i].simple_flags)
             lds_bytes = std::max(lds_bytes, tile_scan_lds_bytes(uint32_t(pb->queries[i].lists.size()) + pb->queries[i].n_temps, uint32_t(pb->queries[i].lists.size()), pb->queries[i].tile_words, stack_depth, cand_cap, desc_cap, tile_queue && !pb->queries[i].simple_n, list_table));
     if (lds_bytes > 160 * 1024) throw VelociError(ERR_UNSUPPORTED, "LDS tile larger than 160 KiB");
-    pb->profiled = idx.profile.enabled;
-    if (pb->profiled) VQ_HIP(hipEventRecord(ws.ev0, st));
-    launch_scan_leaf_f32(st, spans_leaf, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_f), reinterpret_cast<const uint32_t*>(dup + up_qmap_f),
-                         n_leaf, cand_cap, ws.d_span_keys.as<unsigned long long>(), reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits),
-                         reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
-    VQ_HIP(hipGetLastError());
-    launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_r),
-                       reinterpret_cast<const uint32_t*>(dup + up_qmap_r), n_rich, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
-    VQ_HIP(hipGetLastError());
-    launch_scan_simple(st, false, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_w),
-                       reinterpret_cast<const uint32_t*>(dup + up_qmap_w), n_wide, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
-    VQ_HIP(hipGetLastError());
-    // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy)
-    launch_scan_simple(st, false, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_s),
-                       reinterpret_cast<const uint32_t*>(dup + up_qmap_s), n_simple, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist));
-    VQ_HIP(hipGetLastError());
-    launch_scan_union(st, union_has_or, spans_dense, pb->d_blobs, pb->d_blob_off, reinterpret_cast<const uint32_t*>(dup + up_span_d),
-                      reinterpret_cast<const uint32_t*>(dup + up_qmap_d), n_dense, cand_cap, ws.d_span_keys.as<unsigned long long>(),
-                      reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits));
-    VQ_HIP(hipGetLastError());
-    launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, reinterpret_cast<const uint32_t*>(dup + up_qmap_g), n_generic,
-                     stack_depth, cand_cap, desc_cap, ws.d_span_keys.as<unsigned long long>(),
-                     reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits), reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist), tile_queue, list_table);
-    if (pb->profiled) {
-        VQ_HIP(hipEventRecord(ws.ev1, st));
-        std::lock_guard<std::mutex> g(idx.profile_mutex);
-        idx.profile.scan_launches += 1;
-        idx.profile.algorithmic_bytes += algo_bytes;
+    const bool prof = pb->profiled;
+    auto hits_ptr = reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_hits);
+    auto hist_ptr = reinterpret_cast<uint32_t*>(pb->d_partial + lay.off_hist);
+    auto keys_ptr = ws.d_span_keys.as<unsigned long long>();
+    auto tab = [&](size_t o) { return reinterpret_cast<const uint32_t*>(dup + o); };
+    if (spans_leaf) {
+        LaunchTimer t(prof, ws, st, K_SCAN_LEAF_F32, cls_layout[K_SCAN_LEAF_F32], cls_algo[K_SCAN_LEAF_F32], cls_q[K_SCAN_LEAF_F32]);
+        launch_scan_leaf_f32(st, spans_leaf, pb->d_blobs, pb->d_blob_off, tab(up_span_f), tab(up_qmap_f), n_leaf, cand_cap, keys_ptr, hits_ptr, hist_ptr);
     }
     VQ_HIP(hipGetLastError());
-    launch_merge_spans(st, nq, pb->d_blobs, pb->d_blob_off, ws.d_span_keys.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_keys));
+    if (spans_rich) {
+        LaunchTimer t(prof, ws, st, K_SCAN_RICH, cls_layout[K_SCAN_RICH], cls_algo[K_SCAN_RICH], cls_q[K_SCAN_RICH]);
+        launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, tab(up_span_r), tab(up_qmap_r), n_rich, cand_cap, keys_ptr, hits_ptr, hist_ptr);
+    }
+    VQ_HIP(hipGetLastError());
+    if (spans_wide) {
+        LaunchTimer t(prof, ws, st, K_SCAN_AND, cls_layout[K_SCAN_AND], cls_algo[K_SCAN_AND], cls_q[K_SCAN_AND]);
+        launch_scan_simple(st, false, scatter_wide, spans_wide, pb->d_blobs, pb->d_blob_off, tab(up_span_w), tab(up_qmap_w), n_wide, cand_cap, keys_ptr, hits_ptr, hist_ptr);
+    }
+    VQ_HIP(hipGetLastError());
+    // (16384-doc tiles pay off for ORs too once LDS no longer bounds the occupancy)
+    if (spans_simple) {
+        LaunchTimer t(prof, ws, st, K_SCAN_SIMPLE, cls_layout[K_SCAN_SIMPLE], cls_algo[K_SCAN_SIMPLE], cls_q[K_SCAN_SIMPLE]);
+        launch_scan_simple(st, false, scatter_simple, spans_simple, pb->d_blobs, pb->d_blob_off, tab(up_span_s), tab(up_qmap_s), n_simple, cand_cap, keys_ptr, hits_ptr, hist_ptr);
+    }
+    VQ_HIP(hipGetLastError());
+    if (spans_dense) {
+        LaunchTimer t(prof, ws, st, K_SCAN_UNION, cls_layout[K_SCAN_UNION], cls_algo[K_SCAN_UNION], cls_q[K_SCAN_UNION]);
+        launch_scan_union(st, union_has_or, spans_dense, pb->d_blobs, pb->d_blob_off, tab(up_span_d), tab(up_qmap_d), n_dense, cand_cap, keys_ptr, hits_ptr);
+    }
+    VQ_HIP(hipGetLastError());
+    if (spans_generic) {
+        LaunchTimer t(prof, ws, st, K_TILE_SCAN, cls_layout[K_TILE_SCAN], cls_algo[K_TILE_SCAN], cls_q[K_TILE_SCAN]);
+        launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, tab(up_qmap_g), n_generic, stack_depth, cand_cap, desc_cap, keys_ptr,
+                         hits_ptr, hist_ptr, tile_queue, list_table);
+    }
+    VQ_HIP(hipGetLastError());
+    {
+        LaunchTimer t(prof, ws, st, K_MERGE_SPANS, total_span_keys * 8 + total_keys * 8, total_span_keys * 8 + total_keys * 8, nq);
+        launch_merge_spans(st, nq, pb->d_blobs, pb->d_blob_off, keys_ptr, reinterpret_cast<unsigned long long*>(pb->d_partial + lay.off_keys));
+    }
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
     if (timing_enabled())
@@ -1015,26 +1080,44 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         ws.h_down.ensure(down_bytes);
         if (st != idx.stream) VQ_HIP(hipStreamWaitEvent(st, ws.ev_done, 0));
         uint8_t* dd = ws.d_down.as<uint8_t>();
-        launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, lay, reinterpret_cast<uint32_t*>(dd + o_ids),
-                        reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
+        const bool prof = pb.profiled;
+        {
+            LaunchTimer t(prof, ws, st, K_FINALIZE, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, nq);
+            launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, lay, reinterpret_cast<uint32_t*>(dd + o_ids),
+                            reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
+        }
         VQ_HIP(hipGetLastError());
         if (J) {
-            const uint32_t* hist;
-            if (num_shards > 1) {
-                ws.d_hist_sum.ensure(size_t(lay.total_hist) * 4 + 16);
-                launch_hist_reduce(st, gathered, num_shards, lay, ws.d_hist_sum.as<uint32_t>());
-                hist = ws.d_hist_sum.as<uint32_t>();
-            } else hist = reinterpret_cast<const uint32_t*>(gathered + lay.off_hist);
+            // the batch's own histogram area: the caller of the sharded path has summed it over the shards in place (all-reduce)
+            const uint32_t* hist = reinterpret_cast<const uint32_t*>(pb.d_partial + lay.off_hist);
+            LaunchTimer t(prof, ws, st, K_FACET_SELECT, lay.total_hist * 4, lay.total_hist * 4, J);
             launch_facet_select(st, uint32_t(J), pb.d_facet_jobs, hist, reinterpret_cast<uint32_t*>(dd + o_fv), reinterpret_cast<uint32_t*>(dd + o_fc),
                                 reinterpret_cast<uint32_t*>(dd + o_fn));
             VQ_HIP(hipGetLastError());
         }
         VQ_HIP(hipMemcpyAsync(ws.h_down.p, dd, down_bytes, hipMemcpyDeviceToHost, st));
+        std::vector<uint64_t> gathered_bytes;
+        if (prof) {  // bytes the scans read through per-hit gathers (counted by the kernels), per query
+            gathered_bytes.resize(nq);
+            VQ_HIP(hipMemcpyAsync(gathered_bytes.data(), pb.d_partial + lay.off_stats, size_t(nq) * 8, hipMemcpyDeviceToHost, st));
+        }
         VQ_HIP(hipStreamSynchronize(st));
-        if (pb.profiled) {
-            float ms = 0.f;
+        if (prof) {
             std::lock_guard<std::mutex> g(idx.profile_mutex);
-            if (hipEventElapsedTime(&ms, ws.ev0, ws.ev1) == hipSuccess) idx.profile.scan_ms += ms;
+            Profile& P = idx.profile;
+            P.batches += 1;
+            for (const TimedLaunch& t : ws.timed) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ws.ev_pool[t.ev_begin], ws.ev_pool[t.ev_end]) != hipSuccess) continue;
+                KernelProfile& k = P.k[t.kernel];
+                k.ms += ms;
+                k.launches += 1;
+                k.layout_bytes += t.layout_bytes;
+                k.algorithmic_bytes += t.algorithmic_bytes;
+                k.queries += t.queries;
+            }
+            for (uint32_t q = 0; q < nq && q < pb.qclass.size(); ++q) P.k[pb.qclass[q]].layout_bytes += gathered_bytes[q];
+            ws.timed.clear();
         }
     }
     const uint64_t ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - pb.t0).count());

@@ -46,8 +46,8 @@ void DevBuf::upload(const void* src, size_t n, hipStream_t st) {
 
 Index::~Index() {
     for (auto& w : ws) {
-        if (w.ev0) (void)hipEventDestroy(w.ev0);
-        if (w.ev1) (void)hipEventDestroy(w.ev1);
+        for (auto e : w.ev_pool)
+            if (e) (void)hipEventDestroy(e);
         if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -120,8 +120,6 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     idx->stream = idx->own_stream;
     idx->fin_stream = idx->own_fin_stream;
     for (auto& w : idx->ws) {
-        VQ_HIP(hipEventCreate(&w.ev0));
-        VQ_HIP(hipEventCreate(&w.ev1));
         VQ_HIP(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
     }
     const uint32_t lo = b.doc_lo, hi = b.doc_hi;

@@ -13,7 +13,6 @@
 //   k_merge_spans  per query: merge the span-local top-k lists into the shard partial
 //   k_finalize     per query: merge the partials of all shards (after the RCCL all-gather) into the
 //                  final ranked hits; sum hit counts
-//   k_hist_reduce  sum facet histograms of all shards
 //   k_facet_select per (query, facet): top-`top` histogram entries (count desc, value id asc)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -307,6 +306,7 @@ struct ScoreCtx {
     uint32_t* hist;
     const VQ_CONST DOp* kops;      // the same ops / lists in the query blob in HBM, for wave-uniform (scalar) reads
     const VQ_CONST DList* klists;
+    uint32_t* gb;                  // this lane's count of bytes read by per-hit gathers (profiling: QHeader::stat_off)
 };
 
 __device__ __forceinline__ float pick4(float v0, float v1, float v2, float v3, uint32_t k) { return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3; }
@@ -333,6 +333,7 @@ __device__ __forceinline__ float tree_score_simple(const ScoreCtx& c, uint32_t w
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if ((presm >> k) & 1u) raw[k] = as_global(c.lists[li[k]].scores)[idx[k]];
+    *c.gb += 2u * (uint32_t)__popc(presm);
     float val[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
@@ -396,6 +397,7 @@ __device__ float tree_score_generic(const ScoreCtx& c, const HitT& hit) {
                         const uint16_t* sp16 = c.klists[li].scores;
                         if (lflags & LIST_F32) v = as_global(reinterpret_cast<const float*>(sp16))[idx];
                         else v = posting_value(c.klists[li].term_score, as_global(sp16)[idx]);
+                        *c.gb += (lflags & LIST_F32) ? 4u : 2u;
                     }
                     if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
                     present = true;
@@ -407,6 +409,7 @@ __device__ float tree_score_generic(const ScoreCtx& c, const HitT& hit) {
                 const uint32_t li = op.list_begin();
                 if (hit.present(li)) {
                     const float v = as_global(reinterpret_cast<const float*>(c.klists[li].scores))[hit.index(li)];
+                    *c.gb += 4u;
                     c.fstack[top * kBlock] = apply_boost_value(c.fstack[top * kBlock], c.cols[op.child_slot(0)], v);
                 }
             }
@@ -449,6 +452,7 @@ __device__ float tree_score_generic(const ScoreCtx& c, const HitT& hit) {
 template <class HitT>
 __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const HitT& hit) {
     for (uint32_t k = 0; k < c.n_col; ++k) score = apply_col_boost(score, c.cols[k], doc);
+    *c.gb += 4u * c.n_col;
     for (uint32_t g = 0; g < c.n_groups; ++g) {
         bool in = false;
         for (uint32_t j = 0; j < c.groups[g].list_count; ++j) in = in || hit.present(c.groups[g].list_begin + j);
@@ -464,6 +468,7 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const
                 const uint32_t li = c.locf[f].list_begin;
                 if (hit.present(li)) {
                     const float bv = as_global(reinterpret_cast<const float*>(c.lists[li].scores))[hit.index(li)];
+                    *c.gb += 4u;
                     if (!have || bv < best) best = bv;
                     have = true;
                 }
@@ -485,10 +490,12 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const
             const uint32_t row = doc - fa.key_base;
             if (fa.direct) {  // uniform: a scalar field
                 const uint32_t v = as_global(fa.direct)[row];
+                *c.gb += 4u;
                 if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
                 continue;
             }
             const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+            *c.gb += 16u + 4u * (uint32_t)(e1 - e0);
             for (unsigned long long e = e0; e < e1; ++e) {
                 const uint32_t v = as_global(fa.values)[e];
                 if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
@@ -690,6 +697,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const uint32_t n_counts = H->n_counts;
     for (uint32_t c = tid; c < n_counts; c += kBlock) reinterpret_cast<uint32_t*>(cand)[c] = 0u;  // the candidate area holds the counters
     uint32_t my_hits = 0;
+    uint32_t my_gb = 0;  // bytes this lane read by per-hit gathers
     uint32_t par = 0;  // parity of the cursor buffers
     const bool seq_tiles = H->seq_tiles != 0u;
     uint32_t seq_pos = span_lo;
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             VQ_STAMP_AT(4)
 
             ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
-                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists};
+                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb};
             if (compact && use_queue) {
                 for (uint32_t base = 0; base < S; base += 32u) {  // uniform
                     const uint32_t nb = S - base < 32u ? S - base : 32u;
@@ -1119,7 +1127,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     if (qlen) {  // uniform
         __syncthreads();
         ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
-                    bm, pre, cur2, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists};
+                    bm, pre, cur2, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb};
         tile_queue_flush(qlen, sc, qdoc, qmask, qidx, cs, top_k);
     }
     cand_prune(cs, top_k);
@@ -1131,6 +1139,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     if (my_hits) atomicAdd(hits_acc, my_hits);
     __syncthreads();
     if (tid == 0 && *hits_acc) atomicAdd(&num_hits[q], (unsigned long long)*hits_acc);
+    {
+        uint32_t gb_total;
+        (void)wave_excl_scan_u32(my_gb, &gb_total);
+        if (tid == 0 && gb_total && H->stat_off) atomicAdd(&num_hits[H->stat_off], (unsigned long long)gb_total);
+    }
     VQ_STAMP_AT(6)
     VQ_STAMP_FLUSH
 }
@@ -1227,7 +1240,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_spans(const uint8_t* __
     for (uint32_t i = tid; i < top_k; i += kBlock) out[i] = i < n ? cand[i] : 0ull;
 }
 
-// gathered: num_shards packed partial buffers, shard-major, each `part_bytes` long.
+// gathered: the all-gathered parts (hit counts, counters, keys: PartialLayout::off_hist bytes each) of num_shards packed partial buffers, shard-major.
 __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                      const uint8_t* __restrict__ gathered, uint32_t num_shards, PartialLayout lay,
                                                      uint32_t* __restrict__ res_ids, float* __restrict__ res_scores, uint32_t* __restrict__ res_n,
@@ -1245,7 +1258,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     __syncthreads();
     unsigned long long hits = 0;
     for (uint32_t s = 0; s < num_shards; ++s) {
-        const uint8_t* pb = gathered + (size_t)s * lay.bytes;
+        const uint8_t* pb = gathered + (size_t)s * lay.off_hist;
         const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(pb + lay.off_keys) + H->part_keys_off;
         hits += reinterpret_cast<const unsigned long long*>(pb + lay.off_hits)[q];
         if (*cs.n + top_k > (uint32_t)kCandCap) cand_prune(cs, top_k);  // uniform: *cs.n is stable here
@@ -1272,15 +1285,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     if (threadIdx.x == 0) {
         res_hits[q] = hits;
         res_n[q] = ranked;
-    }
-}
-
-__global__ void k_hist_reduce(const uint8_t* __restrict__ gathered, uint32_t num_shards, PartialLayout lay, uint32_t* __restrict__ out) {
-    const size_t n = lay.total_hist;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t s = 0;
-        for (uint32_t p = 0; p < num_shards; ++p) s += reinterpret_cast<const uint32_t*>(gathered + (size_t)p * lay.bytes + lay.off_hist)[i];
-        out[i] = s;
     }
 }
 
@@ -1352,12 +1356,6 @@ void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const ui
     if (!nq) return;
     hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(kBlock), 0, st, blobs, blob_off, gathered, num_shards, lay, res_ids, res_scores, res_n, res_hits);
 }
-void launch_hist_reduce(hipStream_t st, const uint8_t* gathered, uint32_t num_shards, const PartialLayout& lay, uint32_t* out) {
-    if (!lay.total_hist) return;
-    uint32_t blocks = (uint32_t)((lay.total_hist + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_hist_reduce, dim3(blocks), dim3(256), 0, st, gathered, num_shards, lay, out);
-}
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n) {
     if (!n_jobs) return;
@@ -1405,8 +1403,9 @@ __device__ __forceinline__ uint32_t popc4(const u32x4& v) { return (uint32_t)(__
 __device__ __forceinline__ uint32_t comp4(const u32x4& v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 // Score queue entries [0, count) (count <= 64), push the keys into the candidate buffer.
+// `stat` != null: the flush's gathered bytes are added there (profiling, QHeader::stat_off)
 __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const SimpleLeaf (&lf)[4], const uint8_t (&order)[4], const uint8_t (&slot)[4],
-                             uint32_t nslots, const uint32_t* qdoc, const uint32_t* qidx, const CandState& cs, uint32_t top_k) {
+                             uint32_t nslots, const uint32_t* qdoc, const uint32_t* qidx, const CandState& cs, uint32_t top_k, unsigned long long* stat) {
     const uint32_t lane = threadIdx.x;
     const bool have = lane < count;
     uint32_t doc = 0;
@@ -1421,6 +1420,13 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (k < n && idx[k] != 0xFFFFFFFFu) raw[k] = as_global(lf[k].scores)[idx[k]];
+    if (stat) {  // uniform
+        uint32_t g = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < n) g += 2u * (uint32_t)__popcll(__ballot(idx[k] != 0xFFFFFFFFu));
+        if (lane == 0 && g) atomicAdd(stat, (unsigned long long)g);
+    }
     float val[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
@@ -1506,7 +1512,7 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
 // Score queue entries [0, count) of a rich simple query: leaves -> groups -> root (same arithmetic and order as tree_score_generic),
 // then the sink stages in the reference's order (column boosts, phrase groups, term boosts, text locality).
 __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4], const RichShape& R, const uint32_t* qdoc, const uint32_t* qidx,
-                           const uint32_t* qmask, const CandState& cs, uint32_t top_k) {
+                           const uint32_t* qmask, const CandState& cs, uint32_t top_k, unsigned long long* stat) {
     const uint32_t lane = threadIdx.x;
     const bool have = lane < count;
     uint32_t doc = 0, qm = 0, pm = 0;
@@ -1519,11 +1525,13 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
             if (k < n) idx[k] = qidx[k * kQCap + lane];
     }
     uint32_t raw[4] = {0, 0, 0, 0};
+    uint32_t gb = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (k < n && idx[k] != 0xFFFFFFFFu) {
             if ((R.f32_mask >> k) & 1u) raw[k] = as_global(reinterpret_cast<const uint32_t*>(lf[k].scores))[idx[k]];  // uniform: materialised leaf
             else raw[k] = as_global(lf[k].scores)[idx[k]];
+            gb += ((R.f32_mask >> k) & 1u) ? 4u : 2u;
             pm |= 1u << k;
         }
     float val[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1586,6 +1594,7 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
     } else score = gv[0];
     // sink stages
     for (uint32_t k = 0; k < R.n_col; ++k) score = apply_col_boost(score, R.cols[k], doc);
+    if (have) gb += 4u * R.n_col;
 #pragma unroll
     for (uint32_t g = 0; g < 4; ++g)
         if (g < R.n_grp && (qm & b8(R.grp_mask4, g))) score *= R.grp_mult[g];
@@ -1614,10 +1623,12 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
                 const uint32_t row = doc - fa.key_base;
                 if (fa.direct) {  // uniform: a scalar field
                     const uint32_t v = as_global(fa.direct)[row];
+                    gb += 4u;
                     if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
                     continue;
                 }
                 const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+                gb += 16u + 4u * (uint32_t)(e1 - e0);
                 for (unsigned long long e = e0; e < e1; ++e) {
                     const uint32_t v = as_global(fa.values)[e];
                     if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
@@ -1640,6 +1651,11 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
         const int need = __syncthreads_or(pending ? 1 : 0);
         if (!need) break;
         cand_prune(cs, top_k);
+    }
+    if (stat) {  // uniform
+        uint32_t g;
+        (void)wave_excl_scan_u32(gb, &g);
+        if (lane == 0 && g) atomicAdd(stat, (unsigned long long)g);
     }
 }
 
@@ -2057,8 +2073,9 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 qlen += (uint32_t)__popcll(mask);
                 if (qlen >= 64u) {  // uniform
                     __syncthreads();
-                    if constexpr (RICH) rich_flush(64u, n, lf, R, qdoc, qidx, qmask, cs, top_k);
-                    else simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+                    unsigned long long* const stat = H->stat_off ? num_hits + H->stat_off : nullptr;
+                    if constexpr (RICH) rich_flush(64u, n, lf, R, qdoc, qidx, qmask, cs, top_k, stat);
+                    else simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k, stat);
                     // move the remainder to the front
                     const uint32_t rem = qlen - 64u;
                     uint32_t td = 0, tm = 0, ti[4] = {0, 0, 0, 0};
@@ -2085,8 +2102,9 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     }
     __syncthreads();
     if (qlen) {
-        if constexpr (RICH) rich_flush(qlen, n, lf, R, qdoc, qidx, qmask, cs, top_k);
-        else simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k);
+        unsigned long long* const stat = H->stat_off ? num_hits + H->stat_off : nullptr;
+        if constexpr (RICH) rich_flush(qlen, n, lf, R, qdoc, qidx, qmask, cs, top_k, stat);
+        else simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k, stat);
     }
     cand_prune(cs, top_k);
     {
@@ -2781,6 +2799,7 @@ __global__ __launch_bounds__(64) void k_scan_leaf_f32(const uint8_t* __restrict_
     // this span's slice of the list: entries [lo, hi)
     const uint32_t lo = (uint32_t)((unsigned long long)L.len * span / n_spans), hi = (uint32_t)((unsigned long long)L.len * (span + 1) / n_spans);
     uint32_t round = 0;
+    uint32_t my_gb = 0;
     for (uint32_t top = hi; top > lo; top = top - lo > 64u ? top - 64u : lo) {  // uniform; descending
         const uint32_t base = top - lo > 64u ? top - 64u : lo;
         const uint32_t i = base + lane;
@@ -2800,9 +2819,11 @@ __global__ __launch_bounds__(64) void k_scan_leaf_f32(const uint8_t* __restrict_
                 const uint32_t row = doc - fa.key_base;
                 if (fa.direct) {
                     const uint32_t v = as_global(fa.direct)[row];
+                    my_gb += 4u;
                     if (v < fa.num_values) atomicAdd(&hist[fa.hist_off + v], 1u);
                 } else {
                     const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
+                    my_gb += 16u + 4u * (uint32_t)(e1 - e0);
                     for (unsigned long long e = e0; e < e1; ++e) {
                         const uint32_t v = as_global(fa.values)[e];
                         if (v < fa.num_values) atomicAdd(&hist[fa.hist_off + v], 1u);
@@ -2821,6 +2842,11 @@ __global__ __launch_bounds__(64) void k_scan_leaf_f32(const uint8_t* __restrict_
         for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
     }
     if (lane == 0 && hi > lo) atomicAdd(&num_hits[q], (unsigned long long)(hi - lo));
+    if (n_facets) {  // uniform
+        uint32_t gb_total;
+        (void)wave_excl_scan_u32(my_gb, &gb_total);
+        if (lane == 0 && gb_total && H->stat_off) atomicAdd(&num_hits[H->stat_off], (unsigned long long)gb_total);
+    }
 }
 void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
                           uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {

@@ -52,7 +52,6 @@ void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const
                         unsigned long long* part_keys);
 void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const uint8_t* gathered, uint32_t num_shards,
                      const PartialLayout& lay, uint32_t* res_ids, float* res_scores, uint32_t* res_n, unsigned long long* res_hits);
-void launch_hist_reduce(hipStream_t st, const uint8_t* gathered, uint32_t num_shards, const PartialLayout& lay, uint32_t* out);
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n);
 

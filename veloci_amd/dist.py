@@ -2,8 +2,8 @@
 shard per process, RCCL all-gather of the packed per-shard partials, merge on the device.
 
 New surface — the reference has no sharding.  The collective is the only exchange step of the path:
-per batch each rank contributes `PartialBatch.nbytes` bytes (top-(top+skip) keys, hit counts and facet
-histograms of every query), identical in size on every rank.
+per batch each rank contributes `PartialBatch.nbytes` bytes to one all-gather (top-(top+skip) keys and hit counts
+of every query, identical in size on every rank) and sums the batch's facet histograms with one all-reduce.
 """
 import numpy as np
 import torch
@@ -55,6 +55,36 @@ def gather_partials(local, group=None):
         chunks = list(out.chunk(world))
         dist.all_gather(chunks, local, group=group)
     return out
+
+
+def reduce_histograms(hist, group=None):
+    """Sum a batch's facet histograms (uint8 view of u32 counts) over the shards in place: one all-reduce instead of
+    gathering P copies (facet counts are additive).  int32 addition == u32 addition bit for bit."""
+    import torch.distributed as dist
+    if hist.numel() == 0:
+        return hist
+    t = hist.view(torch.int32)
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return hist
+
+
+def exchange_local(pbs):
+    """Rehearsal of the exchange step with every shard in ONE process (tests: several doc-range shards on one GPU): returns the
+    shard-major gathered buffer; the summed histograms end up in pbs[0]'s own histogram area, which is what its merge reads."""
+    g = torch.cat([device_view(pb.device_ptr, pb.nbytes).clone() for pb in pbs])
+    if pbs[0].hist_nbytes:
+        hs = [device_view(pb.hist_device_ptr, pb.hist_nbytes).view(torch.int32) for pb in pbs]
+        total = hs[0].clone()
+        for h in hs[1:]:
+            total += h
+        hs[0].copy_(total)
+    torch.cuda.synchronize()
+    return g
 
 
 class ShardedSearcher:
@@ -115,11 +145,20 @@ class ShardedSearcher:
                     local = device_view(pb.device_ptr, pb.nbytes)
                     ent = self._views[key] = (local, torch.empty(self.world * pb.nbytes, dtype=torch.uint8, device=local.device))
                 dist.all_gather_into_tensor(ent[1], ent[0], group=self.group)
+                hb = pb.hist_nbytes
+                if hb:  # facet histograms: summed in place, read by this rank's merge from its own partial
+                    hkey = ("h", pb.hist_device_ptr, hb)
+                    hv = self._views.get(hkey)
+                    if hv is None:
+                        hv = self._views[hkey] = device_view(pb.hist_device_ptr, hb).view(torch.int32)
+                    dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=self.group)
                 return ent[1]
         # rehearsal backends: the partial is complete (vq_search_batch_partial synchronised the index's own stream);
         # make sure the gathered copy is, too, before the merge kernels (own stream) read it
         local = device_view(pb.device_ptr, pb.nbytes)
         gathered = gather_partials(local, self.group)
+        if pb.hist_nbytes:
+            reduce_histograms(device_view(pb.hist_device_ptr, pb.hist_nbytes), self.group)
         torch.cuda.synchronize()
         return gathered
 

@@ -186,6 +186,11 @@ class Index:
     def profile_enable(self, on=True):
         _lib.check(self.L.vq_profile_enable(self.h, int(on)))
 
+    def profile_json(self, reset=True):
+        """vq_profile_json: per-kernel device time, launches, layout / algorithmic bytes since the last reset."""
+        import json
+        return json.loads(self.L.vq_profile_json(self.h, int(reset)).decode())
+
     def profile_read(self, reset=True):
         ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
         _lib.check(self.L.vq_profile_read(self.h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))

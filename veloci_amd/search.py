@@ -174,6 +174,15 @@ class PartialBatch:
     def device_ptr(self):
         return int(self.L.vq_partial_device_ptr(self.h) or 0)
 
+    @property
+    def hist_nbytes(self):
+        """Bytes of the batch's facet histograms (u32 counts): summed over the shards by an all-reduce, not gathered."""
+        return int(self.L.vq_partial_hist_bytes(self.h))
+
+    @property
+    def hist_device_ptr(self):
+        return int(self.L.vq_partial_hist_device_ptr(self.h) or 0)
+
     def merge(self, gathered_device_ptr=None, num_shards=1, raise_on_error=True):
         outs = (C.c_void_p * self.n)()
         status = (C.c_int * self.n)()
