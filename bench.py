@@ -148,8 +148,9 @@ def kernel_table(prof):
         lay, alg = k["layout_bytes"] / n, k["algorithmic_bytes"] / n
         gbps = lay / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         agbps = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        gath = k.get("gathered_bytes", 0) / n
         out[name] = {"launch_ms": round(ms, 4), "launches": k["launches"], "queries_per_launch": round(k["queries"] / n, 1), "scan": k["scan"],
-                     "layout_bytes_per_launch": int(lay), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                     "layout_bytes_per_launch": int(lay), "gathered_bytes_per_launch": int(gath), "GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
                      "algorithmic_equiv_GBps": round(agbps, 1)}
     return out
 
@@ -215,7 +216,7 @@ class Bench:
         hits = None
         for _ in range(warmup):
             hits = step()
-        index.profile_enable(True)
+        index.profile_enable(os.environ.get("VQ_NO_PROFILE") != "1")  # (VQ_NO_PROFILE=1: what the event brackets and counters cost)
         index.profile_json(reset=True)
         sync()
         t0 = time.perf_counter()
@@ -243,12 +244,20 @@ class Bench:
 
 
 def roofline_object(table, docs, triples, batch, workload, world):
+    if not table:
+        return {"bound": "hbm", "note": "profiling was switched off (VQ_NO_PROFILE=1)"}
     name = dominant({k: v for k, v in table.items() if v["scan"]} or table)
     k = table[name]
     roof = {"bound": "hbm", "kernel": name, "achieved": k["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k["frac"],
             "peak_measured_copy": HBM_COPY_GBPS, "frac_of_measured_copy": round(k["GBps"] / HBM_COPY_GBPS, 4), "traffic": None,
             "bytes_min_this_layout_per_launch": k["layout_bytes_per_launch"], "launch_ms": k["launch_ms"], "launches": k["launches"],
             "queries_per_launch": k["queries_per_launch"],
+            # memory requests, not bytes, are what this kernel runs out of (profiles/r02_fetch_size_calibration.txt: the fabric serves ~40-45 G
+            # requests/s whether a request is a full 128-B line of a stream or a lone 64-B sector holding one 2-byte score): streamed bytes / 128
+            # plus one request per gathered score (an upper bound: neighbouring survivors can share a sector)
+            "requests": {"per_launch_upper_bound": int((k["layout_bytes_per_launch"] - k["gathered_bytes_per_launch"]) / 128 + k["gathered_bytes_per_launch"] / 2),
+                         "Greq_per_s_upper_bound": round(((k["layout_bytes_per_launch"] - k["gathered_bytes_per_launch"]) / 128 + k["gathered_bytes_per_launch"] / 2) / (k["launch_ms"] * 1e-3) / 1e9, 1) if k["launch_ms"] else None,
+                         "ceiling_measured_Greq_per_s": 45.0, "ceiling_source": "tools/fetch_calib.hip: 16 B/lane stream 39.5, paired 64-B sectors 42, lone 64-B sectors 44.8 G requests/s"},
             "algorithmic_equiv": {"GBps": k["algorithmic_equiv_GBps"], "frac": round(k["algorithmic_equiv_GBps"] / HBM_PEAK_GBPS, 4),
                                   "note": "SURVEY.md 8(d) accounting: 6 B per posting of every list + 8 B per returned hit, as if postings were streamed"},
             "note": "achieved = bytes this layout must move (bitmap words of dense lists, 4 B per id of scattered lists, 6 B per streamed posting, "
@@ -275,7 +284,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=100_000_000)
-    ap.add_argument("--triples", type=int, default=32, help="distinct (a,b,c) probe triples; the query stream cycles over them (256: no query repeats inside a launch)")
+    ap.add_argument("--triples", type=int, default=256, help="distinct (a,b,c) probe triples; the query stream cycles over them (256 = one per query of a 256-query launch: no list is read twice inside a launch, so nothing is served from L2 / Infinity Cache that a stream of distinct queries would not find there)")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--probes", type=int, default=1024, help="config4: distinct fuzzy probe terms per batch")
@@ -317,12 +326,17 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    import faulthandler
+    faulthandler.enable()
     bench = Bench(args, args.workload, args.docs, args.terms, args.triples, rank, world, local_rank, dist_on)
+    if rank == 0:
+        log("index staged; running", args.steps, "steps of", args.batch, "queries")
     bench_chunks = int(os.environ["VQ_BENCH_CHUNKS"]) if os.environ.get("VQ_BENCH_CHUNKS") else None  # None: the searcher's default
     qps, ms_step, p50, table, first_hits, reqs_json = bench.run(args.workload, args.batch, args.steps, args.warmup, latency=not args.no_latency, chunks=bench_chunks)
 
     out = None
     if rank == 0:
+        log(f"timed region done: {qps:.1f} q/s, {ms_step:.3f} ms per step")
         spec = bench.spec
         out = {
             "metric": "queries/sec, 3-term AND on 100M-doc index (p50 latency and HBM fraction alongside)",
@@ -343,9 +357,9 @@ def main():
     if rank == 0 and world == 1 and not dist_on and not args.no_extra and args.workload == "and":
         extras = {}
 
-        def short(name, b, workload, steps=4, **kw):
+        def short(name, b, workload, steps=8, **kw):
             try:
-                q, ms, p, tab, fh, _ = b.run(workload, args.batch, steps, 1, **kw)
+                q, ms, p, tab, fh, _ = b.run(workload, args.batch, steps, 3, **kw)
                 extras[name] = {"value": round(q, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "p50_latency_ms_single_query": round(p, 3) if p is not None else None,
                                 "workload": f"{b.docs}-doc index, {WORKLOADS[workload]}, batches of {args.batch}", "first_hit_counts": fh,
                                 "dominant_kernel": dominant({k: v for k, v in tab.items() if v["scan"]} or tab), "kernels": tab}
@@ -386,7 +400,7 @@ def cpu_baseline(data, meta, reqs_json, args):
     t0 = time.time()
     path = "body.textindex.to_anchor_id_score"
     offsets, anchors, scores, _ = data.token_to_anchor_score[path]
-    n_tri = min(4, len(meta.triples))
+    n_tri = min(2, len(meta.triples))
     keep = set()
     for tri in meta.triples[:n_tri]:
         for t in tri:
@@ -406,10 +420,12 @@ def cpu_baseline(data, meta, reqs_json, args):
     sample.load_into(ora)
     sample_reqs = [json.dumps(r) for r in reqs_json[:n_tri]]
     try:
-        cores = len(os.sched_getaffinity(0))  # the host cores this job may use
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)
+        visible = os.cpu_count() or 1
+    # one GPU's share of the host on this pool is 16 cores (8 GPUs per node; the pool's process guard sizes worker pools to it).  More
+    # threads do not help this memory-bound path anyway: measured on the 256-thread box, 256 threads gave 15 q/s, 16 threads 56-63 q/s.
+    cores = max(1, min(visible, int(os.environ.get("VQ_CPU_THREADS", "16"))))
     # single thread: a few queries for the latency (the budget goes to the all-core throughput run)
     secs, lat, _ = ora.bench(sample_reqs, repeat=1, threads=1)
     per_q = secs / len(sample_reqs)
@@ -425,7 +441,7 @@ def cpu_baseline(data, meta, reqs_json, args):
     secsn, latn, _ = ora.bench(sample_reqs, repeat=repn, threads=cores)
     qps_n = len(sample_reqs) * repn / secsn
     log(f"cpu baseline: setup {time.time() - t0:.1f}s, 1 thread {len(sample_reqs) * rep1 / secs1:.2f} q/s, {cores} threads {qps_n:.2f} q/s over {len(sample_reqs) * repn} queries")
-    return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "cores_visible": visible, "kind": "port",
             "measured_queries": len(sample_reqs) * repn, "p50_ms_all_cores": round(float(np.median(latn)) / 1e6, 3), "p95_ms_all_cores": round(float(np.percentile(latn, 95)) / 1e6, 3),
             "single_thread_qps": round(len(sample_reqs) * rep1 / secs1, 3), "single_thread_p50_ms": round(float(np.median(lat1)) / 1e6, 3),
             "sample": f"C++ restatement of the reference algorithm (oracle/, not the Rust binary); {n_tri} of the {len(meta.triples)} probe triples, "

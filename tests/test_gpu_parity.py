@@ -738,7 +738,7 @@ def test_config4_real_shape_matches_the_oracle():
     reqs = [{"search_req": {"search": {"path": "body", "terms": [t], "levenshtein_distance": 2}}, "top": 10, "facets": [{"field": "cat"}, {"field": "tags[]"}]}
             for t in qterms]
     wants = [ora.search_json(json.dumps(r)) for r in reqs]
-    assert sum(w.num_hits > 0 for w in wants) >= 50 and max(w.num_hits for w in wants) >= 500_000  # the shape is exercised
+    assert sum(w.num_hits > 0 for w in wants) >= 50 and max(w.num_hits for w in wants) >= 200_000  # the shape is exercised
     for r, w in list(zip(reqs, wants))[:25]:
         assert_same(r, veloci_amd.search(r, idx), w)
     for r, g, w in zip(reqs, veloci_amd.search_batch(reqs, idx), wants):

@@ -478,9 +478,9 @@ const char* vq_profile_json(const vq_index* i, int reset) {
         const KernelProfile& kp = p.k[k];
         if (!kp.launches) continue;
         char buf[512];
-        std::snprintf(buf, sizeof buf, "%s\"%s\":{\"ms\":%.6f,\"launches\":%llu,\"layout_bytes\":%llu,\"algorithmic_bytes\":%llu,\"queries\":%llu,\"scan\":%s}",
+        std::snprintf(buf, sizeof buf, "%s\"%s\":{\"ms\":%.6f,\"launches\":%llu,\"layout_bytes\":%llu,\"algorithmic_bytes\":%llu,\"gathered_bytes\":%llu,\"queries\":%llu,\"scan\":%s}",
                       first ? "" : ",", kKernelNames[k], kp.ms, (unsigned long long)kp.launches, (unsigned long long)kp.layout_bytes,
-                      (unsigned long long)kp.algorithmic_bytes, (unsigned long long)kp.queries, is_scan_kernel(k) ? "true" : "false");
+                      (unsigned long long)kp.algorithmic_bytes, (unsigned long long)kp.gathered_bytes, (unsigned long long)kp.queries, is_scan_kernel(k) ? "true" : "false");
         out += buf;
         first = false;
     }

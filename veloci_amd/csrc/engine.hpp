@@ -306,6 +306,7 @@ struct KernelProfile {
     uint64_t layout_bytes = 0;       // bytes THIS layout has to move for the launches (bitmap words of dense lists, 4 B per id of scattered lists,
                                      // 6 B per streamed posting, gathered bytes counted by the kernels, 8 B per returned key): roofline numerator
     uint64_t algorithmic_bytes = 0;  // SURVEY.md 8(d) accounting (6 B per posting of every list ...): what a posting-streaming design would move
+    uint64_t gathered_bytes = 0;     // the part of layout_bytes read by per-hit gathers (2 B per f16 score, 4 B per f32 / column / facet value, ...)
     uint64_t queries = 0;
 };
 struct Profile {

@@ -1116,7 +1116,10 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
                 k.algorithmic_bytes += t.algorithmic_bytes;
                 k.queries += t.queries;
             }
-            for (uint32_t q = 0; q < nq && q < pb.qclass.size(); ++q) P.k[pb.qclass[q]].layout_bytes += gathered_bytes[q];
+            for (uint32_t q = 0; q < nq && q < pb.qclass.size(); ++q) {
+                P.k[pb.qclass[q]].layout_bytes += gathered_bytes[q];
+                P.k[pb.qclass[q]].gathered_bytes += gathered_bytes[q];
+            }
             ws.timed.clear();
         }
     }

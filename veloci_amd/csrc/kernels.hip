@@ -1403,9 +1403,9 @@ __device__ __forceinline__ uint32_t popc4(const u32x4& v) { return (uint32_t)(__
 __device__ __forceinline__ uint32_t comp4(const u32x4& v, uint32_t j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 // Score queue entries [0, count) (count <= 64), push the keys into the candidate buffer.
-// `stat` != null: the flush's gathered bytes are added there (profiling, QHeader::stat_off)
+// `stat` != null: the flush's gathered bytes are added to that LDS word (profiling, QHeader::stat_off)
 __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const SimpleLeaf (&lf)[4], const uint8_t (&order)[4], const uint8_t (&slot)[4],
-                             uint32_t nslots, const uint32_t* qdoc, const uint32_t* qidx, const CandState& cs, uint32_t top_k, unsigned long long* stat) {
+                             uint32_t nslots, const uint32_t* qdoc, const uint32_t* qidx, const CandState& cs, uint32_t top_k, uint32_t* stat) {
     const uint32_t lane = threadIdx.x;
     const bool have = lane < count;
     uint32_t doc = 0;
@@ -1425,7 +1425,7 @@ __device__ void simple_flush(uint32_t count, uint32_t n, uint32_t kind, const Si
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
             if (k < n) g += 2u * (uint32_t)__popcll(__ballot(idx[k] != 0xFFFFFFFFu));
-        if (lane == 0 && g) atomicAdd(stat, (unsigned long long)g);
+        if (lane == 0) *stat += g;
     }
     float val[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1512,7 +1512,7 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
 // Score queue entries [0, count) of a rich simple query: leaves -> groups -> root (same arithmetic and order as tree_score_generic),
 // then the sink stages in the reference's order (column boosts, phrase groups, term boosts, text locality).
 __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4], const RichShape& R, const uint32_t* qdoc, const uint32_t* qidx,
-                           const uint32_t* qmask, const CandState& cs, uint32_t top_k, unsigned long long* stat) {
+                           const uint32_t* qmask, const CandState& cs, uint32_t top_k, uint32_t* stat) {
     const uint32_t lane = threadIdx.x;
     const bool have = lane < count;
     uint32_t doc = 0, qm = 0, pm = 0;
@@ -1655,7 +1655,7 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
     if (stat) {  // uniform
         uint32_t g;
         (void)wave_excl_scan_u32(gb, &g);
-        if (lane == 0 && g) atomicAdd(stat, (unsigned long long)g);
+        if (lane == 0) *stat += g;
     }
 }
 
@@ -1817,6 +1817,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     if (lane == 0) {
         *thr = 0ull;
         *cand_n = 0;
+        lds[4] = 0u;
     }
     __syncthreads();
     uint32_t qlen = 0;
@@ -2073,7 +2074,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 qlen += (uint32_t)__popcll(mask);
                 if (qlen >= 64u) {  // uniform
                     __syncthreads();
-                    unsigned long long* const stat = H->stat_off ? num_hits + H->stat_off : nullptr;
+                    uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;  // (misc word 4: gathered bytes of the span, < 2^32)
                     if constexpr (RICH) rich_flush(64u, n, lf, R, qdoc, qidx, qmask, cs, top_k, stat);
                     else simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k, stat);
                     // move the remainder to the front
@@ -2102,7 +2103,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     }
     __syncthreads();
     if (qlen) {
-        unsigned long long* const stat = H->stat_off ? num_hits + H->stat_off : nullptr;
+        uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;
         if constexpr (RICH) rich_flush(qlen, n, lf, R, qdoc, qidx, qmask, cs, top_k, stat);
         else simple_flush(qlen, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k, stat);
     }
@@ -2113,6 +2114,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
     }
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
+    if (lane == 0 && H->stat_off && lds[4]) atomicAdd(&num_hits[H->stat_off], (unsigned long long)lds[4]);
 }
 
 // 16384-doc tiles (NV = 2) cut the per-tile instruction overhead — with LDS sized by need the kernel is VALU-issue bound, not
