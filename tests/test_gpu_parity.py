@@ -256,9 +256,11 @@ def test_generic_kernel_also_matches_for_simple_queries():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"}],
+@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
+                                 {"VQ_NO_WIDE": "1"}],
                          ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
-                              "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels"])
+                              "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
+                              "wide_queries_on_k_tile_scan"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results."""
     import os
@@ -266,7 +268,7 @@ def test_alternative_kernel_routes_match(env):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or (reference_integration and (or_connect or minimal or simple_search))"],
+                        "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or (reference_integration and (or_connect or minimal or simple_search))"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -862,6 +864,42 @@ def test_wide_nodes_up_to_16_operands(corpus):
     with pytest.raises(veloci_amd.VelociError) as e:
         veloci_amd.search({"search_req": {"or": {"queries": [leaf(t) for t in terms[:17]]}}}, idx)
     assert e.value.kind == "Unsupported"  # (declined, never truncated: the evaluation stack holds 16 operands)
+
+
+def test_query_generator_shapes_on_the_wide_kernel(corpus, big_corpus):
+    """k_scan_wide: 5-16 single-list leaves in trees of depth <= 2 — the shapes of the reference's query generator (one leaf per term and
+    field, src/query_generator.rs:175-246): flat ORs / ANDs, a root over AND / OR groups, dense (bitmap) and sparse (scattered) lists mixed,
+    leaf boosts, repeated terms sharing an OR slot, top / skip, single requests (many spans) and batches; on a 300 k- and a 4 M-doc corpus."""
+    import veloci_amd
+    from parity import assert_same
+    for data, meta, idx, ora in (corpus, big_corpus):
+        tri = [list(t) for t in meta.triples]
+        terms = [t for t3 in tri for t in t3] + list(meta.extra_probes) + list(meta.background[:10])
+        leaf = lambda t, **kw: {"search": dict({"path": "body", "terms": [t]}, **kw)}
+        OR = lambda qs: {"or": {"queries": qs}}
+        AND = lambda qs: {"and": {"queries": qs}}
+        reqs = [
+            {"search_req": OR([leaf(t) for t in terms[:8]]), "top": 10},
+            {"search_req": AND([OR([leaf(t) for t in terms[:4]]), OR([leaf(t) for t in terms[4:8]])]), "top": 10},
+            {"search_req": OR([leaf(t) for t in terms[:5]]), "top": 3, "skip": 2},
+            {"search_req": OR([AND([leaf(tri[0][0]), leaf(tri[0][1]), leaf(tri[0][2])]), AND([leaf(tri[1][0]), leaf(tri[1][1]), leaf(tri[1][2])])]), "top": 25},
+            {"search_req": AND([leaf(tri[0][0]), OR([leaf(t) for t in terms[3:7]]), OR([leaf(t) for t in terms[7:10]])]), "top": 10},
+            {"search_req": OR([leaf(t, boost=0.5 + 0.3 * i) for i, t in enumerate(terms[2:15])]), "top": 40},
+            {"search_req": OR([leaf(tri[0][0]), leaf(tri[0][0].upper()), leaf(tri[0][1]), leaf(tri[0][2]), leaf(tri[1][0]), leaf(tri[1][1])]), "top": 10},  # one term twice: a shared slot
+            {"search_req": AND([leaf(t) for t in (tri[0] + tri[1][:2])]), "top": 10},
+            {"search_req": OR([OR([leaf(tri[0][0]), leaf(tri[0][1])]), AND([leaf(tri[0][2]), leaf(tri[1][0])]), leaf(tri[1][1]), leaf(terms[-1]), leaf(terms[-2])]), "top": 12},
+            {"search_req": OR([leaf(t) for t in terms[6:6 + 16]][:16]), "top": 10},
+            {"search_req": AND([OR([leaf(t) for t in terms[:8]]), OR([leaf(t) for t in terms[8:16]])]), "top": 1000},
+        ]
+        wants = [ora.search_json(json.dumps(r)) for r in reqs]
+        for r, w in zip(reqs, wants):
+            assert_same(r, veloci_amd.search(r, idx), w)
+        for r, g, w in zip(reqs * 3, veloci_amd.search_batch(reqs * 3, idx), wants * 3):
+            assert_same(r, g, w)
+        got = _search_batch_over_shards(data, reqs, 2)
+        for r, g, w in zip(reqs, got, wants):
+            assert not isinstance(g, Exception), (str(g), json.dumps(r))
+            assert_same(r, g, w)
 
 
 def test_token_value_boost_shapes_the_term_scores():

@@ -1253,6 +1253,116 @@ struct Compiler {
         cq.simple_flags = f;
     }
 
+    // Wide queries (DWide, k_scan_wide): 5..16 single-list posting leaves in a tree of depth <= 2, nothing but the score tree — the
+    // query generator's shapes (one leaf per term and field).
+    void detect_wide() {
+        static const bool off = std::getenv("VQ_FORCE_GENERIC") != nullptr || std::getenv("VQ_NO_WIDE") != nullptr;
+        if (off || !count_reqs.empty() || cq.ops.empty() || !cq.fops.empty() || !cq.groups.empty() || !cq.tboosts.empty() || !cq.cols.empty() || !cq.locf.empty() ||
+            !cq.facets.empty() || uint64_t(idx.doc_hi) - idx.doc_lo < 65536)
+            return;
+        DWide W{};
+        struct Node {
+            bool is_leaf;
+            uint32_t leaf;
+            DOp op;
+            std::vector<uint32_t> kids;  // leaf indices of a group, in child order
+        };
+        std::vector<Node> st;
+        std::vector<uint16_t> leaves;
+        bool have_root = false;
+        std::vector<Node> root_kids;
+        DOp root_op{};
+        for (size_t o = 0; o < cq.ops.size(); ++o) {
+            const DOp& op = cq.ops[o];
+            if (op.kind == OP_LEAF) {
+                if (op.list_count != 1) return;
+                const HList& l = cq.lists[op.list_begin];
+                if (!(l.flags & LIST_HAS_SCORES) || l.inline_idx >= 0 || l.inline_val_idx >= 0) return;
+                if (leaves.size() >= size_t(kWideMax)) return;
+                for (uint16_t e : leaves)
+                    if (e == op.list_begin) return;  // one list under two leaves: the count planes would count it once
+                st.push_back(Node{true, uint32_t(leaves.size()), op, {}});
+                leaves.push_back(op.list_begin);
+            } else if (op.kind == OP_AND || op.kind == OP_OR) {
+                if (op.nchild > st.size() || op.nchild > kWideMax) return;
+                std::vector<Node> kids(st.end() - op.nchild, st.end());
+                st.resize(st.size() - op.nchild);
+                bool all_leaves = true;
+                for (auto& k : kids) all_leaves = all_leaves && k.is_leaf;
+                const bool last = o + 1 == cq.ops.size();
+                if (last && st.empty()) {
+                    root_kids = kids;
+                    root_op = op;
+                    have_root = true;
+                } else if (all_leaves) {
+                    Node g{false, 0, op, {}};
+                    for (auto& k : kids) g.kids.push_back(k.leaf);
+                    for (size_t c = 1; c < g.kids.size(); ++c)
+                        if (g.kids[c] != g.kids[c - 1] + 1) return;  // (postfix order: always consecutive)
+                    st.push_back(g);
+                } else return;  // deeper than two levels
+            } else return;  // OP_BOOST1N
+        }
+        if (!have_root || leaves.size() < 5 || root_kids.size() > size_t(kWideMax)) return;  // (<= 4 leaves: the simple kernels)
+        const uint32_t n = uint32_t(leaves.size());
+        W.n_leaves = uint8_t(n);
+        W.n_groups = uint8_t(root_kids.size());
+        W.root_kind = root_op.kind;
+        W.root_nslots = root_op.nslots;
+        for (uint32_t k = 0; k < n; ++k) W.leaf_list[k] = leaves[k];
+        for (size_t g = 0; g < root_kids.size(); ++g) {
+            const Node& kid = root_kids[g];
+            W.r_and_order[g] = root_op.and_order[g];
+            W.r_slot[g] = root_op.child_slot[g];
+            if (kid.is_leaf) {
+                W.g_kind[g] = OP_LEAF;
+                W.g_begin[g] = uint8_t(kid.leaf);
+                W.g_count[g] = 1;
+                W.leaf_and_order[kid.leaf] = uint8_t(kid.leaf);
+                W.leaf_slot_order[kid.leaf] = uint8_t(kid.leaf);
+            } else {
+                W.g_kind[g] = kid.op.kind;
+                W.g_begin[g] = uint8_t(kid.kids[0]);
+                W.g_count[g] = uint8_t(kid.kids.size());
+                std::vector<uint32_t> by_slot;
+                for (size_t c = 0; c < kid.kids.size(); ++c) {
+                    W.leaf_slot[kid.kids[c]] = kid.op.child_slot[c];
+                    W.leaf_and_order[kid.kids[0] + c] = uint8_t(kid.kids[kid.op.and_order[c]]);  // and_order holds child positions
+                    by_slot.push_back(kid.kids[c]);
+                }
+                std::stable_sort(by_slot.begin(), by_slot.end(), [&](uint32_t a, uint32_t b) { return W.leaf_slot[a] < W.leaf_slot[b]; });
+                for (size_t c = 0; c < by_slot.size(); ++c) W.leaf_slot_order[kid.kids[0] + c] = uint8_t(by_slot[c]);
+            }
+        }
+        {
+            std::vector<uint32_t> by_slot;
+            for (uint32_t g = 0; g < W.n_groups; ++g) by_slot.push_back(g);
+            std::stable_sort(by_slot.begin(), by_slot.end(), [&](uint32_t a, uint32_t b) { return W.r_slot[a] < W.r_slot[b]; });
+            for (uint32_t g = 0; g < W.n_groups; ++g) W.r_slot_order[g] = uint8_t(by_slot[g]);
+        }
+        for (uint32_t li = 0; li < cq.lists.size(); ++li)  // every list must be a leaf
+            if (std::find(leaves.begin(), leaves.end(), uint16_t(li)) == leaves.end()) return;
+        bool seq = false, any_cover = false;
+        for (uint32_t k = 0; k < n; ++k) {
+            const HList& l = cq.lists[leaves[k]];
+            if ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP)) seq = true;
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            const HList& l = cq.lists[leaves[k]];
+            const bool cover = l.flags & LIST_COVER;
+            any_cover = any_cover || cover;
+            if (cover) W.cover_mask |= uint16_t(1u << k);
+            if ((l.flags & LIST_BITMAP) && (seq || !cover)) W.bitmap_mask |= uint16_t(1u << k);
+            if (l.flags & LIST_F32) W.f32_mask |= uint16_t(1u << k);
+            if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) W.prefetch_mask |= uint16_t(1u << k);
+        }
+        if (!any_cover) return;
+        W.seq = seq ? 1 : 0;
+        cq.wide = W;
+        cq.simple_flags = 1u << 24;
+        cq.simple_n = 0;
+    }
+
     // ------------------------------------------------------------ the whole request (search.rs:143-228)
     void run() {
         if (req.has_select) unsupported("select");
@@ -1587,7 +1697,8 @@ struct Compiler {
                 cq.simple_flags = 1u << 19;
         }
         if (!cq.simple_flags) detect_rich_simple();
-        if (!cq.simple_flags) compute_prune_table();
+        if (!cq.simple_flags) detect_wide();
+        if (!cq.simple_flags || ((cq.simple_flags >> 24) & 1u)) compute_prune_table();
         if (!cq.simple_flags && count_reqs.empty()) {  // k_tile_scan: a dense cover list means every tile gets visited anyway: walk them in order
             bool dense_cover = false;                   // and read the dense lists as bitmap images instead of scattering them
             for (auto& l : cq.lists) dense_cover = dense_cover || ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP));
@@ -1669,16 +1780,19 @@ struct Compiler {
     void compute_layout_bytes(uint64_t cover_len) {
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
         const bool simple = cq.simple_flags != 0;
-        const uint64_t tile_docs = simple ? 16384 : uint64_t(cq.tile_words) << 5;
+        const bool wide = (cq.simple_flags >> 24) & 1u;
+        const uint64_t tile_docs = wide ? 8192 : simple ? 16384 : uint64_t(cq.tile_words) << 5;
         const uint64_t tiles = std::max<uint64_t>((range + tile_docs - 1) / tile_docs, 1);
-        const bool seq = simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
+        const bool seq = wide ? cq.wide.seq != 0 : simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
         const uint64_t visited = seq ? tiles : std::min<uint64_t>(std::max<uint64_t>(cover_len, 1), tiles);
         auto bitmap_cost = [&]() { return visited * (tile_docs / 8 + 4); };
         uint64_t b = 8ull * cq.top_k;
         if ((cq.simple_flags >> 19) & 1u) b += 8ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_leaf_f32
         else if (simple && !((cq.simple_flags >> 18) & 1u) && cq.simple_n == 1 && std::getenv("VQ_NO_UNION") == nullptr)
             b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
-        else if (simple) {
+        else if (wide) {
+            for (uint32_t k = 0; k < cq.wide.n_leaves; ++k) b += ((cq.wide.bitmap_mask >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[cq.wide.leaf_list[k]].len;
+        } else if (simple) {
             std::vector<bool> seen(cq.lists.size(), false);
             const bool rich = (cq.simple_flags >> 18) & 1u;
             for (uint32_t k = 0; k < cq.simple_n; ++k) {

@@ -137,6 +137,25 @@ struct DSimple2 {
     float tb_mult[4];
 };
 
+// "Wide" queries (k_scan_wide): 5..16 single-list posting leaves in a tree of depth <= 2 — the query generator's shapes, one leaf per term
+// and field (src/query_generator.rs:175-246): a flat OR / AND over the leaves, or a root over AND / OR groups of leaves.  No filter, no sink
+// stages.  Leaves of a group are consecutive; a leaf directly under the root is a group of its own (g_kind = OP_LEAF).
+constexpr int kWideMax = 16;
+struct DWide {
+    uint8_t n_leaves, n_groups, root_kind, root_nslots;
+    uint8_t seq, pad0, pad1, pad2;                               // seq: tiles are visited in order (a dense list is in the cover)
+    uint16_t bitmap_mask, cover_mask, prefetch_mask, f32_mask;   // bit k: leaf k is read as a bitmap image / is in the cover / prefetches its
+                                                                 // next id vector / is a materialised list (LIST_F32)
+    uint16_t leaf_list[kWideMax];                                // list index of leaf k
+    uint8_t leaf_slot[kWideMax];                                 // OR group: term slot of leaf k (set_op.rs:122-124)
+    uint8_t g_kind[kWideMax], g_begin[kWideMax], g_count[kWideMax];  // group g: OP_LEAF / OP_AND / OP_OR over leaves [g_begin, g_begin + g_count)
+    uint8_t leaf_and_order[kWideMax];    // AND group g: entries [g_begin, g_begin + g_count) = its leaves in summation order (set_op.rs:393,415-416)
+    uint8_t leaf_slot_order[kWideMax];   // OR group g: the same range = its leaves ordered by term slot
+    uint8_t r_and_order[kWideMax];       // root AND: groups in summation order
+    uint8_t r_slot[kWideMax];            // root OR: term slot of group g
+    uint8_t r_slot_order[kWideMax];      // root OR: groups ordered by term slot
+};
+
 struct QHeader {
     uint32_t n_lists, n_ops, n_fops, n_groups, n_tboost, n_col, n_locf, n_facets;
     uint32_t off_lists, off_ops, off_fops, off_groups, off_tboost, off_col, off_locf, off_facets;
@@ -150,7 +169,7 @@ struct QHeader {
     uint32_t desc_bytes;     // leading part of the blob that the kernel stages into LDS (everything but inline lists)
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
     uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
-    uint32_t off_simple2;    // DSimple2 (simple_flags bit 18)
+    uint32_t off_simple2;    // DSimple2 (simple_flags bit 18) or DWide (simple_flags bit 24)
     uint32_t prune_n;        // k_tile_scan top-k pruning: != 0: number of lists in prune_mask; a doc present in k of them scores at most
                              // unorder(prune_gbits[k]) (monotone in k), so docs with too few of them are counted as hits but never scored
     uint64_t prune_mask;     // the leaf lists of the score tree
@@ -168,7 +187,8 @@ struct QHeader {
     uint32_t simple_n;       // != 0: the score tree is simple_n single-list posting leaves under one AND/OR (or a single leaf)
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are
                              // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
-                             // bit 18: rich simple query (DSimple2); bits 20-23: leaf k has enough entries per tile to prefetch its next 1 KiB round
+                             // bit 18: rich simple query (DSimple2); bit 19: one materialised leaf (k_scan_leaf_f32); bits 20-23: leaf k has enough
+                             // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide)
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

@@ -437,6 +437,7 @@ struct CompiledQuery {
     std::vector<DLocField> locf;
     std::vector<uint16_t> loc_idx;
     DSimple2 simple2{};  // simple_flags bit 18
+    DWide wide{};        // simple_flags bit 24
     std::vector<DFacet> facets;
     std::vector<FacetOut> facet_out;
     uint32_t top = 10, skip = 0, top_k = 10;

@@ -146,7 +146,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres = uint32_t(section(cq.pres.size() * sizeof(DPresOp)));
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
-    h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : 0));
+    h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : (cq.simple_flags >> 24) & 1u ? sizeof(DWide) : 0));
     h.n_temps = cq.n_temps;
     h.n_counts = cq.n_counts;
     h.prune_n = cq.prune_n;
@@ -197,6 +197,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!cq.locf.empty()) std::memcpy(dst + h.off_locf, cq.locf.data(), cq.locf.size() * sizeof(DLocField));
     if (!cq.loc_idx.empty()) std::memcpy(dst + h.off_loc_idx, cq.loc_idx.data(), cq.loc_idx.size() * sizeof(uint16_t));
     if ((cq.simple_flags >> 18) & 1u) std::memcpy(dst + h.off_simple2, &cq.simple2, sizeof(DSimple2));
+    if ((cq.simple_flags >> 24) & 1u) std::memcpy(dst + h.off_simple2, &cq.wide, sizeof(DWide));
     if (!cq.pres.empty()) std::memcpy(dst + h.off_pres, cq.pres.data(), cq.pres.size() * sizeof(DPresOp));
     if (!cq.pres_in.empty()) std::memcpy(dst + h.off_pres_in, cq.pres_in.data(), cq.pres_in.size() * sizeof(uint16_t));
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);
@@ -800,7 +801,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_r = up_span_r + tbl;
     const size_t up_span_f = up_qmap_r + tbl;   // one materialised leaf: k_scan_leaf_f32
     const size_t up_qmap_f = up_span_f + tbl;
-    const size_t up_jobs = up_qmap_f + tbl;
+    const size_t up_span_x = up_qmap_f + tbl;   // wide queries (DWide): k_scan_wide
+    const size_t up_qmap_x = up_span_x + tbl;
+    const size_t up_jobs = up_qmap_x + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
@@ -811,6 +814,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, n_rich = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0, spans_rich = 0;
     uint32_t scatter_rich = 0;
     uint32_t n_leaf = 0, spans_leaf = 0;
+    uint32_t n_xwide = 0, spans_xwide = 0, leaves_xwide = 0, scatter_xwide = 0;
     uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
     {
         size_t off = 0;
@@ -837,7 +841,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t* mr = reinterpret_cast<uint32_t*>(hup + up_qmap_r);
         uint32_t* sf = reinterpret_cast<uint32_t*>(hup + up_span_f);
         uint32_t* mf = reinterpret_cast<uint32_t*>(hup + up_qmap_f);
-        uint32_t accf = 0;
+        uint32_t accf = 0, accx = 0;
+        uint32_t* sx = reinterpret_cast<uint32_t*>(hup + up_span_x);
+        uint32_t* mx = reinterpret_cast<uint32_t*>(hup + up_qmap_x);
         uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0;
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
@@ -856,6 +862,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 sf[n_leaf] = accf;
                 mf[n_leaf++] = qi;
                 accf += cq.n_spans;
+            } else if ((cq.simple_flags >> 24) & 1u) {
+                kclass = K_SCAN_WIDE;
+                leaves_xwide = std::max<uint32_t>(leaves_xwide, cq.wide.n_leaves);
+                scatter_xwide = std::max<uint32_t>(scatter_xwide, cq.wide.n_leaves - uint32_t(__builtin_popcount(cq.wide.bitmap_mask)));
+                sx[n_xwide] = accx;
+                mx[n_xwide++] = qi;
+                accx += cq.n_spans;
             } else if (rich) {
                 kclass = K_SCAN_RICH;
                 scatter_rich = std::max<uint32_t>(scatter_rich, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)) + cq.simple2.n_side);
@@ -900,6 +913,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         spans_rich = accr;
         sf[n_leaf] = accf;
         spans_leaf = accf;
+        sx[n_xwide] = accx;
+        spans_xwide = accx;
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -971,6 +986,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (spans_dense) {
         LaunchTimer t(prof, ws, st, K_SCAN_UNION, cls_layout[K_SCAN_UNION], cls_algo[K_SCAN_UNION], cls_q[K_SCAN_UNION]);
         launch_scan_union(st, union_has_or, spans_dense, pb->d_blobs, pb->d_blob_off, tab(up_span_d), tab(up_qmap_d), n_dense, cand_cap, keys_ptr, hits_ptr);
+    }
+    VQ_HIP(hipGetLastError());
+    if (spans_xwide) {
+        LaunchTimer t(prof, ws, st, K_SCAN_WIDE, cls_layout[K_SCAN_WIDE], cls_algo[K_SCAN_WIDE], cls_q[K_SCAN_WIDE]);
+        launch_scan_wide(st, leaves_xwide, scatter_xwide, spans_xwide, pb->d_blobs, pb->d_blob_off, tab(up_span_x), tab(up_qmap_x), n_xwide, cand_cap, keys_ptr, hits_ptr);
     }
     VQ_HIP(hipGetLastError());
     if (spans_generic) {

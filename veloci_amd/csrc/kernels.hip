@@ -2146,6 +2146,450 @@ void launch_scan_simple(hipStream_t st, bool rich, uint32_t n_scatter, uint32_t 
 }  // namespace vq
 
 // ====================================================================================================
+// k_scan_wide — queries of 5..16 single-list posting leaves in a tree of depth <= 2 (DWide): the shapes of the reference's query
+// generator, which ORs one leaf per term and field (src/query_generator.rs:175-246) — a flat OR over 8 leaves, an AND of two 4-leaf ORs.
+// k_tile_scan interprets such trees op by op for every scored doc; here the tree shape is decoded once per wave and the tile is processed
+// in two phases:
+//   A  stream every leaf's words of the 8192-doc tile (dense lists: one 16 B/lane load of the bitmap image, all loads of up to 8 leaves
+//      in flight together; scattered lists: the ballot-counted id scatter into LDS), fold them into the group / root presence words and
+//      into a bit-sliced per-doc count of the leaves holding the doc (4 planes), keep words and per-lane ranks in LDS for phase B
+//   B  only docs whose count class can still reach the top-k threshold (QHeader::prune_gbits: the score bound of a doc held by at most k
+//      leaves) are queued, classes in DESCENDING order — the few docs of the highest classes raise the threshold before the many docs of
+//      the low classes are looked at, so a span's first tile costs no more than any other; queued docs are scored 64 at a time, all
+//      gathers of a round in flight together, the group / root arithmetic in the reference's order (set_op.rs:169-186, 393, 415-416)
+// Every doc of the root words is a hit (counted), scored or not.  Same results as k_tile_scan bit for bit.
+// ====================================================================================================
+namespace vq {
+
+constexpr uint32_t kWQCap = 128;  // survivor queue entries
+// LDS map (u32): misc[8] | base[16] cur[16] nxt[16] gbits[16] | DWide copy [48] | per-leaf descriptors: bitmap ptr [32] rank_dir ptr [32] docs ptr [32]
+//                scores ptr [32] len [16] term_score [16] | qdoc[kWQCap] | qmask[kWQCap] | cand[2*cand_cap] | qidx[L][kWQCap] | tiles[scattered leaves][kSWW]
+// The tile's words of every leaf stay in REGISTERS from phase A to phase B (ML * 4 VGPRs: the kernel is instantiated for <= 8 and <= 16 leaves);
+// only scattered (id) lists pass through an LDS tile.
+// The tree shape and the leaves' pointers are staged once per wave: inside the tile loop nothing waits for a descriptor read from HBM
+// (sub-dword fields of a descriptor in HBM cannot be scalar loads; as vector loads each one drained the bitmap loads in flight).
+constexpr uint32_t kWLdsCur = 24, kWLdsNxt = 40, kWLdsGbits = 56, kWLdsW = 72, kWLdsBm = 120, kWLdsRk = 152, kWLdsDocs = 184, kWLdsSc = 216,
+                   kWLdsLen = 248, kWLdsTs = 264, kWLdsQDoc = 280, kWLdsQMask = kWLdsQDoc + kWQCap, kWLdsCand = kWLdsQMask + kWQCap;
+static_assert(sizeof(DWide) <= 48 * 4, "DWide copy in LDS");
+size_t scan_wide_lds_bytes(uint32_t cand_cap, uint32_t n_leaves, uint32_t n_scatter) { return (size_t)(kWLdsCand + 2 * cand_cap + n_leaves * kWQCap + n_scatter * kSWW) * 4 + 16; }
+
+// orders this wave's LDS writes / atomics before its later LDS reads (a workgroup is ONE wave: LDS executes a wave's instructions in order, so
+// no barrier and — unlike __syncthreads() — no wait for the vector-memory loads in flight)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct WideShape {  // tree shape and leaf descriptors, staged in LDS
+    const DWide* W;
+    const unsigned long long* sc_ptr;  // [L] scores pointers
+    const float* ts;                   // [L] term scores
+    uint32_t L, G, f32_mask;
+};
+
+// Score queue entries [0, count) (count <= 64): gathers -> leaf values (written over the entries' qidx slots) -> groups -> root -> keys
+__device__ void wide_flush(uint32_t count, const WideShape& S, const uint32_t* qdoc, const uint32_t* qmask, uint32_t* qidx, const CandState& cs, uint32_t top_k,
+                           uint32_t* stat) {
+    const uint32_t lane = threadIdx.x;
+    const bool have = lane < count;
+    const uint32_t doc = have ? qdoc[lane] : 0u;
+    const uint32_t pm = have ? qmask[lane] : 0u;
+    const uint32_t f32m = S.f32_mask;
+    uint32_t raw[kWideMax];
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kWideMax; ++k) {
+        raw[k] = 0u;
+        if (k < S.L && ((pm >> k) & 1u)) {  // (k < L: uniform)
+            const uint32_t idx = qidx[k * kWQCap + lane];
+            const uint16_t* sp = reinterpret_cast<const uint16_t*>(S.sc_ptr[k]);
+            if ((f32m >> k) & 1u) raw[k] = as_global(reinterpret_cast<const uint32_t*>(sp))[idx];  // uniform: materialised leaf
+            else raw[k] = as_global(sp)[idx];
+        }
+    }
+    if (stat) {  // uniform
+        uint32_t gb = 2u * (uint32_t)__popc(pm & ~f32m) + 4u * (uint32_t)__popc(pm & f32m), g;
+        (void)wave_excl_scan_u32(gb, &g);
+        if (lane == 0) *stat += g;
+    }
+    uint32_t* const val = qidx;  // val[k * kWQCap + lane]: f32 bits of the leaf values, later of the group values at the group's first leaf
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)kWideMax; ++k)
+        if (k < S.L) {
+            float v = 0.0f;
+            if ((pm >> k) & 1u) v = ((f32m >> k) & 1u) ? __uint_as_float(raw[k]) : posting_value(S.ts[k], (uint16_t)raw[k]);
+            val[k * kWQCap + lane] = __float_as_uint(v);
+        }
+    // groups (a lane only ever reads its own column: no synchronisation)
+    const DWide* W = S.W;
+    uint32_t gp = 0;
+    for (uint32_t g = 0; g < S.G; ++g) {  // uniform
+        const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)W->g_kind[g]), b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)W->g_begin[g]),
+                       cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)W->g_count[g]);
+        const uint32_t gm = ((1u << cnt) - 1u) << b0;
+        if (kind == OP_LEAF) {
+            if (pm & gm) gp |= 1u << g;
+            continue;  // the value already sits at row b0
+        }
+        float gv;
+        if (kind == OP_AND) {  // set_op.rs:415-416
+            gv = 0.0f;
+            for (uint32_t i = 0; i < cnt; ++i) gv += __uint_as_float(val[(uint32_t)W->leaf_and_order[b0 + i] * kWQCap + lane]);
+            if ((pm & gm) == gm) gp |= 1u << g;
+        } else {  // set_op.rs:169-186: per term slot the maximum over the present leaves, summed in slot order
+            float sum = 0.0f, nd = 0.0f, m = 0.0f;
+            uint32_t cur = W->leaf_slot[W->leaf_slot_order[b0]];
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t k = W->leaf_slot_order[b0 + i], sl = W->leaf_slot[k];
+                if (sl != cur) {  // (the same in every lane)
+                    if (m >= 0.00001f) nd += 1.0f;
+                    sum += m;
+                    m = 0.0f;
+                    cur = sl;
+                }
+                if ((pm >> k) & 1u) m = fmaxf(m, __uint_as_float(val[k * kWQCap + lane]));
+            }
+            if (m >= 0.00001f) nd += 1.0f;
+            sum += m;
+            gv = sum * nd * nd;
+            if (pm & gm) gp |= 1u << g;
+        }
+        val[b0 * kWQCap + lane] = __float_as_uint(gv);
+    }
+    float score;
+    if (W->root_kind == OP_AND) {
+        score = 0.0f;
+        for (uint32_t i = 0; i < S.G; ++i) score += __uint_as_float(val[(uint32_t)W->g_begin[W->r_and_order[i]] * kWQCap + lane]);
+    } else {
+        float sum = 0.0f, nd = 0.0f, m = 0.0f;
+        uint32_t cur = W->r_slot[W->r_slot_order[0]];
+        for (uint32_t i = 0; i < S.G; ++i) {
+            const uint32_t g = W->r_slot_order[i], sl = W->r_slot[g];
+            if (sl != cur) {
+                if (m >= 0.00001f) nd += 1.0f;
+                sum += m;
+                m = 0.0f;
+                cur = sl;
+            }
+            if ((gp >> g) & 1u) m = fmaxf(m, __uint_as_float(val[(uint32_t)W->g_begin[g] * kWQCap + lane]));
+        }
+        if (m >= 0.00001f) nd += 1.0f;
+        sum += m;
+        score = sum * nd * nd;
+    }
+    const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+    bool pending = have && key > *cs.thr && key < cs.upper;
+    while (true) {
+        if (pending) {
+            if (key > *cs.thr) {
+                const uint32_t pos = atomicAdd(cs.n, 1u);
+                if (pos < cs.cap) {
+                    cs.cand[pos] = key;
+                    pending = false;
+                }
+            } else pending = false;
+        }
+        if (!__syncthreads_or(pending ? 1 : 0)) break;
+        cand_prune(cs, top_k);
+    }
+}
+
+template <uint32_t ML>  // leaves the instantiation holds in registers (8 or 16)
+__device__ __forceinline__ void scan_wide_body(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off, const uint32_t* __restrict__ span_base,
+                                               const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap, uint32_t ml,
+                                               unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t SW = kSW, SWW = kSWW;  // 8192 docs, 256 words per tile: one u32x4 per lane and leaf
+    const uint32_t lane = threadIdx.x;
+    uint32_t ql;
+    {
+        uint32_t lo = 0, hi = nq;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (span_base[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        ql = lo;
+    }
+    const uint32_t span = blockIdx.x - span_base[ql];
+    const uint32_t q = qmap[ql];
+    const uint8_t* blob = blobs + blob_off[q];
+    const QHeader* H = reinterpret_cast<const QHeader*>(blob);
+    const uint32_t top_k = H->top_k;
+
+    // ---- stage the tree shape and the leaves' descriptors
+    DWide* const WL = reinterpret_cast<DWide*>(lds + kWLdsW);
+    {
+        const uint32_t* gw = reinterpret_cast<const uint32_t*>(blob + H->off_simple2);
+        if (lane < (uint32_t)(sizeof(DWide) / 4)) lds[kWLdsW + lane] = gw[lane];
+    }
+    unsigned long long* const bm_ptr = reinterpret_cast<unsigned long long*>(lds + kWLdsBm);
+    unsigned long long* const rk_ptr = reinterpret_cast<unsigned long long*>(lds + kWLdsRk);
+    unsigned long long* const docs_ptr = reinterpret_cast<unsigned long long*>(lds + kWLdsDocs);
+    unsigned long long* const sc_ptr = reinterpret_cast<unsigned long long*>(lds + kWLdsSc);
+    uint32_t* const lens = lds + kWLdsLen;
+    float* const tss = reinterpret_cast<float*>(lds + kWLdsTs);
+    wave_lds_fence();
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->n_leaves), G = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->n_groups);
+    if (lane < L) {
+        const DList& d = reinterpret_cast<const DList*>(blob + H->off_lists)[WL->leaf_list[lane]];
+        bm_ptr[lane] = (unsigned long long)(uintptr_t)d.bitmap;
+        rk_ptr[lane] = (unsigned long long)(uintptr_t)d.rank_dir;
+        docs_ptr[lane] = (unsigned long long)(uintptr_t)d.docs;
+        sc_ptr[lane] = (unsigned long long)(uintptr_t)d.scores;
+        lens[lane] = d.len;
+        tss[lane] = d.term_score;
+    }
+    const uint32_t bitmap_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->bitmap_mask), cover_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->cover_mask),
+                   prefetch_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->prefetch_mask);
+    const bool seq = __builtin_amdgcn_readfirstlane((int)WL->seq) != 0;
+    const bool root_and = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->root_kind) == OP_AND;
+    uint32_t gfirst = 0, glast = 0, gand = 0;  // bit k: leaf k opens / closes its group, its group is an AND
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->g_begin[g]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->g_count[g]);
+        gfirst |= 1u << b0;
+        glast |= 1u << (b0 + cnt - 1u);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)WL->g_kind[g]) == OP_AND) gand |= ((1u << cnt) - 1u) << b0;
+    }
+    WideShape S{WL, sc_ptr, tss, L, G, (uint32_t)__builtin_amdgcn_readfirstlane((int)WL->f32_mask)};
+
+    unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t* cand_n = lds + 2;
+    uint32_t* cur = lds + kWLdsCur;
+    uint32_t* nxt = lds + kWLdsNxt;
+    uint32_t* gbits = lds + kWLdsGbits;  // QHeader::prune_gbits (read once: the class loop must not wait for HBM)
+    uint32_t* qdoc = lds + kWLdsQDoc;
+    uint32_t* qmask = lds + kWLdsQMask;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + kWLdsCand);
+    uint32_t* qidx = lds + kWLdsCand + 2 * cand_cap;  // [ml][kWQCap]
+    uint32_t* tiles = qidx + ml * kWQCap;             // [scattered leaves of the query][SWW]
+    CandState cs{cand, cand_n, thr, cand_cap, reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr))};
+    cs.upper = H->key_upper;
+    uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;
+
+    const uint32_t n_spans = H->n_spans;
+    const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(SW - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(SW - 1u));
+    const uint32_t bitmap_base = H->bitmap_base;
+    const uint32_t prune_n = H->prune_n;
+    if (lane < 16u) gbits[lane] = H->prune_gbits[lane];
+    if (lane == 0) {
+        *thr = 0ull;
+        *cand_n = 0;
+        lds[4] = 0u;
+    }
+    wave_lds_fence();
+    for (uint32_t k = 0; k < L; ++k) {  // cursors of the scattered leaves
+        if (!((bitmap_mask >> k) & 1u)) {
+            const uint32_t* docs = reinterpret_cast<const uint32_t*>(docs_ptr[k]);
+            const uint32_t len = lens[k];
+            const uint32_t c = wave_lower_bound(docs, len, span_lo);
+            if (lane == 0) {
+                cur[k] = c;
+                nxt[k] = c < len ? as_global(docs)[c] : 0xFFFFFFFFu;
+            }
+        }
+    }
+    wave_lds_fence();
+    uint32_t qlen = 0, tiles_done = 0;
+    unsigned long long hits = 0;
+    uint32_t pos = span_lo;
+    const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const u32x4 kZero = u32x4{0u, 0u, 0u, 0u};
+    const uint32_t scat_mask = ~bitmap_mask & ((1u << L) - 1u);
+
+    while (true) {
+        uint32_t head = 0xFFFFFFFFu;
+        if (seq) head = pos;
+        else
+            for (uint32_t k = 0; k < L; ++k)
+                if (((cover_mask & ~bitmap_mask) >> k) & 1u) {
+                    const uint32_t d = nxt[k];
+                    head = d < head ? d : head;
+                }
+        head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+        if (head >= span_hi) break;
+        const uint32_t tile_lo = head & ~(SW - 1u);
+        const uint32_t tile_end = tile_lo + SW;
+        const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
+        const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
+        pos = tile_end > tile_lo ? tile_end : 0xFFFFFFFFu;
+        unsigned long long gthr_now = 0ull;
+        const bool adopt = (tiles_done++ & 3u) == 0u;  // now and then: adopt the threshold other spans of the query have published (QHeader::gthr);
+        if (adopt && lane == 0) gthr_now = *reinterpret_cast<volatile unsigned long long*>(cs.gthr);  // (consumed behind phase A: in flight with the tile's loads)
+
+        // ---- phase A: every first load of the tile (bitmap words + rank directory entry, or the first id vector), then the scatters
+        u32x4 wv[ML];
+        uint32_t rank0[ML];
+#pragma unroll
+        for (uint32_t k = 0; k < ML; ++k) {
+            wv[k] = kZero;
+            rank0[k] = 0u;
+            if (k < L) {  // uniform
+                if ((bitmap_mask >> k) & 1u) {
+                    wv[k] = as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(bm_ptr[k]) + ((tile_lo - bitmap_base) >> 5)))[lane];
+                    rank0[k] = as_global(reinterpret_cast<const uint32_t*>(rk_ptr[k]))[(tile_lo - bitmap_base) >> 11];
+                } else {
+                    const uint32_t* docs = reinterpret_cast<const uint32_t*>(docs_ptr[k]);
+                    const uint32_t len = lens[k];
+                    uint32_t c = cur[k];
+                    const uint32_t nx = nxt[k];
+                    if (nx < tile_lo && tile_lo - nx >= SW) {  // a leaf outside the cover that fell more than a tile behind skips ahead first
+                        c += wave_lower_bound(docs + c, len - c, tile_lo);
+                        if (lane == 0) cur[k] = c;
+                    }
+                    const uint32_t v = (c >> 2) + lane;
+                    wv[k] = v < ((len + 3u) >> 2) ? as_global(reinterpret_cast<const u32x4*>(docs))[v] : kSent;
+                    reinterpret_cast<u32x4*>(tiles + (uint32_t)__popc(scat_mask & ((1u << k) - 1u)) * SWW)[lane] = kZero;
+                }
+            }
+        }
+        if (scat_mask) {  // uniform
+            wave_lds_fence();  // cursor updates and tile clears above before the scatters below
+#pragma unroll
+            for (uint32_t k = 0; k < ML; ++k)
+                if (k < L && ((scat_mask >> k) & 1u)) {
+                    uint32_t* const tile = tiles + (uint32_t)__popc(scat_mask & ((1u << k) - 1u)) * SWW;
+                    uint32_t c = cur[k], nx = nxt[k];
+                    rank0[k] = simple_scatter_list(reinterpret_cast<const uint32_t*>(docs_ptr[k]), lens[k], c, nx, tile, wv[k], (prefetch_mask >> k) & 1u, tile_lo, tile_hi, lo_bound);
+                    if (lane == 0) {
+                        cur[k] = c;
+                        nxt[k] = nx;
+                    }
+                }
+            wave_lds_fence();  // LDS atomics above before the reads below
+#pragma unroll
+            for (uint32_t k = 0; k < ML; ++k)
+                if (k < L && ((scat_mask >> k) & 1u)) wv[k] = reinterpret_cast<const u32x4*>(tiles + (uint32_t)__popc(scat_mask & ((1u << k) - 1u)) * SWW)[lane];
+        }
+        // presence of the groups and of the root, bit-sliced count of the leaves holding each doc
+        u32x4 root = root_and ? ~kZero : kZero, acc = kZero;
+        u32x4 p0 = kZero, p1 = kZero, p2 = kZero, p3 = kZero;
+#pragma unroll
+        for (uint32_t k = 0; k < ML; ++k)
+            if (k < L) {
+                const u32x4 w = wv[k];
+                if ((gfirst >> k) & 1u) acc = ((gand >> k) & 1u) ? ~kZero : kZero;
+                acc = ((gand >> k) & 1u) ? (acc & w) : (acc | w);
+                if ((glast >> k) & 1u) root = root_and ? (root & acc) : (root | acc);
+                const u32x4 c0 = p0 & w;
+                p0 ^= w;
+                const u32x4 c1 = p1 & c0;
+                p1 ^= c0;
+                const u32x4 c2 = p2 & c1;
+                p2 ^= c1;
+                p3 ^= c2;
+            }
+        if (adopt) {  // uniform
+            if (lane == 0 && gthr_now > *thr) *thr = gthr_now;
+            wave_lds_fence();
+        }
+        uint32_t Sn;
+        (void)wave_excl_scan_u32(popc4(root), &Sn);
+        if (!Sn) continue;  // uniform
+        hits += Sn;
+
+        // ---- phase B: count classes in descending order (or everything at once when the query has no bound table)
+        bool ranks_ready = false;  // uniform: rank0[k] += entries of leaf k in front of this lane's words — computed when the first doc is queued
+        for (uint32_t cls = prune_n ? prune_n : 1u; cls >= 1u; --cls) {  // uniform
+            u32x4 sel = root;
+            if (prune_n) {
+                const uint32_t thr_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(*thr >> 32));
+                if (thr_hi && (uint32_t)__builtin_amdgcn_readfirstlane((int)gbits[cls]) < thr_hi) break;  // neither this class nor a lower one can reach the threshold
+                sel &= ((cls & 1u) ? p0 : ~p0) & ((cls & 2u) ? p1 : ~p1) & ((cls & 4u) ? p2 : ~p2) & ((cls & 8u) ? p3 : ~p3);
+            }
+            uint32_t rr[4] = {sel.x, sel.y, sel.z, sel.w};
+            while (true) {  // uniform: every round each lane queues its next doc of the class
+                uint32_t j = 0u, rw = 0u;
+#pragma unroll
+                for (uint32_t t = 4; t-- > 0u;)
+                    if (rr[t]) {
+                        j = t;
+                        rw = rr[t];
+                    }
+                const bool has = rw != 0u;
+                const unsigned long long mask = __ballot(has);
+                if (!mask) break;
+                if (!ranks_ready) {  // uniform
+                    ranks_ready = true;
+#pragma unroll
+                    for (uint32_t k = 0; k < ML; ++k)
+                        if (k < L) {
+                            uint32_t dummy;
+                            rank0[k] += wave_excl_scan_u32(popc4(wv[k]), &dummy);
+                        }
+                }
+                if (has) {
+                    const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
+                    const uint32_t cleared = rw & (rw - 1u);
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; ++t)
+                        if (t == j) rr[t] = cleared;
+                    const uint32_t below = (1u << b) - 1u;
+                    const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    qdoc[p] = tile_lo + ((lane * 4u + j) << 5) + b;
+                    uint32_t m16 = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < ML; ++k)
+                        if (k < L) {
+                            const u32x4 w4 = wv[k];
+                            const uint32_t word = comp4(w4, j);
+                            if ((word >> b) & 1u) {
+                                m16 |= 1u << k;
+                                const uint32_t before = (j > 0u ? (uint32_t)__popc(w4.x) : 0u) + (j > 1u ? (uint32_t)__popc(w4.y) : 0u) + (j > 2u ? (uint32_t)__popc(w4.z) : 0u);
+                                qidx[k * kWQCap + p] = rank0[k] + before + (uint32_t)__popc(word & below);
+                            }
+                        }
+                    qmask[p] = m16;
+                }
+                qlen += (uint32_t)__popcll(mask);
+                if (qlen >= 64u) {  // uniform
+                    wave_lds_fence();
+                    wide_flush(64u, S, qdoc, qmask, qidx, cs, top_k, stat);
+                    const uint32_t rem = qlen - 64u;  // move the remainder to the front (source and destination are disjoint)
+                    wave_lds_fence();
+                    if (lane < rem) {
+                        const uint32_t td = qdoc[64u + lane], tm = qmask[64u + lane];
+                        for (uint32_t k = 0; k < L; ++k) qidx[k * kWQCap + lane] = qidx[k * kWQCap + 64u + lane];
+                        qdoc[lane] = td;
+                        qmask[lane] = tm;
+                    }
+                    wave_lds_fence();
+                    qlen = rem;
+                }
+            }
+            if (!prune_n) break;
+        }
+    }
+    wave_lds_fence();
+    if (qlen) wide_flush(qlen, S, qdoc, qmask, qidx, cs, top_k, stat);
+    cand_prune(cs, top_k);
+    {
+        const uint32_t cn = *cand_n;
+        unsigned long long* out = span_keys + (size_t)H->keys_base + (size_t)span * top_k;
+        for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
+    }
+    if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
+    if (lane == 0 && H->stat_off && lds[4]) atomicAdd(&num_hits[H->stat_off], (unsigned long long)lds[4]);
+}
+
+template <uint32_t ML>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ML <= 8 ? 4 : 3, 8))) void k_scan_wide(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                   const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
+                                                   uint32_t ml, unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
+    scan_wide_body<ML>(blobs, blob_off, span_base, qmap, nq, cand_cap, ml, span_keys, num_hits);
+}
+
+void launch_scan_wide(hipStream_t st, uint32_t max_leaves, uint32_t max_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
+                      const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+    if (!total_spans) return;
+    const size_t lds_bytes = scan_wide_lds_bytes(cand_cap, max_leaves, max_scatter);
+    if (max_leaves <= 8)
+        hipLaunchKernelGGL((k_scan_wide<8>), dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, max_leaves, span_keys, num_hits);
+    else
+        hipLaunchKernelGGL((k_scan_wide<16>), dim3(total_spans), dim3(64), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, cand_cap, max_leaves, span_keys, num_hits);
+}
+
+}  // namespace vq
+
+// ====================================================================================================
 // k_dict_scan (K9) — fuzzy / prefix term expansion: one lane per dictionary term, Myers / Hyyrö bit-vector
 // edit distance of the query (pattern, <= 64 code points) against the term (text).  Decides exactly what the
 // reference's Levenshtein DFA accepts (search_field.rs:85-95): distance(term, query) <= max_d, with adjacent
