@@ -1815,6 +1815,8 @@ struct Compiler {
 
 }  // namespace
 
+float default_score_for_distance_host(uint8_t distance, bool prefix_matches) { return default_score_for_distance(distance, prefix_matches); }
+
 // ---- dictionary scans requested by a batch (collected before compilation, answered by k_dict_scan)
 std::string fuzzy_key(const RequestSearchPart& p) {
     std::string path = p.path;

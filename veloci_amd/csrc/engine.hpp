@@ -118,6 +118,7 @@ struct Dictionary {  // term dictionary of one text field
     std::unordered_map<std::string, std::vector<uint32_t>> lower_map;  // lowercase(term) -> ascending term ids (exact lookups)
     // device image for the fuzzy / prefix scan (k_dict_scan): code points as u16, raw and lower-cased
     bool bmp_only = true;  // false: some term has a code point above U+FFFF -> no device image, fuzzy unsupported on this field
+    bool low_exact = true; // false: the lower-cased image is not str::to_lowercase of every term (U+0130): matches are scored on the host
     DevBuf d_off;          // u32 [T + 1]
     DevBuf d_raw;          // u16
     DevBuf d_low;          // u16
@@ -145,6 +146,7 @@ void collect_fuzzy_probes(const Index& idx, const vqreq::Request& req, FuzzyTabl
 struct Workspace;
 void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStream_t st);
 void score_fuzzy_probe(const Index& idx, FuzzyProbe& probe);
+float default_score_for_distance_host(uint8_t distance, bool prefix_matches);  // search_field.rs:27-33
 
 // A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the
 // terms' posting lists with the per-doc maximum of term_score * (f16 / 100).

@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "text.hpp"
 
 namespace vq {
 
@@ -225,89 +226,109 @@ void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStr
     for (auto& kv : table)
         if (kv.second.status == 0) todo.push_back(&kv.second);
     if (todo.empty()) return;
-    std::vector<uint32_t> cap(todo.size(), 0u);
-    for (size_t i = 0; i < todo.size(); ++i) cap[i] = std::min<uint32_t>(uint32_t(idx.dict.at(todo[i]->path).terms.size()), 1u << 16);
-    std::vector<size_t> active(todo.size());
-    for (size_t i = 0; i < todo.size(); ++i) active[i] = i;
-    for (int pass = 0; pass < 2 && !active.empty(); ++pass) {  // pass 1 re-runs the probes whose match set outgrew the first guess
-        const size_t chunk = 4096;                               // probes per launch (grid.y limit 65535, bounded scratch)
-        std::vector<size_t> overflow;
-        for (size_t c0 = 0; c0 < active.size(); c0 += chunk) {
-            const size_t c1 = std::min(active.size(), c0 + chunk);
-            std::vector<DictProbe> probes(c1 - c0);
-            std::vector<uint64_t> out_off(c1 - c0 + 1, 0);
-            uint32_t max_terms = 0;
-            for (size_t i = c0; i < c1; ++i) out_off[i - c0 + 1] = out_off[i - c0] + cap[active[i]];
-            DevBuf &d_probes = ws.d_probe_desc, &d_counts = ws.d_probe_counts, &d_ids = ws.d_probe_ids;
-            d_probes.ensure(probes.size() * sizeof(DictProbe));
-            d_counts.ensure(probes.size() * 4 + 16);
-            d_ids.ensure(out_off.back() * 4 + 16);
-            for (size_t i = c0; i < c1; ++i) {
-                const FuzzyProbe& fp = *todo[active[i]];
-                const Dictionary& d = idx.dict.at(fp.path);
-                DictProbe& P = probes[i - c0];
-                std::memset(&P, 0, sizeof P);
-                P.off = d.d_off.as<uint32_t>();
-                P.chars = fp.ci ? d.d_low.as<uint16_t>() : d.d_raw.as<uint16_t>();
-                P.num_terms = uint32_t(d.terms.size());
-                P.m = uint32_t(fp.query.size());
-                P.max_d = fp.max_d;
-                P.flags = (fp.transposition ? 1u : 0u) | (fp.prefix ? 2u : 0u);
-                P.out_cap = cap[active[i]];
-                P.out_count = d_counts.as<uint32_t>() + (i - c0);
-                P.out_ids = d_ids.as<uint32_t>() + out_off[i - c0];
-                for (size_t j = 0; j < fp.query.size(); ++j) P.query[j] = fp.query[j];
-                max_terms = std::max(max_terms, P.num_terms);
-            }
-            VQ_HIP(hipMemsetAsync(d_counts.p, 0, probes.size() * 4, st));
-            VQ_HIP(hipMemcpyAsync(d_probes.p, probes.data(), probes.size() * sizeof(DictProbe), hipMemcpyHostToDevice, st));
-            {
-                uint64_t dict_bytes = 0;  // every probe reads its dictionary once: offsets + code points (16 B per padded term)
-                for (size_t i = c0; i < c1; ++i) {
-                    const Dictionary& d = idx.dict.at(todo[active[i]]->path);
-                    dict_bytes += d.d_off.bytes + d.d_low.bytes;
-                }
-                LaunchTimer timer(idx.profile.enabled, ws, st, K_DICT_SCAN, dict_bytes, dict_bytes, c1 - c0);
-                launch_dict_scan(st, d_probes.as<DictProbe>(), uint32_t(probes.size()), max_terms);
-            }
-            VQ_HIP(hipGetLastError());
-            std::vector<uint32_t> counts(probes.size());
-            VQ_HIP(hipMemcpyAsync(counts.data(), d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost, st));
-            VQ_HIP(hipStreamSynchronize(st));
-            for (size_t i = c0; i < c1; ++i) {  // all match sets in one go: asynchronous copies, one synchronisation
-                FuzzyProbe& fp = *todo[active[i]];
-                const uint32_t cnt = counts[i - c0];
-                if (cnt > cap[active[i]]) continue;
-                fp.matches.resize(cnt);
-                if (cnt) VQ_HIP(hipMemcpyAsync(fp.matches.data(), d_ids.as<uint32_t>() + out_off[i - c0], size_t(cnt) * 4, hipMemcpyDeviceToHost, st));
-            }
-            VQ_HIP(hipStreamSynchronize(st));
-            for (size_t i = c0; i < c1; ++i) {
-                FuzzyProbe& fp = *todo[active[i]];
-                const uint32_t cnt = counts[i - c0];
-                if (cnt > cap[active[i]]) {
-                    cap[active[i]] = cnt;
-                    overflow.push_back(active[i]);
-                    continue;
-                }
-                std::sort(fp.matches.begin(), fp.matches.end());
-            }
+    auto image_of = [&](const FuzzyProbe& fp) {  // the dictionary image a probe scans
+        const Dictionary& d = idx.dict.at(fp.path);
+        return fp.ci ? d.d_low.as<uint16_t>() : d.d_raw.as<uint16_t>();
+    };
+    // probes of one image next to each other: a launch scans ONE image for a run of probes (blocks answer 16 probes per pass over their terms)
+    std::stable_sort(todo.begin(), todo.end(), [&](const FuzzyProbe* a, const FuzzyProbe* b) { return image_of(*a) < image_of(*b); });
+    std::vector<DictProbe> probes(todo.size());
+    std::vector<uint8_t> host_scored(todo.size(), 0);
+    for (size_t i = 0; i < todo.size(); ++i) {
+        const FuzzyProbe& fp = *todo[i];
+        DictProbe& P = probes[i];
+        std::memset(&P, 0, sizeof P);
+        P.m = uint32_t(fp.query.size());
+        P.max_d = fp.max_d;
+        P.flags = (fp.transposition ? 1u : 0u) | (fp.prefix ? 2u : 0u);
+        for (size_t j = 0; j < fp.query.size(); ++j) P.query[j] = fp.query[j];
+        const auto lcps = vqtext::decode_utf8(fp.lower_term);  // scoring side: the lower-cased term as a whole (search_field.rs:298-300)
+        bool bmp = lcps.size() <= 64 && idx.dict.at(fp.path).low_exact;
+        for (uint32_t cp : lcps) bmp = bmp && cp <= 0xFFFFu;
+        if (bmp) {
+            P.lm = uint32_t(lcps.size());
+            for (size_t j = 0; j < lcps.size(); ++j) P.lquery[j] = uint16_t(lcps[j]);
+        } else {
+            P.lm = 0xFFFFFFFFu;
+            host_scored[i] = 1;
         }
-        active.swap(overflow);
     }
-    // host side of the leaf: score every match once per distinct probe (a few threads when there is a lot to score)
-    size_t total = 0;
-    for (FuzzyProbe* fp : todo) total += fp->matches.size();
-    if (total >= 4096 && todo.size() >= 2) {
-        const size_t nt = std::min<size_t>(4, todo.size());
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                for (size_t i = t; i < todo.size(); i += nt) score_fuzzy_probe(idx, *todo[i]);
-            });
-        for (auto& t : th) t.join();
-    } else
-        for (FuzzyProbe* fp : todo) score_fuzzy_probe(idx, *fp);
+    DevBuf &d_probes = ws.d_probe_desc, &d_count = ws.d_probe_counts, &d_out = ws.d_probe_ids;
+    d_probes.ensure(probes.size() * sizeof(DictProbe));
+    d_count.ensure(64);
+    VQ_HIP(hipMemcpyAsync(d_probes.p, probes.data(), probes.size() * sizeof(DictProbe), hipMemcpyHostToDevice, st));
+    uint32_t cap = uint32_t(std::max<size_t>(64 * todo.size(), 1u << 16));  // matches of the whole batch share one output array
+    std::vector<DictMatch> recs;
+    for (int pass = 0; pass < 2; ++pass) {  // pass 1 only when the matches outgrew the first guess (the count is exact then)
+        d_out.ensure(size_t(cap) * sizeof(DictMatch) + 16);
+        VQ_HIP(hipMemsetAsync(d_count.p, 0, 4, st));
+        {
+            uint64_t dict_bytes = 0, layout = 0;  // every probe reads its dictionary once (offsets + code points) ...
+            for (FuzzyProbe* fp : todo) {
+                const Dictionary& d = idx.dict.at(fp->path);
+                dict_bytes += d.d_off.bytes + d.d_low.bytes;
+            }
+            LaunchTimer timer(idx.profile.enabled, ws, st, K_DICT_SCAN, 0, dict_bytes, todo.size());
+            for (size_t g0 = 0; g0 < todo.size();) {  // one launch per run of probes over the same image
+                size_t g1 = g0 + 1;
+                while (g1 < todo.size() && image_of(*todo[g1]) == image_of(*todo[g0])) ++g1;
+                const Dictionary& d = idx.dict.at(todo[g0]->path);
+                launch_dict_scan(st, d_probes.as<DictProbe>() + g0, uint32_t(g0), uint32_t(g1 - g0), d.d_off.as<uint32_t>(), image_of(*todo[g0]), d.d_low.as<uint16_t>(),
+                                 uint32_t(d.terms.size()), d_count.as<uint32_t>(), cap, d_out.as<DictMatch>());
+                layout += (d.d_off.bytes + d.d_low.bytes) * ((g1 - g0 + 15) / 16);  // ... this layout: once per 16 probes of one image
+                g0 = g1;
+            }
+            if (!ws.timed.empty() && idx.profile.enabled) ws.timed.back().layout_bytes = layout;
+        }
+        VQ_HIP(hipGetLastError());
+        uint32_t count = 0;
+        VQ_HIP(hipMemcpyAsync(&count, d_count.p, 4, hipMemcpyDeviceToHost, st));
+        VQ_HIP(hipStreamSynchronize(st));
+        if (count > cap) {
+            if (pass == 1) throw VelociError(ERR_DEVICE, "dictionary scan: match count changed between passes");
+            cap = count;
+            continue;
+        }
+        recs.resize(count);
+        if (count) {
+            VQ_HIP(hipMemcpyAsync(recs.data(), d_out.p, size_t(count) * sizeof(DictMatch), hipMemcpyDeviceToHost, st));
+            VQ_HIP(hipStreamSynchronize(st));
+        }
+        break;
+    }
+    // bucket by probe, ascending term ids (== FST stream order, which is the reference's callback order)
+    std::sort(recs.begin(), recs.end(), [](const DictMatch& a, const DictMatch& b) { return a.probe != b.probe ? a.probe < b.probe : a.term < b.term; });
+    size_t r = 0;
+    for (size_t i = 0; i < todo.size(); ++i) {
+        FuzzyProbe& fp = *todo[i];
+        fp.matches.clear();
+        fp.scores.clear();
+        const Dictionary& dict = idx.dict.at(fp.path);
+        for (; r < recs.size() && recs[r].probe == i; ++r) {
+            fp.matches.push_back(recs[r].term);
+            if (host_scored[i]) continue;
+            const uint32_t osa = recs[r].info & 0xFFu, lev = (recs[r].info >> 8) & 0xFFu;
+            const bool starts = (recs[r].info >> 16) & 1u;
+            uint32_t d;
+            if (osa <= fp.lev && osa < 255u) d = osa;  // the scoring automaton's answer (search_field.rs:691-702)
+            else {  // its fallback, plain Levenshtein in u8 — 255 for strings of 255 bytes or more (:705-732)
+                const bool long_strings = fp.lower_term.size() >= 255 || (dict.terms[recs[r].term].size() >= 200 && vqtext::to_lower_utf8(dict.terms[recs[r].term]).size() >= 255);
+                d = long_strings ? 255u : lev;
+                if (!long_strings && (osa == 255u || lev == 255u)) {  // capped on the device: exact on the host (never for dictionary-sized terms)
+                    host_scored[i] = 2;
+                    break;
+                }
+            }
+            fp.scores.push_back(default_score_for_distance_host(uint8_t(d), fp.check_prefix && starts));
+        }
+        if (host_scored[i] == 2) {  // (rare) finish the bucket, then score all of it on the host
+            fp.matches.clear();
+            size_t r0 = r;
+            while (r0 > 0 && recs[r0 - 1].probe == i) --r0;
+            for (r = r0; r < recs.size() && recs[r].probe == i; ++r) fp.matches.push_back(recs[r].term);
+        }
+        if (host_scored[i]) score_fuzzy_probe(idx, fp);
+    }
 }
 
 // K2: run the union jobs of a batch.  Level 1 merges groups of <= 64 posting lists (one lane per list); a job with
@@ -339,7 +360,7 @@ void run_union_level(bool timed, Workspace& ws, std::vector<UnionTaskH>& tasks, 
             ulists.push_back(tasks[t].lists[i]);
         }
         u.pivot = u.list_begin + piv;
-        uint64_t spans = std::min<uint64_t>(std::max<uint64_t>(total / 2048, 1), 4096);
+        uint64_t spans = std::min<uint64_t>(std::max<uint64_t>(total / 512, 1), 4096);  // (short spans: a span is one serial merge loop, its length is the pass's latency)
         spans = std::min<uint64_t>(spans, std::max<uint32_t>(tasks[t].lists[piv].len, 1u));
         u.span_begin = uint32_t(span_task.size());
         u.n_spans = uint32_t(spans);
@@ -813,6 +834,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t scatter_wide = 0, scatter_simple = 0;  // id (scattered) lists per query: they alone need an LDS tile in k_scan_simple
     uint32_t n_simple = 0, n_generic = 0, n_dense = 0, n_wide = 0, n_rich = 0, spans_simple = 0, spans_generic = 0, spans_dense = 0, spans_wide = 0, spans_rich = 0;
     uint32_t scatter_rich = 0;
+    bool facets_rich = false;
     uint32_t n_leaf = 0, spans_leaf = 0;
     uint32_t n_xwide = 0, spans_xwide = 0, leaves_xwide = 0, scatter_xwide = 0;
     uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
@@ -871,6 +893,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 accx += cq.n_spans;
             } else if (rich) {
                 kclass = K_SCAN_RICH;
+                facets_rich = facets_rich || !cq.facets.empty();
                 scatter_rich = std::max<uint32_t>(scatter_rich, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)) + cq.simple2.n_side);
                 sr[n_rich] = accr;
                 mr[n_rich++] = qi;
@@ -945,6 +968,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             desc_cap = std::max(desc_cap, uint32_t(d));
         }
     desc_cap = uint32_t(align_up(desc_cap, 16));
+    bool facets_generic = false;  // k_tile_scan queries with facets: room for the LDS counter cache behind the descriptor
+    static const bool no_facet_cache = std::getenv("VQ_NO_FACET_CACHE") != nullptr;
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == 0 && !pb->queries[i].simple_flags && !pb->queries[i].facets.empty()) facets_generic = !no_facet_cache;
+    if (facets_generic) desc_cap += 2 * 1024 * 4;
     static const uint32_t cand_min = [] {
         const char* e = std::getenv("VQ_CAND_CAP");  // (a small buffer is pruned — and its threshold raised — sooner: 64 beats 256 by 2-7 %)
         return uint32_t(e ? std::max(32, std::atoi(e)) : 64);
@@ -969,7 +997,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     if (spans_rich) {
         LaunchTimer t(prof, ws, st, K_SCAN_RICH, cls_layout[K_SCAN_RICH], cls_algo[K_SCAN_RICH], cls_q[K_SCAN_RICH]);
-        launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, tab(up_span_r), tab(up_qmap_r), n_rich, cand_cap, keys_ptr, hits_ptr, hist_ptr);
+        launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, tab(up_span_r), tab(up_qmap_r), n_rich, cand_cap, keys_ptr, hits_ptr, hist_ptr, facets_rich);
     }
     VQ_HIP(hipGetLastError());
     if (spans_wide) {
@@ -996,7 +1024,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (spans_generic) {
         LaunchTimer t(prof, ws, st, K_TILE_SCAN, cls_layout[K_TILE_SCAN], cls_algo[K_TILE_SCAN], cls_q[K_TILE_SCAN]);
         launch_tile_scan(st, spans_generic, lds_bytes, pb->d_blobs, pb->d_blob_off, pb->d_span_base, tab(up_qmap_g), n_generic, stack_depth, cand_cap, desc_cap, keys_ptr,
-                         hits_ptr, hist_ptr, tile_queue, list_table);
+                         hits_ptr, hist_ptr, tile_queue, list_table, facets_generic);
     }
     VQ_HIP(hipGetLastError());
     {

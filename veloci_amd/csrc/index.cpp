@@ -138,6 +138,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             for (uint32_t i = 0; i < d.terms.size(); ++i) {
                 for (uint32_t cp : vqtext::decode_utf8(d.terms[i])) {
                     if (cp > 0xFFFFu) d.bmp_only = false;
+                    if (cp == 0x130u) d.low_exact = false;  // lower-cases to TWO code points ("i" + U+0307): the image is per code point
                     raw.push_back(uint16_t(cp));
                     low.push_back(uint16_t(vqtext::lower_cp(cp)));
                 }

@@ -264,6 +264,28 @@ __device__ float apply_col_boost(float score, const DColBoost& cb, uint32_t doc)
     return apply_boost_value(score, cb, as_global(cb.values)[row]);
 }
 
+constexpr uint32_t kFacetCache = 1024;  // slots of the per-workgroup facet counter cache (keys + counts: 8 KB)
+// Facet counting (persistence.rs:164-175): a hit adds one to the histogram entry of each of its values.  Hot values (a Zipf-skewed category
+// field) would serialise on single HBM words; the workgroup keeps a direct-mapped counter cache in LDS — a value takes the slot its index
+// hashes to if that is free or already its own, else the add goes straight to HBM — and flushes the cache once, when its span ends.
+__device__ __forceinline__ void facet_add(uint32_t* fc_keys, uint32_t* hist, uint32_t idx) {
+    if (fc_keys) {  // uniform
+        const uint32_t slot = (idx * 2654435761u) >> 22;
+        const uint32_t old = atomicCAS(&fc_keys[slot], 0xFFFFFFFFu, idx);
+        if (old == 0xFFFFFFFFu || old == idx) {
+            atomicAdd(&fc_keys[kFacetCache + slot], 1u);
+            return;
+        }
+    }
+    atomicAdd(&hist[idx], 1u);
+}
+__device__ __forceinline__ void facet_cache_flush(uint32_t* fc_keys, uint32_t* hist) {
+    for (uint32_t s2 = threadIdx.x; s2 < kFacetCache; s2 += 64u) {
+        const uint32_t key = fc_keys[s2];
+        if (key != 0xFFFFFFFFu) atomicAdd(&hist[key], fc_keys[kFacetCache + s2]);
+    }
+}
+
 // ------------------------------------------------------------------------------------ per-hit scoring
 // wave64 inclusive add-scan with DPP row shifts / row broadcasts (gfx9 family), ~6 VALU instead of 6 LDS permutes
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
@@ -307,6 +329,7 @@ struct ScoreCtx {
     const VQ_CONST DOp* kops;      // the same ops / lists in the query blob in HBM, for wave-uniform (scalar) reads
     const VQ_CONST DList* klists;
     uint32_t* gb;                  // this lane's count of bytes read by per-hit gathers (profiling: QHeader::stat_off)
+    uint32_t* fc_keys;             // facet counter cache in LDS (null: none)
 };
 
 __device__ __forceinline__ float pick4(float v0, float v1, float v2, float v3, uint32_t k) { return k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3; }
@@ -491,14 +514,14 @@ __device__ float sink_stages(const ScoreCtx& c, float score, uint32_t doc, const
             if (fa.direct) {  // uniform: a scalar field
                 const uint32_t v = as_global(fa.direct)[row];
                 *c.gb += 4u;
-                if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
+                if (v < fa.num_values) facet_add(c.fc_keys, c.hist, fa.hist_off + v);
                 continue;
             }
             const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
             *c.gb += 16u + 4u * (uint32_t)(e1 - e0);
             for (unsigned long long e = e0; e < e1; ++e) {
                 const uint32_t v = as_global(fa.values)[e];
-                if (v < fa.num_values) atomicAdd(&c.hist[fa.hist_off + v], 1u);
+                if (v < fa.num_values) facet_add(c.fc_keys, c.hist, fa.hist_off + v);
             }
         }
     }
@@ -552,6 +575,7 @@ constexpr uint32_t kSurvCap = 256;
 __host__ __device__ constexpr uint32_t lds_desc_off(uint32_t ml) { return kLdsCur + 7u * ml + kSurvCap / 2u; }
 
 size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, bool queue, uint32_t ml) {
+    // (the facet counter cache, 2 * kFacetCache words, sits directly behind the descriptor: launches with facets pass desc_cap + its bytes)
     size_t u32s = lds_desc_off(ml) + desc_cap / 4 + 2 * (size_t)cand_cap + (size_t)stack_depth * kBlock + (size_t)tile_words + (size_t)n_bitmaps * tile_words +
                   ((size_t)n_lists * tile_words + 1) / 2;
     // survivor queue (queries of <= kQueueMaxLists lists): qmask u64[kQueueCap], qdoc u32[kQueueCap], qidx u32[n_lists][kQueueCap]
@@ -654,7 +678,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     uint32_t tiles_done = 0;
     // survivor queue: the few docs per tile that the pruning leaves wait until 64 of them make a full scoring round (a round costs the
     // same for 1 and for 64 docs); their list memberships and posting indices are captured when they are queued
-    const bool use_queue = queue_on && L <= kQueueMaxLists && !H->n_counts && !H->simple_n;  // uniform
+    const bool use_queue = (queue_on & 1u) && L <= kQueueMaxLists && !H->n_counts && !H->simple_n;  // uniform
+    // facet counter cache: the last 2 * kFacetCache words of the descriptor area (the host sized desc_cap for it: queue_on bit 1)
+    uint32_t* const fc_keys = ((queue_on & 2u) && n_facets && !H->n_counts) ? lds + kLdsDesc + desc_cap / 4 - 2u * kFacetCache : nullptr;
+    if (fc_keys)
+        for (uint32_t x = tid; x < kFacetCache; x += kBlock) {
+            fc_keys[x] = 0xFFFFFFFFu;
+            fc_keys[kFacetCache + x] = 0u;
+        }
     uint32_t* const qbase = lds + ((((uint32_t)(reinterpret_cast<uint32_t*>(pre) - lds) + (L * WW + 1u) / 2u) + 1u) & ~1u);
     unsigned long long* const qmask = reinterpret_cast<unsigned long long*>(qbase);
     uint32_t* const qdoc = qbase + 2u * kQueueCap;
@@ -1016,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             VQ_STAMP_AT(4)
 
             ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
-                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb};
+                        bm, pre, cur, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb, fc_keys};
             if (compact && use_queue) {
                 for (uint32_t base = 0; base < S; base += 32u) {  // uniform
                     const uint32_t nb = S - base < 32u ? S - base : 32u;
@@ -1127,7 +1158,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     if (qlen) {  // uniform
         __syncthreads();
         ScoreCtx sc{lists, ops, n_ops, H->simple_n, groups, n_groups, tboosts, n_tboost, cols, n_col, locf, loc_idx, n_locf, facets, n_facets,
-                    bm, pre, cur2, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb};
+                    bm, pre, cur2, cnt_lo, WW, reinterpret_cast<float*>(stack), hist, kops, klists, &my_gb, fc_keys};
         tile_queue_flush(qlen, sc, qdoc, qmask, qidx, cs, top_k);
     }
     cand_prune(cs, top_k);
@@ -1138,6 +1169,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     }
     if (my_hits) atomicAdd(hits_acc, my_hits);
     __syncthreads();
+    if (fc_keys) facet_cache_flush(fc_keys, hist);
     if (tid == 0 && *hits_acc) atomicAdd(&num_hits[q], (unsigned long long)*hits_acc);
     {
         uint32_t gb_total;
@@ -1303,29 +1335,38 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
     __syncthreads();
     const uint32_t* h = hist + job.hist_off;
     const uint32_t k = job.top;
-    for (uint32_t base = 0; base < job.num_values; base += kBlock) {  // uniform trip count
-        const uint32_t v = base + threadIdx.x;
-        bool pending = false;
-        unsigned long long key = 0ull;
-        if (v < job.num_values) {
-            const uint32_t c = h[v];
-            if (c) {
-                key = ((unsigned long long)c << 32) | (unsigned long long)(0xFFFFFFFFu - v);  // count desc, value id asc
+    // four values per thread and round (the batch's histogram area is 4-byte aligned only: values are read one by one, but a round of 256
+    // mostly-zero entries costs one ballot instead of four push loops)
+    for (uint32_t base = 0; base < job.num_values; base += 4u * kBlock) {  // uniform trip count
+        uint32_t c4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t v = base + j * kBlock + threadIdx.x;
+            c4[j] = v < job.num_values ? h[v] : 0u;
+        }
+        if (!__syncthreads_or((c4[0] | c4[1] | c4[2] | c4[3]) != 0u)) continue;  // uniform: nothing counted in these 256 values
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t v = base + j * kBlock + threadIdx.x;
+            unsigned long long key = 0ull;
+            bool pending = false;
+            if (c4[j]) {
+                key = ((unsigned long long)c4[j] << 32) | (unsigned long long)(0xFFFFFFFFu - v);  // count desc, value id asc
                 pending = key > *cs.thr;
             }
-        }
-        while (true) {
-            if (pending) {
-                uint32_t pos = atomicAdd(cs.n, 1u);
-                if (pos < (uint32_t)kCandCap) {
-                    cand[pos] = key;
-                    pending = false;
+            while (true) {
+                if (pending) {
+                    uint32_t pos = atomicAdd(cs.n, 1u);
+                    if (pos < (uint32_t)kCandCap) {
+                        cand[pos] = key;
+                        pending = false;
+                    }
                 }
+                const int need = __syncthreads_or(pending ? 1 : 0);
+                if (!need) break;
+                cand_prune(cs, k);
+                if (pending && !(key > *cs.thr)) pending = false;
             }
-            const int need = __syncthreads_or(pending ? 1 : 0);
-            if (!need) break;
-            cand_prune(cs, k);
-            if (pending && !(key > *cs.thr)) pending = false;
         }
     }
     cand_prune(cs, k, true);
@@ -1341,10 +1382,10 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
 // ------------------------------------------------------------------------------------ launchers
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                       const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys,
-                      unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml) {
+                      unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml, bool facet_cache) {
     if (!total_spans) return;
     hipLaunchKernelGGL(k_tile_scan, dim3(total_spans), dim3(kBlock), lds_bytes, st, blobs, blob_off, span_base, qmap, nq, stack_depth, cand_cap,
-                       desc_cap, span_keys, num_hits, hist, queue ? 1u : 0u, ml);
+                       desc_cap, span_keys, num_hits, hist, (queue ? 1u : 0u) | (facet_cache ? 2u : 0u), ml);
 }
 void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const unsigned long long* span_keys,
                         unsigned long long* part_keys) {
@@ -1388,7 +1429,9 @@ constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
 constexpr uint32_t kSLdsQMask = kSLdsQIdx + 4 * kQCap;  // rich queries: side-list membership bits of the queued doc
 constexpr uint32_t kSLdsCand = kSLdsQMask + kQCap;
 
-size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter) { return (size_t)(kSLdsCand + 2 * cand_cap + n_scatter * kSWW * nv) * 4 + 16; }
+size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter, bool facet_cache) {
+    return (size_t)(kSLdsCand + 2 * cand_cap + n_scatter * kSWW * nv + (facet_cache ? 2 * kFacetCache : 0)) * 4 + 16;
+}
 
 struct SimpleLeaf {
     const uint32_t* docs;
@@ -1477,6 +1520,7 @@ struct RichShape {
     const DFacet* facets;
     uint32_t n_facets;
     uint32_t* hist;
+    uint32_t* fc_keys;  // facet counter cache in LDS (null: none)
     float grp_mult[4], tb_mult[4];
     const DColBoost* cols;
     uint32_t n_col;
@@ -1499,7 +1543,7 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
         R.tb_mult[g] = S2->tb_mult[g];
     }
     R.n_grp = S2->n_grp; R.n_tb = S2->n_tb; R.n_loc = S2->n_loc; R.has_filter = S2->has_filter; R.filter_mask = S2->filter_mask; R.f32_mask = S2->f32_mask;
-    R.facets = nullptr; R.n_facets = 0; R.hist = nullptr;
+    R.facets = nullptr; R.n_facets = 0; R.hist = nullptr; R.fc_keys = nullptr;
     R.grp_mask4 = *reinterpret_cast<const uint32_t*>(S2->grp_mask);
     R.tb_side4 = *reinterpret_cast<const uint32_t*>(S2->tb_side);
     R.loc_leaf2 = (uint32_t)S2->loc_leaf[0] | ((uint32_t)S2->loc_leaf[1] << 8);
@@ -1624,14 +1668,14 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
                 if (fa.direct) {  // uniform: a scalar field
                     const uint32_t v = as_global(fa.direct)[row];
                     gb += 4u;
-                    if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
+                    if (v < fa.num_values) facet_add(R.fc_keys, R.hist, fa.hist_off + v);
                     continue;
                 }
                 const unsigned long long e0 = as_global(fa.offsets)[row], e1 = as_global(fa.offsets)[row + 1];
                 gb += 16u + 4u * (uint32_t)(e1 - e0);
                 for (unsigned long long e = e0; e < e1; ++e) {
                     const uint32_t v = as_global(fa.values)[e];
-                    if (v < fa.num_values) atomicAdd(&R.hist[fa.hist_off + v], 1u);
+                    if (v < fa.num_values) facet_add(R.fc_keys, R.hist, fa.hist_off + v);
                 }
             }
         }
@@ -1712,7 +1756,8 @@ __device__ __forceinline__ uint32_t simple_scatter_list(const uint32_t* docs, ui
 template <uint32_t NV, bool RICH>  // NV: u32x4 bitmap vectors per lane (the tile is NV * 8192 docs); RICH: DSimple2 queries
 __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                  const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t cand_cap,
-                                                 unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
+                                                 unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist,
+                                                 uint32_t fc_off) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t SW = kSW * NV, SWW = kSWW * NV, NW = 4u * NV;  // docs / words per tile, words per lane
     const uint32_t lane = threadIdx.x;
@@ -1744,6 +1789,13 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         R.facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
         R.n_facets = H->n_facets;
         R.hist = hist;
+        if (fc_off && R.n_facets) {  // uniform
+            R.fc_keys = lds + fc_off;
+            for (uint32_t s2 = lane; s2 < kFacetCache; s2 += 64u) {
+                R.fc_keys[s2] = 0xFFFFFFFFu;
+                R.fc_keys[kFacetCache + s2] = 0u;
+            }
+        }
     }
 
     SimpleLeaf lf[4];
@@ -2115,6 +2167,12 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     }
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
     if (lane == 0 && H->stat_off && lds[4]) atomicAdd(&num_hits[H->stat_off], (unsigned long long)lds[4]);
+    if constexpr (RICH) {
+        if (R.fc_keys) {  // uniform
+            __syncthreads();
+            facet_cache_flush(R.fc_keys, hist);
+        }
+    }
 }
 
 // 16384-doc tiles (NV = 2) cut the per-tile instruction overhead — with LDS sized by need the kernel is VALU-issue bound, not
@@ -2123,24 +2181,27 @@ template <uint32_t NV, bool RICH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                     uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
-                                                    unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist) {
-    scan_simple_body<NV, RICH>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits, hist);
+                                                    unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist, uint32_t fc_off) {
+    scan_simple_body<NV, RICH>(blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits, hist, fc_off);
 }
 
 // n_scatter: LDS tiles per workgroup (scattered leaves + side lists, maximum over the launch's queries)
 void launch_scan_simple(hipStream_t st, bool rich, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist) {
+                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool facet_cache) {
     if (!total_spans) return;
     static const uint32_t force_nv = std::getenv("VQ_SIMPLE_NV") ? uint32_t(std::atoi(std::getenv("VQ_SIMPLE_NV"))) : 0u;
-    if (rich)
-        hipLaunchKernelGGL((k_scan_simple<2, true>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits, hist);
-    else if (force_nv == 1u)
-        hipLaunchKernelGGL((k_scan_simple<1, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits, hist);
+    static const bool no_fc = std::getenv("VQ_NO_FACET_CACHE") != nullptr;
+    if (rich) {
+        const bool fc = facet_cache && !no_fc;
+        const uint32_t fc_off = fc ? kSLdsCand + 2 * cand_cap + n_scatter * kSWW * 2 : 0u;
+        hipLaunchKernelGGL((k_scan_simple<2, true>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter, fc), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits, hist, fc_off);
+    } else if (force_nv == 1u)
+        hipLaunchKernelGGL((k_scan_simple<1, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 1, n_scatter, false), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits, hist, 0u);
     else
-        hipLaunchKernelGGL((k_scan_simple<2, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter), st, blobs, blob_off, span_base, qmap, nq,
-                           cand_cap, span_keys, num_hits, hist);
+        hipLaunchKernelGGL((k_scan_simple<2, false>), dim3(total_spans), dim3(64), scan_simple_lds_bytes(cand_cap, 2, n_scatter, false), st, blobs, blob_off, span_base, qmap, nq,
+                           cand_cap, span_keys, num_hits, hist, 0u);
 }
 
 }  // namespace vq
@@ -2598,55 +2659,142 @@ void launch_scan_wide(hipStream_t st, uint32_t max_leaves, uint32_t max_scatter,
 // ====================================================================================================
 namespace vq {
 
-__global__ __launch_bounds__(256) void k_dict_scan(const DictProbe* __restrict__ probes) {
-    const DictProbe& P = probes[blockIdx.y];
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    __shared__ uint16_t q[64];
-    if (threadIdx.x < 64) q[threadIdx.x] = P.query[threadIdx.x];
-    __syncthreads();
-    if (t >= P.num_terms) return;
-    const uint32_t m = P.m, max_d = P.max_d;
-    const bool transposition = P.flags & 1u, prefix = P.flags & 2u;
-    const uint32_t b = P.off[t], e = P.off[t + 1];
-    const uint32_t n = e - b;
-    if (!prefix && (n > m + max_d || n + max_d < m)) return;  // length filter
-    bool match;
-    if (m == 0) {
-        match = prefix || n <= max_d;
-    } else {
-        const unsigned long long top = 1ull << (m - 1);
-        unsigned long long Pv = m == 64 ? ~0ull : ((1ull << m) - 1ull), Mv = 0ull, prevEq = 0ull, prevD0 = ~0ull;
-        uint32_t score = m;
-        uint32_t best = m;  // distance of the empty prefix
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint16_t c = P.chars[b + i];
-            unsigned long long Eq = 0ull;
-            for (uint32_t j = 0; j < m; ++j) Eq |= (unsigned long long)(q[j] == c) << j;
-            unsigned long long D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
-            if (transposition) D0 |= (((~prevD0) & Eq) << 1) & prevEq;  // Hyyrö 2003: adjacent transposition, cost one
-            unsigned long long Ph = Mv | ~(D0 | Pv);
-            unsigned long long Mh = Pv & D0;
-            if (Ph & top) ++score;
-            else if (Mh & top) --score;
-            Ph = (Ph << 1) | 1ull;
-            Mh <<= 1;
-            Pv = Mh | ~(D0 | Ph);
-            Mv = Ph & D0;
-            prevEq = Eq;
-            prevD0 = D0;
-            best = score < best ? score : best;
+// Myers / Hyyrö bit-vector recurrence over the term's code points, in 32-bit words when the pattern has <= 32 code points (half the VALU
+// work).  Whole-term matching leaves the loop as soon as the distance can no longer come back under max_d (the last row of the DP table falls
+// by at most one per text character): most terms of a dictionary are out after two or three characters.
+template <class Word>
+__device__ __forceinline__ bool dict_match(uint32_t m, uint32_t max_d, bool transposition, bool prefix, uint32_t n, const uint16_t* staged, const uint16_t* global,
+                                           const unsigned long long* peq_p, const uint16_t* q) {
+    const Word one = 1;
+    const Word top = one << (m - 1);
+    Word Pv = m == sizeof(Word) * 8 ? ~Word(0) : ((one << m) - one), Mv = 0, prevEq = 0, prevD0 = ~Word(0);
+    uint32_t score = m;
+    uint32_t best = m;  // distance of the empty prefix
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t c = staged ? staged[i] : global[i];
+        Word Eq;
+        if (c < 128u) Eq = (Word)peq_p[c];
+        else {
+            Eq = 0;
+            for (uint32_t j = 0; j < m; ++j) Eq |= (Word)(q[j] == c) << j;
         }
-        match = (prefix ? best : score) <= max_d;
+        Word D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
+        if (transposition) D0 |= (((~prevD0) & Eq) << 1) & prevEq;  // Hyyrö 2003: adjacent transposition, cost one
+        Word Ph = Mv | ~(D0 | Pv);
+        Word Mh = Pv & D0;
+        if (Ph & top) ++score;
+        else if (Mh & top) --score;
+        Ph = (Ph << 1) | one;
+        Mh <<= 1;
+        Pv = Mh | ~(D0 | Ph);
+        Mv = Ph & D0;
+        prevEq = Eq;
+        prevD0 = D0;
+        best = score < best ? score : best;
+        if (!prefix && score > max_d + (n - 1u - i)) return false;  // cannot come back under max_d
     }
-    if (match) {
-        const uint32_t pos = atomicAdd(P.out_count, 1u);
-        if (pos < P.out_cap) P.out_ids[pos] = t;
+    return (prefix ? best : score) <= max_d;
+}
+
+// Distance the reference SCORES a hit with (search_field.rs:691-732): full bit-vector recurrence of the lower-cased term (pattern, <= 64 code
+// points) over the lower-cased hit; TRANS: adjacent transpositions cost one (the scoring automaton), else plain Levenshtein (its fallback).
+template <bool TRANS>
+__device__ uint32_t dict_full_distance(const uint16_t* q, uint32_t m, const uint16_t* __restrict__ text, uint32_t n) {
+    if (m == 0) return n;
+    const unsigned long long top = 1ull << (m - 1);
+    unsigned long long Pv = m == 64 ? ~0ull : ((1ull << m) - 1ull), Mv = 0ull, prevEq = 0ull, prevD0 = ~0ull;
+    uint32_t score = m;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint16_t c = text[i];
+        unsigned long long Eq = 0ull;
+        for (uint32_t j = 0; j < m; ++j) Eq |= (unsigned long long)(q[j] == c) << j;
+        unsigned long long D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
+        if (TRANS) D0 |= (((~prevD0) & Eq) << 1) & prevEq;
+        unsigned long long Ph = Mv | ~(D0 | Pv);
+        unsigned long long Mh = Pv & D0;
+        if (Ph & top) ++score;
+        else if (Mh & top) --score;
+        Ph = (Ph << 1) | 1ull;
+        Mh <<= 1;
+        Pv = Mh | ~(D0 | Ph);
+        Mv = Ph & D0;
+        prevEq = Eq;
+        prevD0 = D0;
+    }
+    return score;
+}
+
+constexpr uint32_t kDictGroup = 16;    // probes one block answers per pass over its terms
+constexpr uint32_t kDictStage = 4096;  // code points of the block's 256 terms staged in LDS (longer stretches are read from HBM)
+
+// One block = 256 consecutive dictionary terms (their code points are one contiguous stretch of the CSR image: staged into LDS with coalesced
+// loads) x a group of kDictGroup probes.  Per probe a match-mask table Peq[c] (bit j: query[j] == c) for c < 128 lives in LDS, so the per-character
+// step of the bit-vector recurrence is one LDS read instead of an m-step compare loop; other code points take the compare loop.
+// All probes of a launch scan the same dictionary image (the host groups them).
+__global__ __launch_bounds__(256) void k_dict_scan(const DictProbe* __restrict__ probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* __restrict__ off,
+                                                   const uint16_t* __restrict__ chars, const uint16_t* __restrict__ low_chars, uint32_t num_terms,
+                                                   uint32_t* __restrict__ out_count, uint32_t out_cap, DictMatch* __restrict__ out) {
+    __shared__ unsigned long long peq[kDictGroup][128];
+    __shared__ uint16_t stage[kDictStage];
+    __shared__ uint16_t qch[kDictGroup][64];
+    __shared__ uint32_t pm[kDictGroup], pmaxd[kDictGroup], pflags[kDictGroup];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t p0 = blockIdx.y * kDictGroup;
+    const uint32_t np = n_probes - p0 < kDictGroup ? n_probes - p0 : kDictGroup;
+    const uint32_t t0 = blockIdx.x * 256u;
+    const uint32_t t_end = t0 + 256u < num_terms ? t0 + 256u : num_terms;
+    for (uint32_t x = tid; x < np * 64u; x += 256u) qch[x >> 6][x & 63u] = probes[p0 + (x >> 6)].query[x & 63u];
+    if (tid < np) {
+        pm[tid] = probes[p0 + tid].m;
+        pmaxd[tid] = probes[p0 + tid].max_d;
+        pflags[tid] = probes[p0 + tid].flags;
+    }
+    const uint32_t base = off[t0], stretch = off[t_end] - base;
+    const uint32_t staged = stretch < kDictStage ? stretch : kDictStage;
+    for (uint32_t x = tid; x < staged; x += 256u) stage[x] = chars[base + x];
+    __syncthreads();
+    for (uint32_t x = tid; x < np * 128u; x += 256u) {
+        const uint32_t p = x >> 7, c = x & 127u, m = pm[p];
+        unsigned long long mask = 0ull;
+        for (uint32_t j = 0; j < m; ++j) mask |= (unsigned long long)(qch[p][j] == c) << j;
+        peq[p][c] = mask;
+    }
+    __syncthreads();
+    const uint32_t t = t0 + tid;
+    if (t >= num_terms) return;
+    const uint32_t b = off[t] - base, e = off[t + 1] - base;
+    const uint32_t n = e - b;
+    const bool in_stage = e <= staged;
+    for (uint32_t p = 0; p < np; ++p) {  // uniform
+        const uint32_t m = pm[p], max_d = pmaxd[p];
+        const bool transposition = pflags[p] & 1u, prefix = pflags[p] & 2u;
+        if (!prefix && (n > m + max_d || n + max_d < m)) continue;  // length filter
+        bool match;
+        if (m == 0) match = prefix || n <= max_d;
+        else if (m <= 32u) match = dict_match<uint32_t>(m, max_d, transposition, prefix, n, in_stage ? stage + b : nullptr, chars + base + b, peq[p], qch[p]);
+        else match = dict_match<unsigned long long>(m, max_d, transposition, prefix, n, in_stage ? stage + b : nullptr, chars + base + b, peq[p], qch[p]);
+        if (match) {  // rare: what the hit's score needs is computed here, on the lower-cased image
+            const DictProbe& P = probes[p0 + p];
+            uint32_t info = 0;
+            const uint32_t lm = P.lm;
+            if (lm != 0xFFFFFFFFu) {
+                const uint16_t* text = low_chars + base + b;
+                const uint32_t osa = dict_full_distance<true>(P.lquery, lm, text, n), lev = dict_full_distance<false>(P.lquery, lm, text, n);
+                bool starts = n >= lm;
+                for (uint32_t i = 0; starts && i < lm; ++i) starts = text[i] == P.lquery[i];
+                info = (osa < 255u ? osa : 255u) | ((lev < 255u ? lev : 255u) << 8) | ((starts ? 1u : 0u) << 16);
+            }
+            const uint32_t pos = atomicAdd(out_count, 1u);
+            if (pos < out_cap) out[pos] = DictMatch{probe_base + p0 + p, t, info};
+        }
     }
 }
 
-void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t n_probes, uint32_t max_terms) {
-    if (!n_probes || !max_terms) return;
-    hipLaunchKernelGGL(k_dict_scan, dim3((max_terms + 255u) / 256u, n_probes), dim3(256), 0, st, d_probes);
+void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* off, const uint16_t* chars, const uint16_t* low_chars,
+                      uint32_t num_terms, uint32_t* out_count, uint32_t out_cap, DictMatch* out) {
+    if (!n_probes || !num_terms) return;
+    hipLaunchKernelGGL(k_dict_scan, dim3((num_terms + 255u) / 256u, (n_probes + kDictGroup - 1u) / kDictGroup), dim3(256), 0, st, d_probes, probe_base, n_probes, off, chars,
+                       low_chars, num_terms, out_count, out_cap, out);
 }
 
 }  // namespace vq

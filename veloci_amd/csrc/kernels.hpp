@@ -9,13 +9,14 @@
 namespace vq {
 
 struct DictProbe {  // one fuzzy / prefix scan of a dictionary (k_dict_scan)
-    const uint32_t* off;    // u32 [num_terms + 1] into chars
-    const uint16_t* chars;  // code points (raw or lower-cased image)
-    uint32_t num_terms, m, max_d, flags;  // flags: 1 transposition costs one, 2 prefix (starts_with)
-    uint32_t out_cap, pad;
-    uint32_t* out_count;
-    uint32_t* out_ids;
-    uint16_t query[64];
+    uint32_t m, max_d, flags, lm;  // flags: 1 transposition costs one, 2 prefix (starts_with); lm: code points of `lquery`, or 0xFFFFFFFF
+    uint16_t query[64];            // match side: the ORIGINAL term (lower-cased per code point when case-insensitive)
+    uint16_t lquery[64];           // scoring side: the lower-cased term (search_field.rs:298-300); lm == 0xFFFFFFFF: the host scores the matches
+};
+struct DictMatch {  // one matched dictionary term, with what its score needs (search_field.rs:304-321, 691-732)
+    uint32_t probe, term;
+    uint32_t info;  // optimal-string-alignment distance of the lower-cased hit to the lower-cased term | plain Levenshtein distance << 8 (both
+                    // capped at 255) | (lower-cased hit starts with the lower-cased term) << 16
 };
 
 struct UList {  // one input list of a union task (k_union)
@@ -41,13 +42,14 @@ struct FacetJob {
 size_t tile_scan_lds_bytes(uint32_t n_bitmaps, uint32_t n_lists, uint32_t tile_words, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, bool queue, uint32_t ml);
 
 void launch_tile_scan(hipStream_t st, uint32_t total_spans, size_t lds_bytes, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                      const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml);
+                      const uint32_t* qmap, uint32_t nq, uint32_t stack_depth, uint32_t cand_cap, uint32_t desc_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool queue, uint32_t ml,
+                      bool facet_cache = false);
 void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
                           uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
-size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter);
+size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter, bool facet_cache);
 uint32_t debug_div100_mismatches();
 void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
-                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
+                        const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool facet_cache = false);
 size_t scan_wide_lds_bytes(uint32_t cand_cap, uint32_t n_leaves, uint32_t n_scatter);
 void launch_scan_wide(hipStream_t st, uint32_t max_leaves, uint32_t max_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                       const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
@@ -63,7 +65,9 @@ void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList*
                   const uint64_t* span_off, uint32_t* out_docs, float* out_vals, uint32_t* task_min);
 void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
                        uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
-void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t n_probes, uint32_t max_terms);
+// all n_probes scan the SAME dictionary image (off / chars); matches are appended to out[0 .. out_cap) (the count keeps running beyond the cap)
+void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* off, const uint16_t* chars, const uint16_t* low_chars,
+                      uint32_t num_terms, uint32_t* out_count, uint32_t out_cap, DictMatch* out);
 
 #ifdef VQ_STAMP
 void debug_read_stamps(unsigned long long* out, int reset);
