@@ -628,6 +628,53 @@ def test_bench_jmdict_request_shape_matches_the_oracle():
     assert ran >= 16, ran
 
 
+def test_text_locality_on_multi_valued_text_fields_device_prepass():
+    """A9 / K7 on the device: text locality of fields whose text ids are NOT anchors (boost.rs:34-87) — 1:n text fields whose texts repeat
+    across documents (one text id -> many anchors), terms matching many tokens (prefix / fuzzy: long token -> text rows, counts c > 2), two
+    such fields in one request (the smallest boost per anchor wins, boost.rs:25), single / batched / two doc-range shards; 30 000 documents,
+    far beyond what the old host path's tests covered."""
+    import veloci_amd
+    from veloci_amd import mini_indexer
+    from oracle import binding as O
+    from parity import assert_same
+    rng = np.random.default_rng(9)
+    words = ["alpha", "alpine", "alps", "beta", "betal", "gamma", "gamut", "delta", "deltoid", "omega", "omen", "river", "rival", "stone", "story", "storm"]
+    phrases = [" ".join(rng.choice(words, int(rng.integers(2, 5)))) for _ in range(400)]  # texts repeat across documents
+    notes = [" ".join(rng.choice(words, int(rng.integers(2, 6)))) for _ in range(3000)]
+    docs = []
+    for d in range(30_000):
+        doc = {"title": str(rng.choice(phrases)), "lines": [{"text": str(rng.choice(phrases))} for _ in range(int(rng.integers(1, 4)))],
+               "notes": [str(rng.choice(notes)) for _ in range(int(rng.integers(0, 3)))]}
+        if not doc["notes"]:
+            del doc["notes"]
+        docs.append(doc)
+    indices = {"title": {"fulltext": {"tokenize": True}}, "lines[].text": {"fulltext": {"tokenize": True}}, "notes[]": {"fulltext": {"tokenize": True}}}
+    data, info = mini_indexer.build_index(docs, indices)
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    leaf = lambda path, t, **kw: {"search": dict({"path": path, "terms": [t]}, **kw)}
+    reqs = []
+    for path in ("lines[].text", "notes[]", "title"):
+        for a, b in (("alpha", "beta"), ("gamma", "delta"), ("river", "stone"), ("omega", "storm")):
+            reqs.append({"search_req": {"or": {"queries": [leaf(path, a), leaf(path, b)]}}, "text_locality": True, "top": 20})
+            reqs.append({"search_req": {"and": {"queries": [leaf(path, a), leaf(path, b)]}}, "text_locality": True, "top": 20})
+        reqs.append({"search_req": {"or": {"queries": [leaf(path, "al", starts_with=True), leaf(path, "st", starts_with=True), leaf(path, "delta", levenshtein_distance=1)]}},
+                     "text_locality": True, "top": 30})
+    reqs.append({"search_req": {"or": {"queries": [leaf("lines[].text", "alpha"), leaf("lines[].text", "beta"), leaf("notes[]", "alpha"), leaf("notes[]", "beta"),
+                                                   leaf("title", "alpha"), leaf("title", "beta")]}}, "text_locality": True, "top": 50})
+    reqs.append({"search_req": {"or": {"queries": [leaf("lines[].text", "gamma"), leaf("lines[].text", "gamma"), leaf("lines[].text", "omen")]}}, "text_locality": True})
+    wants = [ora.search_json(json.dumps(r)) for r in reqs]
+    assert sum(w.num_hits > 100 for w in wants) > len(wants) // 2
+    for r, w in zip(reqs, wants):
+        assert_same(r, veloci_amd.search(r, idx), w)
+    for r, g, w in zip(reqs * 4, veloci_amd.search_batch(reqs * 4, idx), wants * 4):
+        assert_same(r, g, w)
+    for r, g, w in zip(reqs, _search_batch_over_shards(data, reqs, 2), wants):
+        assert not isinstance(g, Exception), (str(g), json.dumps(r))
+        assert_same(r, g, w)
+
+
 def test_random_requests_in_batches_match_the_oracle():
     """The same generator through vq_search_batch: dictionary scans, union jobs and count pre-passes of many requests share one batch."""
     import veloci_amd

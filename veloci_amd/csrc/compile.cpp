@@ -159,6 +159,7 @@ struct Compiler {
     const FuzzyTable* fuzzy = nullptr;
     const UnionTable* unions = nullptr;
     const RangeTable* ranges = nullptr;
+    const LocalityTable* localities = nullptr;
     Boost1nCache* boost_cache = nullptr;
     const QueryCounts* counts = nullptr;
     uint32_t next_node = 0;
@@ -1504,47 +1505,38 @@ struct Compiler {
                 if (terms.size() <= 1) continue;  // boost.rs:36-39
                 const KVStore& t2t = kv_store(path + TOKENS_TO_TEXT_ID);
                 if (!idx.is_anchor_identity(path)) {
-                    // Text ids are not anchors (boost.rs:72-83): count the texts on the host copy of the small side tables,
-                    // hand the kernel one (anchor, 2*c*c) list per field.  Bounded: long token->text rows are declined.
-                    static const size_t cap = std::getenv("VQ_LOCALITY_HOST_MAX") ? size_t(std::atoll(std::getenv("VQ_LOCALITY_HOST_MAX"))) : (size_t(1) << 22);
-                    std::vector<uint32_t> all;
-                    for (auto& [term, ids] : terms)
-                        for (uint32_t id : ids) {
-                            const uint32_t *rb, *re;
-                            if (t2t.host_row(id, &rb, &re)) all.insert(all.end(), rb, re);
-                            if (all.size() > cap) unsupported("text_locality on a non-identity field with more than " + std::to_string(cap) + " token->text entries");
-                        }
-                    std::sort(all.begin(), all.end());
+                    // Text ids are not anchors (boost.rs:72-83): the K7 pre-pass (run_locality_jobs) gathers the terms' token -> text rows, counts
+                    // the texts, expands them to anchors and hands back one (anchor, smallest 2*c*c) list for the field
                     const KVStore& t2a = kv_store(path + TEXT_ID_TO_ANCHOR);
-                    std::vector<std::pair<uint32_t, float>> pairs;
-                    for (size_t i = 0; i < all.size();) {
-                        size_t j = i;
-                        while (j < all.size() && all[j] == all[i]) ++j;
-                        const size_t c = j - i;  // counts list entries, not distinct terms (:51-56)
-                        if (c > 1) {
-                            const uint32_t *rb, *re;
-                            if (t2a.host_row(all[i], &rb, &re))
-                                for (const uint32_t* p = rb; p != re; ++p) pairs.push_back({*p, 2.0f * float(c) * float(c)});
+                    if (!t2t.text_csr || !t2a.d_row_len.p) unsupported("text_locality: " + path + " is not staged for the device pre-pass");
+                    LocalityJob job;
+                    job.t2t_path = path + TOKENS_TO_TEXT_ID;
+                    job.t2a_path = path + TEXT_ID_TO_ANCHOR;
+                    job.key = "loc|" + path;
+                    for (auto& [term, ids] : terms) {
+                        job.key += "|";
+                        for (uint32_t id : ids) {
+                            job.tokens.push_back(id);
+                            job.key += std::to_string(id) + ",";
                         }
-                        i = j;
                     }
-                    std::sort(pairs.begin(), pairs.end());  // by anchor, then value: the first entry of an anchor is its minimum (:25)
-                    std::vector<uint32_t> docs;
-                    std::vector<float> vals;
-                    for (auto& pr : pairs)
-                        if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi && (docs.empty() || docs.back() != pr.first)) {
-                            docs.push_back(pr.first);
-                            vals.push_back(pr.second);
-                        }
+                    const LocalityJob* done = nullptr;
+                    if (localities) {
+                        auto it = localities->find(job.key);
+                        if (it != localities->end()) done = &it->second;
+                    }
+                    if (!done) {
+                        cq.locality_requests.push_back(std::move(job));  // compiled again after the job ran
+                        continue;
+                    }
+                    if (!done->len) continue;  // no text holds two of the terms' tokens (in this shard)
                     HList h;
-                    h.len = uint32_t(docs.size());
-                    h.global_len = docs.size();
+                    h.d_docs = done->d_docs;
+                    h.d_scores = reinterpret_cast<const uint16_t*>(done->d_vals);
+                    h.len = done->len;
+                    h.global_len = done->len;
                     h.flags = LIST_HAS_SCORES | LIST_F32;
                     h.term_score = 1.0f;
-                    h.inline_idx = int(cq.inline_lists.size());
-                    h.inline_val_idx = int(cq.inline_vals.size());
-                    cq.inline_lists.push_back(std::move(docs));
-                    cq.inline_vals.push_back(std::move(vals));
                     DLocField lf{};
                     lf.list_begin = uint16_t(add_list(h));
                     lf.list_count = kLocPrecomputed;
@@ -1894,9 +1886,10 @@ void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& tabl
 }
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts,
-                            const RangeTable* ranges, Boost1nCache* boost_cache) {
+                            const RangeTable* ranges, Boost1nCache* boost_cache, const LocalityTable* localities) {
     Compiler c(idx, req, fuzzy);
     c.boost_cache = boost_cache;
+    c.localities = localities;
     c.unions = unions;
     c.counts = counts;
     c.ranges = ranges;
@@ -1905,7 +1898,7 @@ CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const F
         if (!c.cq.range_requests.empty()) {
             c.cq.status = kStatusNeedsRanges;
             c.cq.error = "internal: range jobs pending";
-        } else if (!c.cq.union_requests.empty()) {
+        } else if (!c.cq.union_requests.empty() || !c.cq.locality_requests.empty()) {
             c.cq.status = kStatusNeedsUnion;
             c.cq.error = "internal: union jobs pending";
         } else if (c.cq.n_counts) {

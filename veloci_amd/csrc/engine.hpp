@@ -179,7 +179,20 @@ struct Boost1nCache {
     std::mutex mu;
     std::unordered_map<std::string, std::shared_ptr<const std::vector<std::pair<uint32_t, float>>>> map;
 };
-constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union jobs have run
+// Text locality of a field whose text ids are not anchors (boost.rs:34-87), resolved before the final compilation by the K7 pre-pass: the
+// token -> text rows of the query's terms are gathered and sorted, texts occurring c > 1 times are expanded to their anchors with the boost
+// 2*c*c, the (anchor, boost) pairs are sorted and the smallest boost of every anchor is kept (the reference's reversed max_by, boost.rs:25).
+struct LocalityJob {
+    std::string key;
+    std::string t2t_path, t2a_path;                   // "<field>.textindex.tokens_to_text_id" / ".text_id_to_anchor"
+    std::vector<uint32_t> tokens;                     // token ids of all terms (multiplicity kept: the count is over list entries, boost.rs:51-56)
+    // result (valid until the batch that ran it is finished; lives in the batch workspace)
+    const uint32_t* d_docs = nullptr;
+    const float* d_vals = nullptr;
+    uint32_t len = 0;
+};
+using LocalityTable = std::map<std::string, LocalityJob>;
+constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union / locality jobs have run
 constexpr int kStatusNeedsCounts = -2; // internal: the compiled query IS a count pre-pass; compile again with its results
 constexpr int kStatusNeedsRanges = -3; // internal: compile again once the requested range jobs have run
 
@@ -218,6 +231,11 @@ struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device ima
     std::vector<uint64_t> start;  // first entry of row r inside `values` (multiple of 4)
     std::vector<uint32_t> len;    // entries of row r inside this shard
     DevBuf values;
+    DevBuf d_row_start, d_row_len;  // text_id_to_anchor: `start` / `len` on the device (u64 / u32 per row) — text locality expands text ids there (K7)
+    // text use: tokens_to_text_id of a field whose text ids are NOT anchors: the whole table as a CSR in HBM (values are text ids: replicated
+    // on every shard like the dictionary), read by the text-locality pre-pass (K7)
+    bool text_csr = false;
+    DevBuf d_text_vals;  // u32, host_values as handed over (row r = [host_off[r], host_off[r + 1]))
     // facet use: keys are anchors -> CSR restricted to the shard's anchors
     bool facet_csr = false;
     uint32_t csr_key_base = 0, csr_num_keys = 0;
@@ -299,6 +317,7 @@ struct Workspace {  // scratch of one in-flight batch
     DevBuf d_partial;
     DevBuf d_down;      // results
     DevBuf d_union_docs[2], d_union_vals[2], d_union_max, d_union_meta;  // materialised leaves (k_union), level 1 / level 2
+    DevBuf d_loc_a, d_loc_b, d_loc_pairs_a, d_loc_pairs_b, d_loc_meta, d_loc_tmp, d_loc_docs, d_loc_vals;  // text locality pre-pass (K7)
     DevBuf d_probe_desc, d_probe_counts, d_probe_ids;                    // dictionary scans (k_dict_scan): kept, so that no hipFree synchronises the device mid-pipeline
 };
 
@@ -416,6 +435,7 @@ struct CompiledQuery {
     std::string error;
     std::vector<RangeJob> range_requests;  // status == kStatusNeedsRanges
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
+    std::vector<LocalityJob> locality_requests;  // likewise (K7)
     std::vector<uint32_t> count_nodes;     // status == kStatusNeedsCounts: node ids; counters 2i / 2i+1 = hits / hits inside the filter, then the filter
     uint32_t n_counts = 0;
     std::vector<HList> lists;
@@ -453,7 +473,9 @@ struct CompiledQuery {
 };
 
 CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy = nullptr, const UnionTable* unions = nullptr,
-                            const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr, Boost1nCache* boost_cache = nullptr);
+                            const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr, Boost1nCache* boost_cache = nullptr,
+                            const LocalityTable* localities = nullptr);
+void run_locality_jobs(const Index& idx, Workspace& ws, LocalityTable& table, hipStream_t st);
 void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 struct Result;

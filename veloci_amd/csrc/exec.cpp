@@ -535,6 +535,138 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
     }
 }
 
+// K7: text locality of fields whose text ids are not anchors, for every (request, field) job of the batch (see kernels.hip, k_loc_*).
+void run_locality_jobs(const Index& idx, Workspace& ws, LocalityTable& table, hipStream_t st) {
+    std::vector<LocalityJob*> jobs;
+    for (auto& kv : table) jobs.push_back(&kv.second);
+    if (jobs.empty()) return;
+    // all jobs of one table next to each other: one gather launch per tokens_to_text_id table
+    std::stable_sort(jobs.begin(), jobs.end(), [](const LocalityJob* a, const LocalityJob* b) { return a->t2t_path < b->t2t_path; });
+    const size_t nj = jobs.size();
+    std::vector<LocJob> dj(nj);
+    std::vector<LocRow> rows;
+    std::vector<std::pair<size_t, size_t>> table_rows;  // per run of jobs over one table: [first row, end row)
+    uint64_t cursor = 0;
+    for (size_t j = 0; j < nj; ++j) {
+        const KVStore& t2t = idx.kv.at(jobs[j]->t2t_path);
+        const KVStore& t2a = idx.kv.at(jobs[j]->t2a_path);
+        if (j == 0 || jobs[j]->t2t_path != jobs[j - 1]->t2t_path) table_rows.push_back({rows.size(), rows.size()});
+        LocJob& J = dj[j];
+        std::memset(&J, 0, sizeof J);
+        J.t2a_vals = t2a.values.as<uint32_t>();
+        J.t2a_start = t2a.d_row_start.as<uint64_t>();
+        J.t2a_len = t2a.d_row_len.as<uint32_t>();
+        J.t2a_key_base = t2a.key_base;
+        J.t2a_num_keys = t2a.num_keys;
+        J.seg_begin = uint32_t(cursor);
+        for (uint32_t id : jobs[j]->tokens) {
+            if (id < t2t.key_base || id - t2t.key_base >= t2t.num_keys) continue;
+            const uint32_t r = id - t2t.key_base;
+            uint64_t src = t2t.host_off[r], left = t2t.host_off[r + 1] - t2t.host_off[r];
+            while (left) {  // long rows in pieces: one workgroup copies one piece
+                const uint32_t piece = uint32_t(std::min<uint64_t>(left, 65536));
+                rows.push_back(LocRow{src, cursor, piece, 0u});
+                src += piece;
+                cursor += piece;
+                left -= piece;
+            }
+        }
+        if (cursor > 0xFFFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "text_locality: more than 2^32 token->text entries in one batch");
+        J.seg_end = uint32_t(cursor);
+        table_rows.back().second = rows.size();
+    }
+    const uint32_t E = uint32_t(cursor);
+    for (auto* j : jobs) {
+        j->d_docs = nullptr;
+        j->d_vals = nullptr;
+        j->len = 0;
+    }
+    if (!E) return;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    // meta: [jobs][rows][seg_begin u32][seg_end u32][counters u32][pair_begin u32][pair_end u32][out_len u32]
+    const size_t o_jobs = 0, o_rows = al(nj * sizeof(LocJob)), o_sb = o_rows + al(rows.size() * sizeof(LocRow)), o_se = o_sb + al(nj * 4), o_cnt = o_se + al(nj * 4),
+                 o_pb = o_cnt + al(nj * 4), o_pe = o_pb + al(nj * 4), o_len = o_pe + al(nj * 4), meta_bytes = o_len + al(nj * 4);
+    ws.d_loc_meta.ensure(meta_bytes);
+    uint8_t* m = ws.d_loc_meta.as<uint8_t>();
+    std::vector<uint32_t> sb(nj), se(nj);
+    for (size_t j = 0; j < nj; ++j) {
+        sb[j] = dj[j].seg_begin;
+        se[j] = dj[j].seg_end;
+    }
+    ws.d_loc_a.ensure(size_t(E) * 4 + 16);
+    ws.d_loc_b.ensure(size_t(E) * 4 + 16);
+    LaunchTimer timer(idx.profile.enabled, ws, st, K_LOCALITY, size_t(E) * 16, size_t(E) * 4, nj);
+    VQ_HIP(hipMemcpyAsync(m + o_jobs, dj.data(), nj * sizeof(LocJob), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_rows, rows.data(), rows.size() * sizeof(LocRow), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_sb, sb.data(), nj * 4, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_se, se.data(), nj * 4, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemsetAsync(m + o_cnt, 0, nj * 4, st));
+    {
+        size_t tr = 0;
+        for (size_t j = 0; j < nj; ++j)
+            if (j == 0 || jobs[j]->t2t_path != jobs[j - 1]->t2t_path) {
+                const KVStore& t2t = idx.kv.at(jobs[j]->t2t_path);
+                const auto [r0, r1] = table_rows[tr++];
+                launch_loc_gather(st, reinterpret_cast<const LocRow*>(m + o_rows) + r0, uint32_t(r1 - r0), t2t.d_text_vals.as<uint32_t>(), ws.d_loc_a.as<uint32_t>());
+            }
+    }
+    VQ_HIP(hipGetLastError());
+    auto sort32 = [&](const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* b, const uint32_t* e) {
+        const size_t need = seg_sort_u32(nullptr, 0, in, out, n, uint32_t(nj), b, e, st);
+        if (need == size_t(-1)) throw VelociError(ERR_DEVICE, "segmented radix sort failed (size query)");
+        ws.d_loc_tmp.ensure(need + 256);
+        if (seg_sort_u32(ws.d_loc_tmp.p, need, in, out, n, uint32_t(nj), b, e, st) == size_t(-1)) throw VelociError(ERR_DEVICE, "segmented radix sort failed");
+    };
+    sort32(ws.d_loc_a.as<uint32_t>(), ws.d_loc_b.as<uint32_t>(), E, reinterpret_cast<const uint32_t*>(m + o_sb), reinterpret_cast<const uint32_t*>(m + o_se));
+    // count pass: (anchor, boost) pairs per job
+    launch_loc_expand(st, false, reinterpret_cast<const LocJob*>(m + o_jobs), uint32_t(nj), ws.d_loc_b.as<uint32_t>(), E, reinterpret_cast<uint32_t*>(m + o_cnt), nullptr);
+    VQ_HIP(hipGetLastError());
+    std::vector<uint32_t> totals(nj);
+    VQ_HIP(hipMemcpyAsync(totals.data(), m + o_cnt, nj * 4, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    uint64_t P = 0, out_cursor = 0;
+    std::vector<uint32_t> pb(nj), pe(nj);
+    for (size_t j = 0; j < nj; ++j) {
+        dj[j].pair_begin = pb[j] = uint32_t(P);
+        P += totals[j];
+        if (P > 0xFFFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "text_locality: more than 2^32 (anchor, boost) pairs in one batch");
+        dj[j].pair_end = pe[j] = uint32_t(P);
+        dj[j].out_off = uint32_t(out_cursor);
+        out_cursor += (uint64_t(totals[j]) + 8 + 3) / 4 * 4;  // 8 sentinel entries behind every list, starts stay 16-byte aligned
+    }
+    ws.d_loc_docs.ensure(out_cursor * 4 + 64);
+    ws.d_loc_vals.ensure(out_cursor * 4 + 64);
+    if (P) {
+        ws.d_loc_pairs_a.ensure(P * 8 + 16);
+        ws.d_loc_pairs_b.ensure(P * 8 + 16);
+        VQ_HIP(hipMemcpyAsync(m + o_jobs, dj.data(), nj * sizeof(LocJob), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(m + o_pb, pb.data(), nj * 4, hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(m + o_pe, pe.data(), nj * 4, hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemsetAsync(m + o_cnt, 0, nj * 4, st));
+        launch_loc_expand(st, true, reinterpret_cast<const LocJob*>(m + o_jobs), uint32_t(nj), ws.d_loc_b.as<uint32_t>(), E, reinterpret_cast<uint32_t*>(m + o_cnt),
+                          ws.d_loc_pairs_a.as<unsigned long long>());
+        VQ_HIP(hipGetLastError());
+        const size_t need = seg_sort_u64(nullptr, 0, ws.d_loc_pairs_a.as<unsigned long long>(), ws.d_loc_pairs_b.as<unsigned long long>(), uint32_t(P), uint32_t(nj),
+                                         reinterpret_cast<const uint32_t*>(m + o_pb), reinterpret_cast<const uint32_t*>(m + o_pe), st);
+        if (need == size_t(-1)) throw VelociError(ERR_DEVICE, "segmented radix sort failed (size query)");
+        ws.d_loc_tmp.ensure(need + 256);
+        if (seg_sort_u64(ws.d_loc_tmp.p, need, ws.d_loc_pairs_a.as<unsigned long long>(), ws.d_loc_pairs_b.as<unsigned long long>(), uint32_t(P), uint32_t(nj),
+                         reinterpret_cast<const uint32_t*>(m + o_pb), reinterpret_cast<const uint32_t*>(m + o_pe), st) == size_t(-1))
+            throw VelociError(ERR_DEVICE, "segmented radix sort failed");
+    } else VQ_HIP(hipMemcpyAsync(m + o_jobs, dj.data(), nj * sizeof(LocJob), hipMemcpyHostToDevice, st));
+    launch_loc_compact(st, reinterpret_cast<const LocJob*>(m + o_jobs), uint32_t(nj), ws.d_loc_pairs_b.as<unsigned long long>(), ws.d_loc_docs.as<uint32_t>(),
+                       ws.d_loc_vals.as<float>(), reinterpret_cast<uint32_t*>(m + o_len));
+    VQ_HIP(hipGetLastError());
+    std::vector<uint32_t> lens(nj);
+    VQ_HIP(hipMemcpyAsync(lens.data(), m + o_len, nj * 4, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    for (size_t j = 0; j < nj; ++j) {
+        jobs[j]->d_docs = ws.d_loc_docs.as<uint32_t>() + dj[j].out_off;
+        jobs[j]->d_vals = ws.d_loc_vals.as<float>() + dj[j].out_off;
+        jobs[j]->len = lens[j];
+    }
+}
+
 // Count pre-pass: launches k_tile_scan in count mode for queries whose AND operands' result sizes the compiler needs
 // (set_op.rs:388-393,439) and returns them per query.  Presence only: no scores are read.
 static void run_count_queries(const Index& idx, Workspace& ws, const std::vector<CompiledQuery*>& cqs, std::vector<QueryCounts>& out, hipStream_t st) {
@@ -644,12 +776,14 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch
     UnionTable unions;
     RangeTable ranges;
+    LocalityTable localities;
     std::vector<size_t> again;
     bool any_ranges = false;
     for (size_t i = 0; i < n; ++i)
         if (pb->queries[i].status == kStatusNeedsUnion || pb->queries[i].status == kStatusNeedsRanges) {
             again.push_back(i);
             for (auto& j : pb->queries[i].union_requests) unions.emplace(j.key, j);
+            for (auto& j : pb->queries[i].locality_requests) localities.emplace(j.key, j);
             for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
             any_ranges = any_ranges || pb->queries[i].status == kStatusNeedsRanges;
         }
@@ -664,6 +798,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             size_t k = 0;
             for (auto& kv : unions) kv.second.global_len = lens[k++];
         }
+        if (!localities.empty()) run_locality_jobs(idx, ws, localities, pst);
         t_unions = t_ranges = now_ms();
         // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits,
         //      on the merged list of a materialised leaf)
@@ -678,7 +813,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                     q.error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
                     continue;
                 }
-                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, nullptr, ranges.empty() ? nullptr : &ranges, &boost_cache);
+                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, nullptr, ranges.empty() ? nullptr : &ranges, &boost_cache,
+                                  localities.empty() ? nullptr : &localities);
                 if (q.status == kStatusNeedsUnion || q.status == kStatusNeedsRanges) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
@@ -724,7 +860,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             }
             for (size_t k = 0; k < need.size(); ++k) {
                 CompiledQuery& q = pb->queries[need[k]];
-                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k], rangesp, &boost_cache);
+                q = compile_query(idx, *reqs[need[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, &counts[k], rangesp, &boost_cache,
+                                  localities.empty() ? nullptr : &localities);
                 if (q.status < 0) {
                     q.status = ERR_UNSUPPORTED;
                     q.error = "unsupported on the MI355X query path: query still needs a pre-pass after the count pre-pass (internal)";

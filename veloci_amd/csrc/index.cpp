@@ -276,6 +276,19 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             s.values.alloc(vals.size() * 4 + 16);
             s.values.upload(vals.data(), vals.size() * 4);
             idx->device_bytes += s.values.bytes;
+            if (ends_with(path, TEXT_ID_TO_ANCHOR)) {  // row table on the device: the text-locality pre-pass (K7) expands text ids to anchors there
+                s.d_row_start.alloc(s.start.size() * 8 + 16);
+                s.d_row_start.upload(s.start.data(), s.start.size() * 8);
+                s.d_row_len.alloc(s.len.size() * 4 + 16);
+                s.d_row_len.upload(s.len.data(), s.len.size() * 4);
+                idx->device_bytes += s.d_row_start.bytes + s.d_row_len.bytes;
+            }
+        }
+        if (ends_with(path, TOKENS_TO_TEXT_ID) && !identity_t2t) {  // text ids are not anchors: the table itself goes to HBM for K7
+            s.text_csr = true;
+            s.d_text_vals.alloc(k.values.size() * 4 + 16);
+            s.d_text_vals.upload(k.values.data(), k.values.size() * 4);
+            idx->device_bytes += s.d_text_vals.bytes;
         }
         // facet sources: anchor-keyed value lists (facet.rs:38-44)
         s.facet_csr = ends_with(path, ANCHOR_TO_TEXT_ID) || (ends_with(path, PARENT_TO_VALUE_ID) && path.find("[]") == std::string::npos);

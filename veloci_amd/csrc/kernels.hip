@@ -2800,6 +2800,104 @@ void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t probe_
 }  // namespace vq
 
 // ====================================================================================================
+// Text locality of a field whose text ids are not anchors (K7, boost.rs:34-87), as a pre-pass over the batch's (request, field) jobs:
+//   k_loc_gather   the token -> text rows of every query term, copied into one buffer (a job = one contiguous slice)
+//   [segmented radix sort of the text ids]
+//   k_loc_expand   a text id occurring c > 1 times in its job's slice (c counts list entries, boost.rs:51-56) is expanded through
+//                  text_id_to_anchor: one (anchor << 32 | f32 bits of 2*c*c) pair per anchor (count pass, then write pass)
+//   [segmented radix sort of the pairs: by anchor, then by boost]
+//   k_loc_compact  the first pair of every anchor — its smallest boost, which is what the reference's reversed max_by keeps (boost.rs:25) —
+//                  goes to the job's (doc, f32) list, padded like a materialised leaf; the scan kernels read it as a LIST_F32 id list
+// ====================================================================================================
+namespace vq {
+
+__global__ __launch_bounds__(256) void k_loc_gather(const LocRow* __restrict__ rows, const uint32_t* __restrict__ table, uint32_t* __restrict__ gathered) {
+    const LocRow r = rows[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < r.len; i += 256u) gathered[r.dst + i] = table[r.src + i];
+}
+void launch_loc_gather(hipStream_t st, const LocRow* rows, uint32_t n_rows, const uint32_t* table, uint32_t* gathered) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_loc_gather, dim3(n_rows), dim3(256), 0, st, rows, table, gathered);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_loc_expand(const LocJob* __restrict__ jobs, uint32_t n_jobs, const uint32_t* __restrict__ ids, uint32_t n,
+                                                    uint32_t* __restrict__ counters, unsigned long long* __restrict__ pairs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = n_jobs;  // the job whose slice holds element i (slices are consecutive, in job order)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].seg_begin <= i) lo = mid;
+        else hi = mid;
+    }
+    const LocJob J = jobs[lo];
+    if (i >= J.seg_end) return;
+    const uint32_t t = ids[i];
+    if (i + 1 < J.seg_end && ids[i + 1] == t) return;  // not the last entry of its run
+    uint32_t a = J.seg_begin, b = i;                    // first entry of the run: lower bound of t inside [seg_begin, i]
+    while (a < b) {
+        const uint32_t mid = a + ((b - a) >> 1);
+        if (ids[mid] < t) a = mid + 1;
+        else b = mid;
+    }
+    const uint32_t c = i - a + 1u;
+    if (c <= 1u) return;
+    if (t < J.t2a_key_base || t - J.t2a_key_base >= J.t2a_num_keys) return;
+    const uint32_t row = t - J.t2a_key_base;
+    const uint32_t len = J.t2a_len[row];
+    if (!len) return;
+    const uint32_t at = atomicAdd(&counters[lo], len);
+    if (WRITE) {
+        const float boost = 2.0f * (float)c * (float)c;  // boost.rs:70,80
+        const unsigned long long low = (unsigned long long)__float_as_uint(boost);
+        const uint32_t* anchors = J.t2a_vals + J.t2a_start[row];
+        for (uint32_t e = 0; e < len; ++e) pairs[(size_t)J.pair_begin + at + e] = ((unsigned long long)anchors[e] << 32) | low;
+    }
+}
+void launch_loc_expand(hipStream_t st, bool write, const LocJob* jobs, uint32_t n_jobs, const uint32_t* sorted_text_ids, uint32_t n, uint32_t* counters,
+                       unsigned long long* pairs) {
+    if (!n || !n_jobs) return;
+    if (write) hipLaunchKernelGGL(k_loc_expand<true>, dim3((n + 255u) / 256u), dim3(256), 0, st, jobs, n_jobs, sorted_text_ids, n, counters, pairs);
+    else hipLaunchKernelGGL(k_loc_expand<false>, dim3((n + 255u) / 256u), dim3(256), 0, st, jobs, n_jobs, sorted_text_ids, n, counters, pairs);
+}
+
+// one wave per job: an ordered compaction of its sorted pairs
+__global__ __launch_bounds__(64) void k_loc_compact(const LocJob* __restrict__ jobs, const unsigned long long* __restrict__ sorted, uint32_t* __restrict__ out_docs,
+                                                    float* __restrict__ out_vals, uint32_t* __restrict__ out_len) {
+    const LocJob J = jobs[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    uint32_t written = 0;
+    for (uint32_t base = J.pair_begin; base < J.pair_end; base += 64u) {  // uniform
+        const uint32_t i = base + lane;
+        bool keep = false;
+        unsigned long long p = 0ull;
+        if (i < J.pair_end) {
+            p = sorted[i];
+            keep = i == J.pair_begin || (uint32_t)(sorted[i - 1] >> 32) != (uint32_t)(p >> 32);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const uint32_t pos = J.out_off + written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            out_docs[pos] = (uint32_t)(p >> 32);
+            out_vals[pos] = __uint_as_float((uint32_t)p);
+        }
+        written += (uint32_t)__popcll(m);
+    }
+    if (lane < 8u) {  // list padding: sentinel docs up to the vector width and beyond
+        out_docs[J.out_off + written + lane] = 0xFFFFFFFFu;
+        out_vals[J.out_off + written + lane] = 0.0f;
+    }
+    if (lane == 0) out_len[blockIdx.x] = written;
+}
+void launch_loc_compact(hipStream_t st, const LocJob* jobs, uint32_t n_jobs, const unsigned long long* sorted_pairs, uint32_t* out_docs, float* out_vals, uint32_t* out_len) {
+    if (!n_jobs) return;
+    hipLaunchKernelGGL(k_loc_compact, dim3(n_jobs), dim3(64), 0, st, jobs, sorted_pairs, out_docs, out_vals, out_len);
+}
+
+}  // namespace vq
+
+// ====================================================================================================
 // k_union (K2) — multi-list union with per-doc max: materialises the hits of a leaf whose dictionary
 // expansion matched many terms (resolve_token_to_anchor, search_field.rs:419-464: every posting becomes
 // Hit(doc, term_score * (f16 / 100)), then sort by doc and dedup keeping the max).  One wave per span of the

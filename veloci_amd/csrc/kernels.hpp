@@ -69,6 +69,29 @@ void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const
 void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* off, const uint16_t* chars, const uint16_t* low_chars,
                       uint32_t num_terms, uint32_t* out_count, uint32_t out_cap, DictMatch* out);
 
+// ---- text locality pre-pass (K7)
+struct LocRow {  // copy table[src .. src + len) to the gather buffer at dst
+    uint64_t src, dst;
+    uint32_t len, pad;
+};
+struct LocJob {  // one (request, field): its slice [seg_begin, seg_end) of the gathered text ids, its text_id_to_anchor rows, its output ranges
+    const uint32_t* t2a_vals;
+    const uint64_t* t2a_start;
+    const uint32_t* t2a_len;
+    uint32_t t2a_key_base, t2a_num_keys;
+    uint32_t seg_begin, seg_end;
+    uint32_t pair_begin, pair_end;  // slice of the (anchor, boost) pair buffer (known after the count pass)
+    uint32_t out_off, pad;          // first entry of the job's result inside the output arrays
+};
+void launch_loc_gather(hipStream_t st, const LocRow* rows, uint32_t n_rows, const uint32_t* table, uint32_t* gathered);
+void launch_loc_expand(hipStream_t st, bool write, const LocJob* jobs, uint32_t n_jobs, const uint32_t* sorted_text_ids, uint32_t n, uint32_t* totals_or_cursors,
+                       unsigned long long* pairs);
+void launch_loc_compact(hipStream_t st, const LocJob* jobs, uint32_t n_jobs, const unsigned long long* sorted_pairs, uint32_t* out_docs, float* out_vals, uint32_t* out_len);
+size_t seg_sort_u32(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t nseg, const uint32_t* seg_begin, const uint32_t* seg_end,
+                    hipStream_t st);
+size_t seg_sort_u64(void* tmp, size_t tmp_bytes, const unsigned long long* in, unsigned long long* out, uint32_t n, uint32_t nseg, const uint32_t* seg_begin,
+                    const uint32_t* seg_end, hipStream_t st);
+
 #ifdef VQ_STAMP
 void debug_read_stamps(unsigned long long* out, int reset);
 #endif
