@@ -37,8 +37,7 @@ enum {
     VQ_ERR_FST_NOT_FOUND = 2,
     /* VelociError::StringError("Did not found path in indices ...") (src/persistence.rs:454-458) */
     VQ_ERR_INDEX_NOT_FOUND = 3,
-    /* request uses a feature outside the GPU hot path (select, why_found, snippet, regex, suggest,
-       explain): never silently ignored */
+    /* request uses a feature outside the GPU hot path (select, why_found_info, snippet, explain ...): never silently ignored */
     VQ_ERR_UNSUPPORTED = 4,
     /* HIP runtime failure / no device / extension missing */
     VQ_ERR_DEVICE = 5,
@@ -163,9 +162,28 @@ const char* vq_result_facet_field(const vq_result*, size_t facet);
 size_t vq_result_facet_len(const vq_result*, size_t facet);
 const char* vq_result_facet_value(const vq_result*, size_t facet, size_t i);
 uint64_t vq_result_facet_count(const vq_result*, size_t facet, size_t i);
-/* serde_json rendering of the SearchResult (ids/scores/facets), for diffing. */
+/* serde_json rendering of the SearchResult (ids/scores/facets/why_found_terms), for diffing. */
 const char* vq_result_to_json(const vq_result*);
+/* `SearchResult.why_found_terms` (src/search/result/search_result.rs:21-25, filled at src/search.rs:186 when the request says
+ * `why_found: true`): per text index path the matched dictionary terms, as JSON {"<path>": ["term", ...]} (thread-local string;
+ * the reference's map and list orders are unspecified).  `why_found` together with `select` (why_found_info: highlighting of the
+ * returned documents) is declined. */
+const char* vq_result_why_found_terms_json(const vq_result*);
 void vq_result_free(vq_result*);
+
+/* ---------------------------------------------------------------- suggest
+ *
+ * == search_field::suggest_multi(persistence, request) (src/search/search_field.rs:194-219) when `json` is a Request with
+ * "suggest": [RequestSearchPart, ...] (+ top / skip), == search_field::suggest(persistence, &part) (:221-231) when it is a bare
+ * RequestSearchPart.  Dictionary side only: the matched terms of every part (fuzzy / prefix scans run on the device, regex leaves on
+ * the host), lower-cased texts, equal texts merged keeping the best score, ranked by score.  SuggestFieldResult = Vec<(String, Score, TermId)>. */
+typedef struct vq_suggest_result vq_suggest_result;
+int vq_suggest_json(const vq_index*, const char* json, size_t len, vq_suggest_result** out);
+size_t vq_suggest_len(const vq_suggest_result*);
+const char* vq_suggest_text(const vq_suggest_result*, size_t i);
+float vq_suggest_score(const vq_suggest_result*, size_t i);
+uint32_t vq_suggest_term_id(const vq_suggest_result*, size_t i);
+void vq_suggest_free(vq_suggest_result*);
 
 /* ----------------------------------------------------------------- search */
 

@@ -52,6 +52,18 @@ def lib():
         L.vo_result_facet_count.restype = C.c_uint64
         L.vo_result_facet_count.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         L.vo_result_free.argtypes = [C.c_void_p]
+        L.vo_result_why_found_terms_json.restype = C.c_char_p
+        L.vo_result_why_found_terms_json.argtypes = [C.c_void_p]
+        L.vo_suggest_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.vo_suggest_len.restype = C.c_size_t
+        L.vo_suggest_len.argtypes = [C.c_void_p]
+        L.vo_suggest_text.restype = C.c_char_p
+        L.vo_suggest_text.argtypes = [C.c_void_p, C.c_size_t]
+        L.vo_suggest_score.restype = C.c_float
+        L.vo_suggest_score.argtypes = [C.c_void_p, C.c_size_t]
+        L.vo_suggest_term_id.restype = C.c_uint32
+        L.vo_suggest_term_id.argtypes = [C.c_void_p, C.c_size_t]
+        L.vo_suggest_free.argtypes = [C.c_void_p]
         L.vo_bench_search.restype = C.c_double
         L.vo_bench_search.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, u64p]
         L.vo_op_default_score_for_distance.restype = C.c_float
@@ -130,9 +142,26 @@ class OracleIndex:
                 fl = self.L.vo_result_facet_len(out, f)
                 facets.append((self.L.vo_result_facet_field(out, f).decode(),
                                [(self.L.vo_result_facet_value(out, f, i).decode(), int(self.L.vo_result_facet_count(out, f, i))) for i in range(fl)]))
-            return OracleResult(int(self.L.vo_result_num_hits(out)), ids, scores, facets, int(self.L.vo_result_execution_time_ns(out)))
+            res = OracleResult(int(self.L.vo_result_num_hits(out)), ids, scores, facets, int(self.L.vo_result_execution_time_ns(out)))
+            import json as _json
+            res.why_found_terms = _json.loads(self.L.vo_result_why_found_terms_json(out).decode())
+            return res
         finally:
             self.L.vo_result_free(out)
+
+    def suggest_json(self, js):
+        """suggest_multi / suggest (search_field.rs:194-231): -> [(text, score, term_id)]"""
+        if not isinstance(js, (bytes, bytearray)):
+            js = js.encode()
+        out = C.c_void_p()
+        rc = self.L.vo_suggest_json(self.h, js, len(js), C.byref(out))
+        if rc != 0:
+            raise OracleError(rc, self.L.vo_last_error().decode())
+        try:
+            return [(self.L.vo_suggest_text(out, i).decode(), float(self.L.vo_suggest_score(out, i)), int(self.L.vo_suggest_term_id(out, i)))
+                    for i in range(self.L.vo_suggest_len(out))]
+        finally:
+            self.L.vo_suggest_free(out)
 
     def bench(self, jsons, repeat=1, threads=1):
         """Run the requests on `threads` host threads; returns (wall_seconds, latencies_ns, checksum)."""

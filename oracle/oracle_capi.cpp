@@ -15,6 +15,7 @@ struct ResultBox {
     SearchResult r;
     std::vector<uint32_t> ids;
     std::vector<float> scores;
+    std::string why_json, explain_json;
 };
 int fail(const VelociError& e) {
     g_err = e.what();
@@ -103,6 +104,58 @@ int vo_search_json(const void* index, const char* json, size_t len, void** out) 
         return fail(e);
     }
 }
+// why_found_terms (search.rs:186) as JSON {"<path>": ["term", ...]}
+const char* vo_result_why_found_terms_json(const void* r) {
+    auto* box = const_cast<ResultBox*>(static_cast<const ResultBox*>(r));
+    std::string& s = box->why_json;
+    s = "{";
+    bool first = true;
+    for (auto& kv : box->r.why_found_terms) {
+        if (!first) s += ',';
+        first = false;
+        vqjson::escape_to(s, kv.first);
+        s += ":[";
+        for (size_t i = 0; i < kv.second.size(); ++i) {
+            if (i) s += ',';
+            vqjson::escape_to(s, kv.second[i]);
+        }
+        s += ']';
+    }
+    s += '}';
+    return s.c_str();
+}
+// suggest (search_field.rs:194-231): `json` is a Request with "suggest" parts, or a bare RequestSearchPart (then top / skip are the part's)
+struct SuggestBox {
+    std::vector<SuggestEntry> e;
+};
+int vo_suggest_json(const void* index, const char* json, size_t len, void** out) {
+    try {
+        *out = nullptr;
+        vqjson::Value v = vqjson::parse(json, len);
+        Request req;
+        if (v.is_object() && v.get("suggest")) req = request_from_json(v);
+        else {
+            RequestSearchPart part = search_part_from_json(v);
+            req.suggest = std::vector<RequestSearchPart>{part};
+            req.top = part.top;  // :226-227
+            req.skip = part.skip;
+        }
+        auto* box = new SuggestBox();
+        box->e = suggest_multi(*static_cast<const Index*>(index), std::move(req));
+        *out = box;
+        return 0;
+    } catch (const VelociError& e) {
+        return fail(e);
+    } catch (const vqjson::ParseError& e) {
+        return fail(VelociError(ERR_JSON, std::string("JsonError: ") + e.what()));
+    }
+}
+size_t vo_suggest_len(const void* s) { return static_cast<const SuggestBox*>(s)->e.size(); }
+const char* vo_suggest_text(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].text.c_str(); }
+float vo_suggest_score(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].score; }
+uint32_t vo_suggest_term_id(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].term_id; }
+void vo_suggest_free(void* s) { delete static_cast<SuggestBox*>(s); }
+
 uint64_t vo_result_num_hits(const void* r) { return static_cast<const ResultBox*>(r)->r.num_hits; }
 uint64_t vo_result_execution_time_ns(const void* r) { return static_cast<const ResultBox*>(r)->r.execution_time_ns; }
 size_t vo_result_len(const void* r) { return static_cast<const ResultBox*>(r)->ids.size(); }

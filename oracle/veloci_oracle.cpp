@@ -3,6 +3,7 @@
 #include "veloci_oracle.hpp"
 
 #include <chrono>
+#include <regex>
 #include <cstdio>
 
 namespace vo {
@@ -183,9 +184,16 @@ static inline bool score_id_before(const Hit& a, const Hit& b) {
     return a.score > b.score;
 }
 
+// search_field.rs:72-83: regex-automata 0.1.9 dense DFA over the term's bytes, unanchored at the start (the builder's default acts as if the
+// pattern began with `(?s:.)*?`), accepted when the walk ENDS in a match state; `starts_with` accepts once any prefix did.  Restated with
+// std::regex (ECMAScript grammar, the common subset of the two syntaxes; byte-wise: `.` is one byte here, one scalar value there).
+static bool regex_matches(const std::regex& whole, const std::regex& anywhere, bool starts_with, const std::string& term) {
+    if (starts_with) return std::regex_search(term, anywhere);
+    return std::regex_match(term, whole);
+}
+
 SearchFieldResult get_term_ids_in_field(const Index& index, PlanRequestSearchPart& options) {
     RequestSearchPart& req = options.request;
-    if (req.is_regex) throw VelociError(ERR_UNSUPPORTED, "is_regex is not restated by the oracle");
     if (req.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");  // reference: index out of bounds panic
     if (!ends_with(req.path, TEXTINDEX)) req.path += TEXTINDEX;  // :278-280
     SearchFieldResult result;
@@ -226,6 +234,8 @@ SearchFieldResult get_term_ids_in_field(const Index& index, PlanRequestSearchPar
             }
             result.hits_scores.push_back(Hit{token_text_id, score});
         }
+        if (options.return_term || options.store_term_texts)  // :347-353 (not reached by a hit the top-n cut has just dropped, :324-327)
+            result.terms[token_text_id] = options.return_term_lowercase ? vqtext::to_lower_utf8(text_or_token) : text_or_token;
     };
 
     // The reference walks the FST under the automaton; stream order == bytewise order == id order.
@@ -248,7 +258,18 @@ SearchFieldResult get_term_ids_in_field(const Index& index, PlanRequestSearchPar
         if (!req.starts_with && (tn > query_cps.size() + match_max_d || tn + match_max_d < query_cps.size())) return false;
         return lev_span(tp, tn, query_cps.data(), query_cps.size(), match_transposition, match_ci, req.starts_with) <= match_max_d;
     };
-    if (match_max_d == 0 && !req.starts_with) {
+    if (req.is_regex) {  // :72-83
+        std::regex whole, anywhere;
+        try {
+            const auto flags = std::regex::ECMAScript | (req.ignore_case.value_or(true) ? std::regex::icase : std::regex::ECMAScript);
+            whole = std::regex("[\\s\\S]*?(?:" + req.terms[0] + ")", flags);
+            anywhere = std::regex(req.terms[0], flags);
+        } catch (const std::regex_error& e) {
+            throw VelociError(ERR_INVALID_REQUEST, std::string("InvalidRequest: \"regex ") + e.what() + "\" ");  // (the reference unwrap()s: a panic)
+        }
+        for (uint32_t id = 0; id < fst.terms.size(); ++id)
+            if (regex_matches(whole, anywhere, req.starts_with, fst.terms[id])) callback(fst.terms[id], id);
+    } else if (match_max_d == 0 && !req.starts_with) {
         std::vector<uint32_t> cand;
         if (match_ci) {
             auto it = fst.lower_map.find(vqtext::to_lower_utf8(req.terms[0]));
@@ -275,6 +296,11 @@ SearchFieldResult get_term_ids_in_field(const Index& index, PlanRequestSearchPar
         std::vector<uint32_t> ids;
         for (auto& h : result.hits_scores) ids.push_back(h.id);
         result.term_id_hits_in_field[req.path][req.terms[0]] = ids;
+    }
+    if (options.store_term_texts && !result.terms.empty()) {  // :386-389
+        std::vector<std::string> texts;
+        for (auto& kv : result.terms) texts.push_back(kv.second);
+        result.term_text_in_field[req.path] = texts;
     }
     if (req.token_value) {  // :391-395
         RequestBoostPart tb = *req.token_value;
@@ -356,6 +382,14 @@ static TermIdHits merge_term_id_hits(std::vector<SearchFieldResult>& results) { 
     return out;
 }
 
+static std::map<std::string, std::vector<std::string>> merge_term_id_texts(std::vector<SearchFieldResult>& results) {  // set_op.rs:49-63
+    std::map<std::string, std::vector<std::string>> out;
+    for (auto& el : results) {
+        for (auto& kv : el.term_text_in_field) out[kv.first].insert(out[kv.first].end(), kv.second.begin(), kv.second.end());
+        el.term_text_in_field.clear();
+    }
+    return out;
+}
 template <class V>
 static size_t get_shortest_result(const std::vector<V>& lens) {  // :9-17 (first minimal)
     size_t idx = 0;
@@ -376,6 +410,7 @@ SearchFieldResult intersect_hits_score(std::vector<SearchFieldResult> and_result
     if (and_results.empty()) return SearchFieldResult{};
     if (and_results.size() == 1) return std::move(and_results[0]);
     TermIdHits term_id_hits_in_field = merge_term_id_hits(and_results);
+    auto term_text_in_field = merge_term_id_texts(and_results);
     std::vector<size_t> lens;
     for (auto& r : and_results) lens.push_back(r.hits_scores.size());
     size_t index_shortest = get_shortest_result(lens);
@@ -424,6 +459,7 @@ SearchFieldResult intersect_hits_score(std::vector<SearchFieldResult> and_result
     }
     SearchFieldResult res;
     res.term_id_hits_in_field = std::move(term_id_hits_in_field);
+    res.term_text_in_field = std::move(term_text_in_field);
     res.hits_scores = std::move(intersected_hits);
     res.request = and_results[0].request;  // :439
     return res;
@@ -433,6 +469,7 @@ SearchFieldResult union_hits_score(std::vector<SearchFieldResult> or_results) { 
     if (or_results.empty()) return SearchFieldResult{};
     if (or_results.size() == 1) return std::move(or_results[0]);
     TermIdHits term_id_hits_in_field = merge_term_id_hits(or_results);
+    auto term_text_in_field = merge_term_id_texts(or_results);
     for (auto& r : or_results) sort_hits_by_id(r.hits_scores);  // :114-117
     std::vector<std::string> terms;  // :122-124
     for (auto& r : or_results) terms.push_back(r.request.terms.empty() ? std::string() : r.request.terms[0]);
@@ -478,6 +515,7 @@ SearchFieldResult union_hits_score(std::vector<SearchFieldResult> or_results) { 
     }
     SearchFieldResult res;
     res.term_id_hits_in_field = std::move(term_id_hits_in_field);
+    res.term_text_in_field = std::move(term_text_in_field);
     res.hits_scores = std::move(union_hits);
     res.request = or_results[0].request;  // :215
     return res;
@@ -998,6 +1036,7 @@ struct PlanCtx {
         if (r.kind == SearchRequest::Search) {
             LeafEntry& e = leaf(r.part);
             e.req.store_term_id_hits |= (request.why_found || request.text_locality);
+            e.req.store_term_texts |= request.why_found;  // :416
         } else
             for (auto& q : r.tree.queries) flag_tree(q);
     }
@@ -1196,11 +1235,38 @@ SearchResult search(Request request, const Index& index) {
         search_result.has_facets = true;
         for (auto& fr : *request.facets) search_result.facets.push_back({fr.field, get_facet(index, fr, hit_ids)});
     }
+    search_result.why_found_terms = res.term_text_in_field;  // :186
     search_result.num_hits = res.hits_scores.size();  // :207
     search_result.data = top_n_sort(std::move(res.hits_scores), uint32_t(*request.top) + uint32_t(request.skip.value_or(0)));  // :210-211
     apply_top_skip(search_result.data, request.skip, request.top);  // :218
     search_result.execution_time_ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - start).count());
     return search_result;
+}
+
+// search_field.rs:160-219: every part's matched terms (lower-cased texts, scores), texts merged keeping the best score, ranked by score
+std::vector<SuggestEntry> suggest_multi(const Index& index, Request req) {
+    if (!req.suggest) throw VelociError(ERR_INVALID_REQUEST, "only suggest allowed in suggest function");  // StringError, :196-198
+    std::vector<SuggestEntry> out;
+    for (auto& part : *req.suggest) {
+        PlanRequestSearchPart p;
+        p.request = part;
+        p.get_scores = true;
+        p.return_term = true;
+        p.return_term_lowercase = true;
+        SearchFieldResult r = get_term_ids_in_field(index, p);
+        for (auto& h : r.hits_scores) out.push_back(SuggestEntry{r.terms.at(h.id), h.score, h.id});
+    }
+    // merge same text (:175-187): sort by text descending, a later duplicate hands its score to the kept one when larger
+    std::stable_sort(out.begin(), out.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.text > b.text; });
+    std::vector<SuggestEntry> merged;
+    for (auto& e : out) {
+        if (!merged.empty() && merged.back().text == e.text) {
+            if (e.score > merged.back().score) merged.back().score = e.score;
+        } else merged.push_back(e);
+    }
+    std::stable_sort(merged.begin(), merged.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.score > b.score; });  // :189 (unstable there)
+    apply_top_skip(merged, req.skip, req.top);
+    return merged;
 }
 
 }  // namespace vo

@@ -101,11 +101,15 @@ struct SearchFieldResult {  // src/search/result/field_result.rs:7-30
     RequestSearchPart request;
     std::optional<std::pair<std::string, std::string>> phrase_boost;  // (search1.terms[0], search2.terms[0])
     TermIdHits term_id_hits_in_field;
+    std::map<uint32_t, std::string> terms;                                 // term id -> text (return_term / store_term_texts, search_field.rs:347-353)
+    std::map<std::string, std::vector<std::string>> term_text_in_field;    // path -> matched term texts (why_found, :386-389)
     static SearchFieldResult new_from(const SearchFieldResult& o) {  // :42-52
         SearchFieldResult r;
         r.request = o.request;
         r.phrase_boost = o.phrase_boost;
         r.term_id_hits_in_field = o.term_id_hits_in_field;
+        r.terms = o.terms;
+        r.term_text_in_field = o.term_text_in_field;
         return r;
     }
 };
@@ -132,7 +136,14 @@ struct SearchResult {  // src/search/result/search_result.rs:9-26
     std::vector<Hit> data;
     bool has_facets = false;
     std::vector<std::pair<std::string, std::vector<std::pair<std::string, uint64_t>>>> facets;  // request order
+    std::map<std::string, std::vector<std::string>> why_found_terms;  // search.rs:186 (the reference's map and list orders are unspecified)
 };
+struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, Score, TermId)>
+    std::string text;
+    float score;
+    uint32_t term_id;
+};
+std::vector<SuggestEntry> suggest_multi(const struct Index& index, Request req);  // search_field.rs:194-219 (and :221-231 for a bare RequestSearchPart)
 
 // ------------------------------------------------------------------ decoded index (Persistence, src/persistence.rs:52-72)
 struct Fst {  // sorted term table standing in for fst::Map (ordinal == term id)
@@ -235,6 +246,7 @@ uint32_t levenshtein_cps(const std::vector<uint32_t>& a, const std::vector<uint3
 struct PlanRequestSearchPart {  // plan_creator/execution_plan.rs:16-44
     RequestSearchPart request;
     bool get_scores = false, get_ids = false, store_term_id_hits = false;
+    bool return_term = false, return_term_lowercase = false, store_term_texts = false;
 };
 SearchFieldResult get_term_ids_in_field(const Index&, PlanRequestSearchPart& options);  // search_field.rs:277-398
 // A2

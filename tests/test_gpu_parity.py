@@ -198,7 +198,7 @@ def test_errors(corpus):
         veloci_amd.search({"top": 3}, idx)
     assert e2.value.code == 1
     with pytest.raises(veloci_amd.VelociError) as e3:
-        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"]}}, "why_found": True}, idx)
+        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"]}}, "why_found": True, "select": ["body"]}, idx)  # why_found_info: highlighting
     assert e3.value.code == 4
 
 
@@ -673,6 +673,84 @@ def test_text_locality_on_multi_valued_text_fields_device_prepass():
     for r, g, w in zip(reqs, _search_batch_over_shards(data, reqs, 2), wants):
         assert not isinstance(g, Exception), (str(g), json.dumps(r))
         assert_same(r, g, w)
+
+
+def test_suggest_regex_and_why_found_terms_match_the_reference_and_the_oracle():
+    """SURVEY.md §8f-5 / f-4 (dictionary side): suggest (search_field.rs:194-231), regex leaves (:72-83) and `why_found_terms` (search.rs:186)
+    through the C ABI — the reference's own assertions (tests/golden/reference_suggest_regex.json), then product == oracle on a wider set."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    import test_reference_integration as T
+    fx = T._load_suggest_regex()
+    built = {}
+
+    def corpus_of(name, tv=None):
+        key = (name, json.dumps(tv))
+        if key not in built:
+            data, docs, info = T.build_fixture_corpus(fx, name, tv)
+            ora = O.OracleIndex(data.num_anchors)
+            data.load_into(ora)
+            built[key] = (veloci_amd.Index(data, device=0), ora, docs, info)
+        return built[key]
+
+    for case in fx["suggest"]:
+        idx, ora, docs, info = corpus_of(case["corpus"], case.get("token_values"))
+        got = veloci_amd.suggest(case["request"], idx)
+        T.check_suggest_case(case, got)
+        want = ora.suggest_json(json.dumps(case["request"]))
+        assert [(t, np.float32(s).view(np.uint32)) for t, s, _ in got] == [(t, np.float32(s).view(np.uint32)) for t, s, _ in want], case["name"]
+    for case in fx["term_lookup"]:
+        idx, ora, docs, info = corpus_of(case["corpus"])
+        assert sorted(t for t, _, _ in veloci_amd.suggest(case["request"], idx)) == case["expect_terms_sorted_lowercase"], case["name"]
+    for case in fx["regex"]:
+        idx, ora, docs, info = corpus_of(case["corpus"])
+        res = veloci_amd.search(case["request"], idx)
+        assert len(res.ids) == case["expect_len"], (case["name"], res.ids)
+        if "expect_doc0" in case:
+            assert docs[int(res.ids[0])][case["expect_doc0"][0]] == case["expect_doc0"][1], case["name"]
+        assert_same(case["request"], res, ora.search_json(json.dumps(case["request"])))
+    # wider: suggest parts of every kind, regex leaves inside trees, why_found_terms of trees
+    idx, ora, docs, info = corpus_of("test_all")
+    parts = []
+    for path in ("meanings.ger[]", "meanings.eng[]", "title", "kanji[].text"):
+        for term, kw in (("will", {"starts_with": True}), ("majes", {"starts_with": True, "top": 3}), ("wille", {"levenshtein_distance": 1}), ("Begeisterung", {"levenshtein_distance": 2, "skip": 1, "top": 2}),
+                         (".*e.*", {"is_regex": True}), ("w.*", {"is_regex": True, "ignore_case": False}), ("der", {}), ("majestät", {"levenshtein_distance": 1, "boost": 2.5})):
+            parts.append(dict({"terms": [term], "path": path}, **kw))
+    for part in parts:
+        js = json.dumps(part)
+        try:
+            want = ora.suggest_json(js)
+        except O.OracleError as e:
+            with pytest.raises(veloci_amd.VelociError) as g:
+                veloci_amd.suggest(part, idx)
+            assert str(g.value) == str(e), js
+            continue
+        got = veloci_amd.suggest(part, idx)
+        assert sorted((t, np.float32(s).view(np.uint32)) for t, s, _ in got) == sorted((t, np.float32(s).view(np.uint32)) for t, s, _ in want), js
+        assert [np.float32(s).view(np.uint32) for _, s, _ in got] == [np.float32(s).view(np.uint32) for _, s, _ in want], js
+    multi = {"suggest": parts[:6], "top": 7, "skip": 1}
+    assert [(t, s) for t, s, _ in veloci_amd.suggest(multi, idx)] == [(t, s) for t, s, _ in ora.suggest_json(json.dumps(multi))]
+    leaf = lambda **kw: {"search": kw}
+    reqs = [
+        {"search_req": leaf(terms=[".*wil.*"], path="meanings.ger[]", is_regex=True), "why_found": True},
+        {"search_req": {"or": {"queries": [leaf(terms=["will"], path="meanings.ger[]", levenshtein_distance=1), leaf(terms=["will"], path="meanings.eng[]"),
+                                           leaf(terms=[".*ung.*"], path="meanings.ger[]", is_regex=True)]}}, "why_found": True, "top": 20},
+        {"search_req": {"and": {"queries": [leaf(terms=["m.*"], path="meanings.ger[]", is_regex=True, ignore_case=False), leaf(terms=["majes"], path="meanings.ger[]", starts_with=True)]}},
+         "why_found": True, "filter": leaf(terms=["der"], path="meanings.ger[]")},
+        {"search_req": {"or": {"queries": [leaf(terms=["will"], path="meanings.eng[]"), leaf(terms=["will"], path="meanings.eng[]")]}}, "why_found": True},
+        {"search_req": leaf(terms=["[0-9]+.*"], path="meanings.ger[]", is_regex=True)},
+    ]
+    for req in reqs:
+        want = ora.search_json(json.dumps(req))
+        got = veloci_amd.search(req, idx)
+        assert_same(req, got, want)
+        assert {k: sorted(v) for k, v in got.why_found_terms.items()} == {k: sorted(v) for k, v in want.why_found_terms.items()}, json.dumps(req)
+    for req, got in zip(reqs, veloci_amd.search_batch(reqs, idx)):
+        assert_same(req, got, ora.search_json(json.dumps(req)))
+    with pytest.raises(veloci_amd.VelociError) as e:
+        veloci_amd.search(dict(reqs[0], select=["title"]), idx)
+    assert e.value.kind == "Unsupported"
 
 
 def test_random_requests_in_batches_match_the_oracle():

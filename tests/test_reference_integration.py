@@ -46,3 +46,84 @@ def test_tokenizer_vectors():
     assert [t for t, _ in tokenize("das \n ist ein txt, test", D)] == ["das", " \n ", "ist", " ", "ein", " ", "txt", ", ", "test"]
     assert [t for t, _ in tokenize(" Taschenbuch (kartoniert)", D)] == [" ", "Taschenbuch", " (", "kartoniert", ")"]
     assert [t for t, _ in tokenize("T oll", D)] == ["T", " ", "oll"]
+
+
+# ---------------------------------------------------------------- suggest / regex leaves
+def _load_suggest_regex():
+    import os
+    with open(os.path.join(refcases.HERE, "golden", "reference_suggest_regex.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def build_fixture_corpus(fx, name, token_values=None):
+    """IndexData + docs of a corpus named by a fixture (its own corpora first, then reference_integration.json's)."""
+    from veloci_amd import mini_indexer
+    c = fx["corpora"].get(name) or refcases.load()["corpora"][name]
+    docs = refcases.corpus_docs(c)
+    data, info = mini_indexer.build_index(docs, c["indices"], token_values=tuple(token_values) if token_values else None)
+    return data, docs, info
+
+
+def texts_in_score_groups(entries):
+    """[(text, score, id)] -> [sorted texts of every run of equal scores]: the reference's final sort is unstable (search_field.rs:189)"""
+    groups = []
+    for text, score, _ in entries:
+        if groups and groups[-1][0] == score:
+            groups[-1][1].append(text)
+        else:
+            groups.append((score, [text]))
+    return [sorted(g[1]) for g in groups]
+
+
+def check_suggest_case(case, entries):
+    got = texts_in_score_groups(entries)
+    want, i = [], 0
+    for g in got:  # cut the expected sequence into the same group sizes
+        want.append(sorted(case["expect_texts"][i:i + len(g)]))
+        i += len(g)
+    assert got == want and i == len(case["expect_texts"]), f"{case['name']}: {[e[0] for e in entries]} != {case['expect_texts']}"
+
+
+def test_oracle_reproduces_reference_suggest_and_regex_assertions():
+    from oracle import binding as O
+    fx = _load_suggest_regex()
+    for case in fx["suggest"]:
+        data, docs, info = build_fixture_corpus(fx, case["corpus"], case.get("token_values"))
+        ora = O.OracleIndex(data.num_anchors)
+        data.load_into(ora)
+        check_suggest_case(case, ora.suggest_json(json.dumps(case["request"])))
+    for case in fx["term_lookup"]:
+        data, docs, info = build_fixture_corpus(fx, case["corpus"])
+        ora = O.OracleIndex(data.num_anchors)
+        data.load_into(ora)
+        got = sorted(t for t, _, _ in ora.suggest_json(json.dumps(case["request"])))
+        assert got == case["expect_terms_sorted_lowercase"], (case["name"], got)
+    for case in fx["regex"]:
+        data, docs, info = build_fixture_corpus(fx, case["corpus"])
+        ora = O.OracleIndex(data.num_anchors)
+        data.load_into(ora)
+        res = ora.search_json(json.dumps(case["request"]))
+        assert len(res.ids) == case["expect_len"], (case["name"], res.ids)
+        if "expect_doc0" in case:
+            assert docs[int(res.ids[0])][case["expect_doc0"][0]] == case["expect_doc0"][1], case["name"]
+
+
+def test_oracle_regex_match_sets_agree_with_python_re():
+    """The oracle's regex leaves (std::regex) against an independent engine: Python's `re` with the reference's semantics — unanchored at the
+    start, the match must reach the end of the term (search_field.rs:72-83); starts_with: any prefix may match."""
+    import re
+    from oracle import binding as O
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    for path in ("meanings.ger[]", "meanings.eng[]"):
+        terms = info[path + ".textindex"]["terms"] if path + ".textindex" in info else info[path]["terms"]
+        for pat in (".*wil.*", "w.l+e?", "[a-m]+", ".*(ung|ing)", "maje.*", ".*\\(f\\)", "W.*", ".* .*"):
+            for ci in (True, False):
+                for sw in (False, True):
+                    rx = re.compile(pat, re.IGNORECASE if ci else 0)
+                    want = sorted(t for t in terms if (rx.search(t) if sw else re.fullmatch("[\\s\\S]*?(?:" + pat + ")", t, re.IGNORECASE if ci else 0)))
+                    part = {"terms": [pat], "path": path, "is_regex": True, "ignore_case": ci, "starts_with": sw}
+                    got_ids = [i for _, _, i in ora.suggest_json(json.dumps(part))]
+                    got = sorted(terms[i] for i in got_ids)
+                    assert got == want, (path, pat, ci, sw, got, want)

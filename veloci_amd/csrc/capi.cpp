@@ -56,6 +56,26 @@ struct vq_result {
 struct vq_partial_batch {
     std::unique_ptr<PartialBatch> pb;
 };
+struct vq_suggest_result {
+    std::vector<SuggestEntry> e;
+};
+
+static void why_found_terms_json(std::string& s, const std::map<std::string, std::vector<std::string>>& m) {
+    s += '{';
+    bool first = true;
+    for (auto& kv : m) {
+        if (!first) s += ',';
+        first = false;
+        vqjson::escape_to(s, kv.first);
+        s += ":[";
+        for (size_t i = 0; i < kv.second.size(); ++i) {
+            if (i) s += ',';
+            vqjson::escape_to(s, kv.second[i]);
+        }
+        s += ']';
+    }
+    s += '}';
+}
 
 extern "C" {
 
@@ -247,10 +267,54 @@ const char* vq_result_to_json(const vq_result* r) {
         }
         s += '}';
     }
+    if (!r->r.why_found_terms.empty()) {
+        s += ",\"why_found_terms\":";
+        why_found_terms_json(s, r->r.why_found_terms);
+    }
     s += '}';
     return s.c_str();
 }
+const char* vq_result_why_found_terms_json(const vq_result* r) {
+    thread_local std::string s;
+    s.clear();
+    why_found_terms_json(s, r->r.why_found_terms);
+    return s.c_str();
+}
 void vq_result_free(vq_result* r) { delete r; }
+
+// ------------------------------------------------------------------ suggest
+int vq_suggest_json(const vq_index* index, const char* json, size_t len, vq_suggest_result** out) {
+    return guard([&] {
+        if (!index || !json || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_suggest_json: null argument");
+        *out = nullptr;
+        Request req;
+        try {
+            vqjson::Value v = vqjson::parse(json, len);
+            if (v.is_object() && v.get("suggest")) req = vqreq::request_from_json(v);
+            else {  // a bare RequestSearchPart: search_field::suggest (:221-231), top / skip are the part's
+                vqreq::RequestSearchPart part = vqreq::search_part_from_json(v);
+                req.suggest = std::vector<vqreq::RequestSearchPart>{part};
+                req.top = part.top;
+                req.skip = part.skip;
+            }
+        } catch (const vqjson::ParseError& e) {
+            throw VelociError(VQ_ERR_JSON, std::string("JsonError: ") + e.what());
+        }
+        auto* r = new vq_suggest_result();
+        try {
+            r->e = run_suggest(*index->idx, req);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+    });
+}
+size_t vq_suggest_len(const vq_suggest_result* r) { return r->e.size(); }
+const char* vq_suggest_text(const vq_suggest_result* r, size_t i) { return r->e[i].text.c_str(); }
+float vq_suggest_score(const vq_suggest_result* r, size_t i) { return r->e[i].score; }
+uint32_t vq_suggest_term_id(const vq_suggest_result* r, size_t i) { return r->e[i].term_id; }
+void vq_suggest_free(vq_suggest_result* r) { delete r; }
 
 // ------------------------------------------------------------------ search
 static int run_batch(const vq_index* index, const vq_request* const* requests, size_t n, vq_result** out, int* status, std::string* first_error) {

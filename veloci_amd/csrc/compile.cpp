@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <regex>
 #include <set>
 
 #include "engine.hpp"
@@ -127,6 +128,8 @@ struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:
     RequestSearchPart part;
     std::string path;  // with ".textindex"
     bool get_scores = false, get_ids = false, store_term_id_hits = false;
+    bool return_term = false, return_term_lowercase = false, store_term_texts = false;  // execution_plan.rs:16-44
+    std::vector<std::pair<uint32_t, std::string>> terms;  // term id -> text (search_field.rs:347-353), ascending ids
     bool computed = false;
     std::vector<std::pair<uint32_t, float>> hits_scores;  // (term id, term score), ascending term id
     std::vector<uint32_t> hits_ids;                        // term ids
@@ -198,11 +201,42 @@ struct Compiler {
         else
             for (auto& q : r.tree.queries) flag_tree(q);
     }
+    void flag_tree_texts(const SearchRequest& r) {  // execution_plan.rs:416
+        if (r.kind == SearchRequest::Search) leaf(r.part).store_term_texts |= req.why_found;
+        else
+            for (auto& q : r.tree.queries) flag_tree_texts(q);
+    }
+
+    // Regex leaf (search_field.rs:72-83), a HOST fallback for the dictionary side only (the postings of the matched terms stay on the device):
+    // regex-automata 0.1.9's dense DFA walks the term's bytes, unanchored at the start (its builder acts as if the pattern began with
+    // `(?s:.)*?`), and the term is accepted when the walk ENDS in a match state; `starts_with` accepts once any prefix did.  Restated over code
+    // points with std::wregex (ECMAScript grammar: the common subset of the two syntaxes; case-insensitivity beyond ASCII follows the C locale).
+    std::vector<uint32_t> regex_candidates(const Dictionary& dict, const RequestSearchPart& p) {
+        auto widen = [](const std::string& u8) {
+            std::wstring w;
+            for (uint32_t cp : vqtext::decode_utf8(u8)) w.push_back(wchar_t(cp));
+            return w;
+        };
+        std::wregex whole, anywhere;
+        try {
+            const auto flags = std::regex::ECMAScript | (p.ignore_case.value_or(true) ? std::regex::icase : std::regex::ECMAScript);
+            const std::wstring pat = widen(p.terms[0]);
+            whole = std::wregex(L"[\\s\\S]*?(?:" + pat + L")", flags);
+            anywhere = std::wregex(pat, flags);
+        } catch (const std::regex_error& e) {
+            throw VelociError(ERR_INVALID_REQUEST, std::string("InvalidRequest: \"regex ") + e.what() + "\" ");
+        }
+        std::vector<uint32_t> out;
+        for (uint32_t id = 0; id < dict.terms.size(); ++id) {
+            const std::wstring w = widen(dict.terms[id]);
+            if (p.starts_with ? std::regex_search(w, anywhere) : std::regex_match(w, whole)) out.push_back(id);
+        }
+        return out;
+    }
 
     // get_term_ids_in_field (search_field.rs:277-398) — dictionary side only
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
         const RequestSearchPart& p = l.part;
-        if (p.is_regex) unsupported("is_regex");
         if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
         if (p.options && p.options->explain) unsupported("explain");
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
@@ -222,8 +256,10 @@ struct Compiler {
         const auto query_cps = vqtext::decode_utf8(p.terms[0]);
         std::vector<uint32_t> cand;
         const FuzzyProbe* probe = nullptr;
-        const bool scan = lev != 0 || p.starts_with;
-        if (scan) {  // match set computed on the device before compilation (k_dict_scan), ascending == FST stream order
+        const bool regex = p.is_regex;
+        const bool scan = !regex && (lev != 0 || p.starts_with);
+        if (regex) cand = regex_candidates(dict, p);
+        else if (scan) {  // match set computed on the device before compilation (k_dict_scan), ascending == FST stream order
             const FuzzyProbe* fp = nullptr;
             if (fuzzy) {
                 auto it = fuzzy->find(fuzzy_key(p));
@@ -246,7 +282,7 @@ struct Compiler {
         const bool check_prefix = p.starts_with || lev != 0;  // :302
         for (size_t ci_ = 0; ci_ < cand.size(); ++ci_) {  // ascending ids == FST stream order
             const uint32_t id = cand[ci_];
-            if (!scan) {
+            if (!scan && !regex) {
                 const auto cps = vqtext::decode_utf8(dict.terms[id]);
                 if (cps.size() != query_cps.size()) continue;
                 bool eq = true;
@@ -263,7 +299,7 @@ struct Compiler {
                     score = default_score_for_distance(scoring_distance(lower_hit, lower_term, lev), prefix_matches);
                 }
                 if (limit_result) {
-                    if (score < worst_score) continue;
+                    if (score < worst_score) continue;  // (:324-327 returns before the term text is recorded)
                     if (!l.hits_scores.empty() && l.hits_scores.size() == top_n_search + 200) {  // sort.rs:24-34
                         std::sort(l.hits_scores.begin(), l.hits_scores.end(), [](auto& a, auto& b) { return a.second == b.second ? a.first > b.first : a.second > b.second; });
                         l.hits_scores.resize(top_n_search);
@@ -272,6 +308,8 @@ struct Compiler {
                 }
                 l.hits_scores.push_back({id, score});
             }
+            if (l.return_term || l.store_term_texts)  // :347-353
+                l.terms.push_back({id, l.return_term_lowercase ? vqtext::to_lower_utf8(dict.terms[id]) : dict.terms[id]});
         }
         if (p.boost)  // :359-364
             for (auto& h : l.hits_scores) h.second *= *p.boost;
@@ -714,6 +752,10 @@ struct Compiler {
         info.node_id = my_id;
         if (r.kind == SearchRequest::Search) {
             Leaf& l = field_result(r.part);
+            if (!is_filter && l.store_term_texts && !l.terms.empty()) {  // search_field.rs:386-389, merged upwards by set_op.rs:49-63 (a leaf used twice counts twice)
+                auto& dst = cq.why_found_terms[l.path];
+                for (auto& t : l.terms) dst.push_back(t.second);
+            }
             const RequestBoostPart* boost_1n = nullptr;
             if (!is_filter) {  // 1:n boosts joined through a shared [] prefix (execution_plan.rs:422-509)
                 size_t pos = r.part.path.rfind("[]");
@@ -1367,7 +1409,7 @@ struct Compiler {
     // ------------------------------------------------------------ the whole request (search.rs:143-228)
     void run() {
         if (req.has_select) unsupported("select");
-        if (req.why_found) unsupported("why_found");
+        if (req.why_found && req.has_select) unsupported("why_found with select (why_found_info: highlighting of the returned documents)");
         if (req.explain) unsupported("explain");
         if (req.has_suggest) unsupported("suggest");
         if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
@@ -1393,6 +1435,7 @@ struct Compiler {
         if (req.filter) collect(*req.filter, true);
         if (req.filter) flag_tree(*req.filter);
         flag_tree(*req.search_req);
+        if (req.why_found) flag_tree_texts(*req.search_req);
         if (req.phrase_boosts)
             for (auto& el : *req.phrase_boosts) {
                 leaf(el.search1).get_ids = true;
@@ -1809,6 +1852,26 @@ struct Compiler {
 
 float default_score_for_distance_host(uint8_t distance, bool prefix_matches) { return default_score_for_distance(distance, prefix_matches); }
 
+// suggest (search_field.rs:194-219): one part's matched terms with lower-cased texts and scores — get_term_ids_in_field with get_scores,
+// return_term and return_term_lowercase; the dictionary scan of a fuzzy / prefix part has run on the device (`fuzzy`).
+std::vector<SuggestEntry> suggest_part(const Index& idx, const RequestSearchPart& part, const FuzzyTable* fuzzy) {
+    Request dummy;
+    Compiler c(idx, dummy, fuzzy);
+    Leaf l;
+    l.part = part;
+    l.get_scores = true;
+    l.return_term = true;
+    l.return_term_lowercase = true;
+    c.lookup_terms(idx, l, true, false);
+    if (part.token_value) c.apply_token_value(*part.token_value, l);
+    std::vector<SuggestEntry> out;
+    std::map<uint32_t, const std::string*> text;
+    for (auto& t : l.terms) text[t.first] = &t.second;
+    for (auto& h : l.hits_scores) out.push_back(SuggestEntry{*text.at(h.first), h.second, h.first});
+    return out;
+}
+
+
 // ---- dictionary scans requested by a batch (collected before compilation, answered by k_dict_scan)
 std::string fuzzy_key(const RequestSearchPart& p) {
     std::string path = p.path;
@@ -1819,7 +1882,7 @@ std::string fuzzy_key(const RequestSearchPart& p) {
     k += std::to_string(clamped_lev(p)) + (p.starts_with ? "p" : "-") + (p.ignore_case ? (*p.ignore_case ? "T" : "F") : "N");
     return k;
 }
-bool needs_dictionary_scan(const RequestSearchPart& p) { return !p.terms.empty() && (clamped_lev(p) != 0 || p.starts_with); }
+bool needs_dictionary_scan(const RequestSearchPart& p) { return !p.terms.empty() && !p.is_regex && (clamped_lev(p) != 0 || p.starts_with); }
 
 static void probe_part(const Index& idx, const RequestSearchPart& p, FuzzyTable& table) {
     if (!needs_dictionary_scan(p)) return;
@@ -1871,6 +1934,11 @@ void score_fuzzy_probe(const Index& idx, FuzzyProbe& fp) {
         const bool prefix_matches = fp.check_prefix && lower_hit.size() >= fp.lower_term.size() && lower_hit.compare(0, fp.lower_term.size(), fp.lower_term) == 0;
         fp.scores[i] = default_score_for_distance(scoring_distance(lower_hit, fp.lower_term, fp.lev), prefix_matches);
     }
+}
+
+void collect_suggest_probes(const Index& idx, const Request& req, FuzzyTable& table) {
+    if (req.suggest)
+        for (auto& p : *req.suggest) probe_part(idx, p, table);
 }
 
 void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& table) {

@@ -147,6 +147,14 @@ struct Workspace;
 void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStream_t st);
 void score_fuzzy_probe(const Index& idx, FuzzyProbe& probe);
 float default_score_for_distance_host(uint8_t distance, bool prefix_matches);  // search_field.rs:27-33
+struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, Score, TermId)>
+    std::string text;
+    float score;
+    uint32_t term_id;
+};
+std::vector<SuggestEntry> suggest_part(const Index& idx, const vqreq::RequestSearchPart& part, const FuzzyTable* fuzzy);
+void collect_suggest_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
+std::vector<SuggestEntry> run_suggest(const Index& idx, const vqreq::Request& req);  // suggest_multi, search_field.rs:194-219
 
 // A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the
 // terms' posting lists with the per-doc maximum of term_score * (f16 / 100).
@@ -462,6 +470,7 @@ struct CompiledQuery {
     DWide wide{};        // simple_flags bit 24
     std::vector<DFacet> facets;
     std::vector<FacetOut> facet_out;
+    std::map<std::string, std::vector<std::string>> why_found_terms;  // search.rs:186: path -> matched term texts (request.why_found)
     uint32_t top = 10, skip = 0, top_k = 10;
     uint64_t total_len = 0;       // sum of shard-local list lengths (work estimate)
     uint64_t algorithmic_bytes = 0;
@@ -496,6 +505,7 @@ struct Result {
     std::vector<float> scores;
     std::vector<ResultFacet> facets;
     bool has_facets = false;
+    std::map<std::string, std::vector<std::string>> why_found_terms;
     bool deep = false;  // holds the first page of a deep request (see CompiledQuery::deep)
     mutable std::string json;
 };

@@ -1177,6 +1177,38 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     return pb;
 }
 
+// suggest_multi (search_field.rs:194-219): dictionary side only — the parts' matched terms, equal texts merged keeping the best score, ranked
+std::vector<SuggestEntry> run_suggest(const Index& idx, const vqreq::Request& req) {
+    if (!req.suggest) throw VelociError(ERR_INVALID_REQUEST, "only suggest allowed in suggest function");
+    VQ_HIP(hipSetDevice(idx.device));
+    FuzzyTable fuzzy;
+    collect_suggest_probes(idx, req, fuzzy);
+    if (!fuzzy.empty()) {
+        Workspace& ws = idx.ws[idx.next_ws.fetch_add(1) % kWorkspaces];
+        std::unique_lock<std::mutex> lock(ws.mu);
+        ws.timed.clear();
+        ws.ev_used = 0;
+        run_fuzzy_probes(idx, ws, fuzzy, idx.pre_stream ? idx.pre_stream : idx.stream);
+    }
+    std::vector<SuggestEntry> out;
+    for (auto& part : *req.suggest) {
+        auto one = suggest_part(idx, part, fuzzy.empty() ? nullptr : &fuzzy);
+        out.insert(out.end(), one.begin(), one.end());
+    }
+    std::stable_sort(out.begin(), out.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.text > b.text; });  // :176 (descending)
+    std::vector<SuggestEntry> merged;
+    for (auto& e : out) {
+        if (!merged.empty() && merged.back().text == e.text) {
+            if (e.score > merged.back().score) merged.back().score = e.score;
+        } else merged.push_back(e);
+    }
+    std::stable_sort(merged.begin(), merged.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.score > b.score; });  // :189
+    const size_t skip = std::min(req.skip.value_or(0), merged.size());  // apply_top_skip, search.rs:230-239
+    merged.erase(merged.begin(), merged.begin() + skip);
+    if (req.top && merged.size() > *req.top) merged.resize(*req.top);
+    return merged;
+}
+
 void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
                             std::vector<int>& status, std::vector<std::string>& errors) {
     constexpr uint64_t kMaxDeep = 65536;  // ranked hits one request may reach (64 scans)
@@ -1337,6 +1369,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         r->deep = cq.deep;
         key_off += cq.top_k;
         if (!cq.facet_out.empty()) r->has_facets = true;
+        r->why_found_terms = cq.why_found_terms;
         for (size_t f = 0; f < cq.facet_out.size(); ++f, ++job) {
             const FacetOut& fo = cq.facet_out[f];
             ResultFacet rf;

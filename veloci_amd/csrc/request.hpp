@@ -78,6 +78,7 @@ struct RequestPhraseBoost {  // src/search/request/mod.rs:89-93
 struct Request {  // src/search/request/mod.rs:15-87
     std::optional<SearchRequest> search_req;
     bool has_suggest = false;
+    std::optional<std::vector<RequestSearchPart>> suggest;  // request/mod.rs:21-24: answered by suggest_multi (search_field.rs:194-219), not by search()
     std::optional<std::vector<RequestBoostPart>> boost;
     std::optional<std::vector<RequestSearchPart>> boost_term;
     std::optional<std::vector<FacetRequest>> facets;
@@ -284,7 +285,13 @@ inline Request request_from_json(const vqjson::Value& v) {
     if (!v.is_object()) json_fail("Request: expected an object");
     Request r;
     if (const vqjson::Value* s = v.get("search_req"); s && !s->is_null()) r.search_req = search_request_from_json(*s);
-    if (const vqjson::Value* s = v.get("suggest"); s && !s->is_null()) r.has_suggest = true;
+    if (const vqjson::Value* s = v.get("suggest"); s && !s->is_null()) {
+        if (!s->is_array()) json_fail("suggest: expected a sequence");
+        std::vector<RequestSearchPart> out;
+        for (auto& e : s->arr) out.push_back(search_part_from_json(e));
+        r.suggest = out;
+        r.has_suggest = true;
+    }
     if (const vqjson::Value* b = v.get("boost"); b && !b->is_null()) {
         if (!b->is_array()) json_fail("boost: expected a sequence");
         std::vector<RequestBoostPart> out;

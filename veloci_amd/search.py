@@ -74,7 +74,9 @@ def _take_result(L, h):
                 fl = L.vq_result_facet_len(h, f)
                 facets[L.vq_result_facet_field(h, f).decode()] = [(L.vq_result_facet_value(h, f, i).decode(), int(L.vq_result_facet_count(h, f, i)))
                                                                    for i in range(fl)]
-        return SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
+        res = SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
+        res.why_found_terms = json.loads(L.vq_result_why_found_terms_json(h).decode())
+        return res
     finally:
         L.vq_result_free(h)
 
@@ -90,6 +92,22 @@ def search(request, index):
     out = C.c_void_p()
     _lib.check(L.vq_search(index.h, req.h, C.byref(out)))
     return _take_result(L, out)
+
+
+def suggest(request, index):
+    """== search_field::suggest_multi / suggest (src/search/search_field.rs:194-231): `request` is a Request with "suggest" parts or a bare
+    RequestSearchPart (dict or JSON).  -> [(text, score, term_id)]"""
+    L = _lib.lib()
+    if isinstance(request, dict):
+        request = json.dumps(request)
+    if isinstance(request, str):
+        request = request.encode()
+    out = C.c_void_p()
+    _lib.check(L.vq_suggest_json(index.h, request, len(request), C.byref(out)))
+    try:
+        return [(L.vq_suggest_text(out, i).decode(), float(L.vq_suggest_score(out, i)), int(L.vq_suggest_term_id(out, i))) for i in range(L.vq_suggest_len(out))]
+    finally:
+        L.vq_suggest_free(out)
 
 
 def search_batch(requests, index, raise_on_error=True):
