@@ -257,10 +257,10 @@ def test_generic_kernel_also_matches_for_simple_queries():
 
 
 @pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
-                                 {"VQ_NO_WIDE": "1"}],
+                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}],
                          ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
                               "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
-                              "wide_queries_on_k_tile_scan"])
+                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results."""
     import os
@@ -1269,3 +1269,35 @@ def test_concurrent_searches_from_host_threads(corpus):
     for t in threads:
         t.join()
     assert not errors, errors[:2]
+
+
+def test_query_generator_requests_match_the_reference_and_the_oracle():
+    """SURVEY.md §8f-3: the requests `query_generator::search_query` builds for the reference's own tests (tests/golden/reference_query_generator.json:
+    every term expanded into an OR over all 14 searched fields) through the C ABI — the reference's assertions, and product == oracle bit for bit."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    import refcases
+    import test_reference_integration as T
+    fx = T._load_query_generator()
+    built = {}
+    ran = 0
+    for case in fx["cases"]:
+        if "request" not in case:
+            continue
+        if case["corpus"] not in built:
+            c = fx["corpora"][case["corpus"]]
+            data, docs, info = T.build_fixture_corpus(fx, case["corpus"], c.get("token_values"))
+            ora = O.OracleIndex(data.num_anchors)
+            data.load_into(ora)
+            built[case["corpus"]] = (veloci_amd.Index(data, device=0), ora, docs, info)
+        idx, ora, docs, info = built[case["corpus"]]
+        request = dict(case["request"])
+        request.pop("explain", None)  # explain records: test_explain_records_match_the_oracle
+        res = refcases.check_expectations(dict(case, request=request), docs, info, lambda req: veloci_amd.search(req, idx))
+        assert_same(request, veloci_amd.search(request, idx), ora.search_json(json.dumps(request)))
+        for extra in ({"why_found": True}, {"top": 2, "skip": 1}):
+            wide = dict(request, **extra)
+            assert_same(wide, veloci_amd.search(wide, idx), ora.search_json(json.dumps(wide)))
+        ran += 1
+    assert ran == 23

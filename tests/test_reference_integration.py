@@ -127,3 +127,55 @@ def test_oracle_regex_match_sets_agree_with_python_re():
                     got_ids = [i for _, _, i in ora.suggest_json(json.dumps(part))]
                     got = sorted(terms[i] for i in got_ids)
                     assert got == want, (path, pat, ci, sw, got, want)
+
+
+# ---------------------------------------------------------------- query generator replay
+def _load_query_generator():
+    import os
+    with open(os.path.join(refcases.HERE, "golden", "reference_query_generator.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_query_generator_restatement_regenerates_the_committed_requests():
+    """tests/qgen.py (query_generator.rs:175-246) against the committed fixture: the requests are reproducible from each test's parameters, and the
+    generator's own errors carry the text the reference tests look for (test_query_generator.rs:362-381)."""
+    import qgen
+    fx = _load_query_generator()
+    for case in fx["cases"]:
+        c = fx["corpora"][case["corpus"]]
+        if "generator_error_contains" in case["expect"]:
+            with pytest.raises(qgen.GeneratorError) as e:
+                qgen.search_query(c["all_fields"], c["search_fields"], case["params"])
+            assert case["expect"]["generator_error_contains"] in str(e.value), case["name"]
+            assert case["generator_error"] == str(e.value)
+        else:
+            assert qgen.search_query(c["all_fields"], c["search_fields"], case["params"]) == case["request"], case["name"]
+    # the pieces of the generator the reference unit-tests itself
+    assert qgen.get_default_levenshtein("a" * 2, 1, False) == 0 and qgen.get_default_levenshtein("a" * 3, 1, False) == 1  # query_generator.rs:84-99
+    assert qgen.get_default_levenshtein("a" * 3, 1, True) == 0 and qgen.get_default_levenshtein("a" * 6, 2, False) == 2
+    assert qgen.regex_escape("a.b*c") == "a\\.b\\*c"
+    flat = qgen.simplify({"or": {"queries": [{"or": {"queries": [{"search": 1}, {"search": 2}]}}, {"search": 3}]}})
+    assert flat == {"or": {"queries": [{"search": 3}, {"search": 1}, {"search": 2}]}}
+
+
+def test_oracle_reproduces_reference_query_generator_assertions():
+    """Every search-producing case of tests/all/test_query_generator.rs and the query-generator half of test_code_search.rs, through the oracle."""
+    from oracle import binding as O
+    fx = _load_query_generator()
+    oracles = {}
+    ran = 0
+    for case in fx["cases"]:
+        if "request" not in case:
+            continue
+        if case["corpus"] not in oracles:
+            c = fx["corpora"][case["corpus"]]
+            data, docs, info = build_fixture_corpus(fx, case["corpus"], c.get("token_values"))
+            ora = O.OracleIndex(data.num_anchors)
+            data.load_into(ora)
+            oracles[case["corpus"]] = (ora, docs, info)
+        ora, docs, info = oracles[case["corpus"]]
+        request = dict(case["request"])
+        request.pop("explain", None)  # the records are checked in test_explain (f-4); hits and scores do not depend on the flag
+        refcases.check_expectations(dict(case, request=request), docs, info, lambda req: ora.search_json(json.dumps(req)))
+        ran += 1
+    assert ran == 23

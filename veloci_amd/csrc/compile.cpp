@@ -467,7 +467,7 @@ struct Compiler {
     }
 
     // key of the union job that materialises this leaf, or "" when the leaf's lists are scanned as they are (same rule and key as
-    // in compile_leaf_scores)
+    // in compile_leaf_lists)
     std::string leaf_union_key(const Leaf& l) {
         const PostingStore& ps = posting_store(l.path);
         size_t nonempty = 0;
@@ -480,93 +480,114 @@ struct Compiler {
 
     // score leaf: the posting lists of the matched terms (resolve_token_to_anchor, search_field.rs:400-504)
     NodeInfo compile_leaf_scores(const SearchRequest& r, Leaf& l, std::vector<DOp>& ops, uint32_t& sp) {
+        std::vector<Leaf*> one{&l};
+        return compile_leaf_lists(r.part.terms[0], one, ops, sp);
+    }
+
+    // One OP_LEAF over the posting lists of `members`' matched terms: the union of the lists, per doc the largest s_t * (f16 / 100).
+    // One member: a leaf of the request (search_field.rs:453-464 keeps the maximum per doc).  Several: leaves of ONE OR node that carry the
+    // same term — the query generator's expansion of a term over the fields — fused: they share a term slot there, and a slot's value is the
+    // maximum over its operands (set_op.rs:169-177), i.e. the same maximum over the same values; hits and scores are unchanged, the node keeps
+    // one operand per distinct term.
+    NodeInfo compile_leaf_lists(const std::string& label, const std::vector<Leaf*>& members, std::vector<DOp>& ops, uint32_t& sp) {
         NodeInfo info;
         DOp op{};
         op.kind = OP_LEAF;
         op.list_begin = uint16_t(cq.lists.size());
-        info.label = r.part.terms[0];
-        {
-                const PostingStore& ps = posting_store(l.path);
-                uint32_t count = 0;
-                uint32_t with_entries = 0;
-                size_t nonempty = 0;  // lists with entries anywhere: every shard must take the same decision (the pre-passes are collective)
-                for (auto& [tid, score] : l.hits_scores)
-                    if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
-                if (nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req))) {
-                    // K2: the leaf's hits are materialised once per batch (union, max per doc) and scanned as one list
-                    const std::string ukey = leaf_union_key(l);
-                    const UnionJob* done = nullptr;
-                    if (unions) {
-                        auto it = unions->find(ukey);
-                        if (it != unions->end()) done = &it->second;
+        info.label = label;
+        struct Entry {
+            const PostingStore* ps;
+            uint32_t tid;
+            float score;
+        };
+        std::vector<Entry> entries;
+        for (Leaf* l : members) {
+            const PostingStore& ps = posting_store(l->path);
+            for (auto& [tid, score] : l->hits_scores)
+                if (tid < ps.num_tokens) entries.push_back({&ps, tid, score});
+        }
+        size_t nonempty = 0;  // lists with entries anywhere: every shard must take the same decision (the pre-passes are collective)
+        for (auto& e : entries)
+            if (e.ps->global_len[e.tid]) ++nonempty;
+        uint32_t count = 0;
+        if (nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req))) {
+            // K2: the leaf's hits are materialised once per batch (union, max per doc) and scanned as one list
+            std::string ukey;
+            if (members.size() == 1) ukey = leaf_union_key(*members[0]);
+            else {
+                ukey = "u|fused";
+                for (Leaf* l : members) ukey += "|" + l->path + "|" + l->part.key();
+            }
+            const UnionJob* done = nullptr;
+            if (unions) {
+                auto it = unions->find(ukey);
+                if (it != unions->end()) done = &it->second;
+            }
+            info.glen = 0;
+            if (!done) {
+                UnionJob job;
+                job.key = ukey;
+                for (auto& e : entries)
+                    if (e.ps->global_len[e.tid]) {
+                        job.terms.push_back(UnionJob::Term{e.ps, e.tid, e.score});
+                        job.input_postings += e.ps->len[e.tid];
                     }
-                    info.glen = 0;
-                    if (!done) {
-                        UnionJob job;
-                        job.key = ukey;
-                        job.store_path = l.path + TO_ANCHOR_ID_SCORE;
-                        for (auto& [tid, score] : l.hits_scores)
-                            if (tid < ps.num_tokens && ps.global_len[tid]) {
-                                job.terms.push_back({tid, score});
-                                job.input_postings += ps.len[tid];
-                            }
-                        cq.union_requests.push_back(std::move(job));  // compiled again after the jobs ran
-                        info.len_known = true;
-                    } else {
-                        if (done->len) {
-                            HList h;
-                            h.d_docs = done->d_docs;
-                            h.d_scores = reinterpret_cast<const uint16_t*>(done->d_vals);
-                            h.len = done->len;
-                            h.global_len = done->global_len;
-                            h.flags = LIST_HAS_SCORES | LIST_F32;
-                            h.term_score = 1.0f;
-                            h.max_value = done->max_value;
-                            uint32_t li = add_list(h);
-                            info.cover.push_back(li);
-                            info.cover_len += h.len;
-                            count = 1;
-                        }
-                        cq.algorithmic_bytes += 6ull * done->input_postings + 8ull * done->len;
-                        info.glen = done->global_len;
-                        // the merged length is this shard's only: known globally when the index is not sharded
-                        info.len_known = !req.filter && idx.can_sum_over_shards();
-                    }
-                    op.list_count = uint16_t(count);
-                    push_op(ops, op, sp);
-                    info.emitted = true;
-                    return info;
-                }
-                for (auto& [tid, score] : l.hits_scores) {
-                    if (tid >= ps.num_tokens) continue;
-                    if (ps.global_len[tid]) ++with_entries;
-                    if (ps.len[tid] == 0) continue;
+                cq.union_requests.push_back(std::move(job));  // compiled again after the jobs ran
+                info.len_known = true;
+            } else {
+                if (done->len) {
                     HList h;
-                    h.d_docs = ps.docs.as<uint32_t>() + ps.start[tid];
-                    h.d_scores = ps.scores.as<uint16_t>() + ps.start[tid];
-                    h.len = ps.len[tid];
-                    h.global_len = ps.global_len[tid];
-                    h.flags = LIST_HAS_SCORES;
-                    h.term_score = score;
-                    h.max_raw = ps.max_raw[tid];
-                    if (!ps.bm_start.empty() && ps.bm_start[tid] >= 0) {
-                        h.flags |= LIST_BITMAP;
-                        h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[tid];
-                        h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[tid];
-                    }
+                    h.d_docs = done->d_docs;
+                    h.d_scores = reinterpret_cast<const uint16_t*>(done->d_vals);
+                    h.len = done->len;
+                    h.global_len = done->global_len;
+                    h.flags = LIST_HAS_SCORES | LIST_F32;
+                    h.term_score = 1.0f;
+                    h.max_value = done->max_value;
                     uint32_t li = add_list(h);
                     info.cover.push_back(li);
                     info.cover_len += h.len;
-                    cq.algorithmic_bytes += 6ull * h.len;
-                    ++count;
+                    count = 1;
                 }
-                op.list_count = uint16_t(count);
-                // a single posting list and no Set filter in front of it: the result length is the list length
-                info.len_known = with_entries <= 1 && !req.filter;
-                info.glen = 0;
-                for (auto& [tid, score] : l.hits_scores)
-                    if (tid < ps.num_tokens) info.glen += ps.global_len[tid];
+                cq.algorithmic_bytes += 6ull * done->input_postings + 8ull * done->len;
+                info.glen = done->global_len;
+                // the merged length is this shard's only: known globally when the index is not sharded
+                info.len_known = !req.filter && idx.can_sum_over_shards();
+            }
+            op.list_count = uint16_t(count);
+            push_op(ops, op, sp);
+            info.emitted = true;
+            return info;
         }
+        uint32_t with_entries = 0;
+        for (auto& e : entries) {
+            const PostingStore& ps = *e.ps;
+            if (ps.global_len[e.tid]) ++with_entries;
+            if (ps.len[e.tid] == 0) continue;
+            HList h;
+            h.d_docs = ps.docs.as<uint32_t>() + ps.start[e.tid];
+            h.d_scores = ps.scores.as<uint16_t>() + ps.start[e.tid];
+            h.len = ps.len[e.tid];
+            h.global_len = ps.global_len[e.tid];
+            h.flags = LIST_HAS_SCORES;
+            h.term_score = e.score;
+            h.max_raw = ps.max_raw[e.tid];
+            if (!ps.bm_start.empty() && ps.bm_start[e.tid] >= 0) {
+                h.flags |= LIST_BITMAP;
+                h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[e.tid];
+                h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[e.tid];
+            }
+            uint32_t li = add_list(h);
+            info.cover.push_back(li);
+            info.cover_len += h.len;
+            cq.algorithmic_bytes += 6ull * h.len;
+            ++count;
+        }
+        op.list_count = uint16_t(count);
+        // a single posting list and no Set filter in front of it: the result length is the list length
+        info.len_known = with_entries <= 1 && !req.filter;
+        info.glen = 0;
+        for (auto& e : entries) info.glen += e.ps->global_len[e.tid];
         push_op(ops, op, sp);
         info.emitted = true;
         return info;
@@ -746,30 +767,36 @@ struct Compiler {
         c.glen = filter_is_set ? it->second.second : it->second.first;
         c.len_known = true;
     }
+    // the 1:n boost joined to a search path through a shared [] prefix (execution_plan.rs:422-509)
+    const RequestBoostPart* find_boost_1n(const RequestSearchPart& part, const std::vector<RequestBoostPart>& boost) {
+        const RequestBoostPart* boost_1n = nullptr;
+        size_t pos = part.path.rfind("[]");
+        if (pos == std::string::npos) return nullptr;
+        std::string end_obj = part.path.substr(0, pos);
+        for (auto& el : boost) {
+            size_t p = el.path.rfind("[]");
+            if (p != std::string::npos && el.path.substr(0, p) == end_obj) {
+                if (boost_1n) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"more than one boost matches the 1:n search path\" ");
+                boost_1n = &el;
+            }
+        }
+        return boost_1n;
+    }
+    // bookkeeping of a score leaf's result that does not depend on how its lists are scanned
+    void note_score_leaf(Leaf& l) {
+        if (l.store_term_texts && !l.terms.empty()) {  // search_field.rs:386-389, merged upwards by set_op.rs:49-63 (a leaf used twice counts twice)
+            auto& dst = cq.why_found_terms[l.path];
+            for (auto& t : l.terms) dst.push_back(t.second);
+        }
+    }
     NodeInfo compile_node_inner(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost,
                                 uint32_t my_id) {
         NodeInfo info;
         info.node_id = my_id;
         if (r.kind == SearchRequest::Search) {
             Leaf& l = field_result(r.part);
-            if (!is_filter && l.store_term_texts && !l.terms.empty()) {  // search_field.rs:386-389, merged upwards by set_op.rs:49-63 (a leaf used twice counts twice)
-                auto& dst = cq.why_found_terms[l.path];
-                for (auto& t : l.terms) dst.push_back(t.second);
-            }
-            const RequestBoostPart* boost_1n = nullptr;
-            if (!is_filter) {  // 1:n boosts joined through a shared [] prefix (execution_plan.rs:422-509)
-                size_t pos = r.part.path.rfind("[]");
-                if (pos != std::string::npos) {
-                    std::string end_obj = r.part.path.substr(0, pos);
-                    for (auto& el : boost) {
-                        size_t p = el.path.rfind("[]");
-                        if (p != std::string::npos && el.path.substr(0, p) == end_obj) {
-                            if (boost_1n) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"more than one boost matches the 1:n search path\" ");
-                            boost_1n = &el;
-                        }
-                    }
-                }
-            }
+            if (!is_filter) note_score_leaf(l);
+            const RequestBoostPart* boost_1n = is_filter ? nullptr : find_boost_1n(r.part, boost);
             if (boost_1n) {  // the leaf, then a unary op that applies the per-anchor boost values
                 NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
                 leaf_info.node_id = my_id;
@@ -816,8 +843,43 @@ struct Compiler {
             info.root_op = int(ops.size()) - 1;
             return info;
         }
+        // Operands of a scored OR that are plain leaves with the same term — the query generator's expansion of one term over the searched
+        // fields (query_parser_to_veloci_request.rs:84-109) — share a term slot (set_op.rs:143), and a slot's value is the maximum over its
+        // operands (:169-177): they are compiled as ONE leaf over all their posting lists (compile_leaf_lists), the OR keeps one operand per
+        // distinct term.  fuse_with[i]: the operands fused into operand i (itself first); skip[i]: operand i was fused into an earlier one.
+        static const bool no_fuse = std::getenv("VQ_NO_LEAF_FUSION") != nullptr;
+        std::vector<std::vector<size_t>> fuse_with(queries.size());
+        std::vector<bool> skip(queries.size(), false);
+        if (!is_filter && r.kind == SearchRequest::Or && queries.size() > 1 && !no_fuse) {
+            std::map<std::string, size_t> first_of;
+            for (size_t i = 0; i < queries.size(); ++i) {
+                const SearchRequest& q = queries[i];
+                if (q.kind != SearchRequest::Search || q.part.terms.empty() || q.part.options || find_boost_1n(q.part, boost)) continue;
+                auto [it, fresh] = first_of.emplace(q.part.terms[0], i);
+                fuse_with[it->second].push_back(i);
+                skip[i] = !fresh;
+            }
+        }
         std::vector<NodeInfo> ch;
-        for (auto& q : queries) {
+        for (size_t qi = 0; qi < queries.size(); ++qi) {
+            const SearchRequest& q = queries[qi];
+            if (skip[qi]) continue;
+            if (fuse_with[qi].size() > 1) {
+                std::vector<Leaf*> members;
+                uint32_t first_id = UINT32_MAX;
+                for (size_t m : fuse_with[qi]) {
+                    const uint32_t id = next_node++;
+                    if (first_id == UINT32_MAX) first_id = id;
+                    Leaf& l = field_result(queries[m].part);
+                    note_score_leaf(l);
+                    members.push_back(&l);
+                }
+                NodeInfo fused = compile_leaf_lists(q.part.terms[0], members, ops, sp);
+                fused.node_id = first_id;
+                fused.root_op = int(ops.size()) - 1;
+                ch.push_back(std::move(fused));
+                continue;
+            }
             std::vector<RequestBoostPart> child_boost = boost;  // merge_vec execution_plan.rs:263-270
             if (q.get_options() && q.get_options()->boost) child_boost.insert(child_boost.end(), q.get_options()->boost->begin(), q.get_options()->boost->end());
             ch.push_back(compile_node(q, is_filter, ops, sp, child_boost));
@@ -829,7 +891,7 @@ struct Compiler {
                 push_op(ops, op, sp);
             }
         }
-        if (ch.size() == 1) return ch[0];  // set_op.rs:93-96 / :372-375: the single operand is passed through
+        if (queries.size() == 1) return ch[0];  // set_op.rs:93-96 / :372-375: the single operand is passed through
         if (is_filter) {
             info.label_known = false;
             info.emitted = true;

@@ -125,6 +125,7 @@ struct Dictionary {  // term dictionary of one text field
 };
 
 struct Index;
+struct PostingStore;
 struct FuzzyProbe {  // one dictionary scan of a batch (get_text_lines_from_fst, search_field.rs:68-99)
     std::string key;
     std::string path;                 // "<field>.textindex"
@@ -160,8 +161,12 @@ std::vector<SuggestEntry> run_suggest(const Index& idx, const vqreq::Request& re
 // terms' posting lists with the per-doc maximum of term_score * (f16 / 100).
 struct UnionJob {
     std::string key;
-    std::string store_path;                            // "<field>.textindex.to_anchor_id_score"
-    std::vector<std::pair<uint32_t, float>> terms;     // (token id, term score) with entries in this shard
+    struct Term {
+        const PostingStore* store;  // "<field>.textindex.to_anchor_id_score" of the term's field (a fused leaf spans several fields)
+        uint32_t token;
+        float score;                // term score
+    };
+    std::vector<Term> terms;                           // the lists to merge (those with entries in the unsharded index)
     // result (valid until the batch that ran it is finished; lives in the batch workspace)
     const uint32_t* d_docs = nullptr;
     const float* d_vals = nullptr;

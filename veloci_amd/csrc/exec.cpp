@@ -477,14 +477,14 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
     std::vector<UnionTaskH> l1, l2;
     for (auto& kv : table) {
         UnionJob& job = kv.second;
-        const PostingStore& ps = idx.postings.at(job.store_path);
         std::vector<UList> raw;
-        for (auto& [tid, score] : job.terms) {
+        for (auto& t : job.terms) {
+            const PostingStore& ps = *t.store;
             UList u{};
-            u.docs = ps.docs.as<uint32_t>() + ps.start[tid];
-            u.scores = ps.scores.as<uint16_t>() + ps.start[tid];
-            u.len = ps.len[tid];
-            u.term_score = score;
+            u.docs = ps.docs.as<uint32_t>() + ps.start[t.token];
+            u.scores = ps.scores.as<uint16_t>() + ps.start[t.token];
+            u.len = ps.len[t.token];
+            u.term_score = t.score;
             raw.push_back(u);
         }
         if (raw.size() > 64 * 64) throw VelociError(ERR_UNSUPPORTED, "leaf expansion with more than 4096 posting lists");
