@@ -169,6 +169,14 @@ const char* vq_result_to_json(const vq_result*);
  * the reference's map and list orders are unspecified).  `why_found` together with `select` (why_found_info: highlighting of the
  * returned documents) is declined. */
 const char* vq_result_why_found_terms_json(const vq_result*);
+/* `explain: true` (src/search/request/mod.rs:83-86; or `options.explain` on the single leaf of a request): the `Explain` records
+ * (src/search/result/explain.rs:2-21) of the returned hits, i.e. `SearchResult.explain.get(&hit.id)` of src/search.rs:86,96 — a JSON array
+ * parallel to the hits, each element null or the hit's records in serde's form ({"TermToAnchor":{"term_score":..,"anchor_score":..,
+ * "final_score":..,"term_id":..}}, {"LevenshteinScore":{"score":..,"text_or_token_id":"..","term_id":..}}, {"OrSumOverDistinctTerms":..},
+ * {"Boost":..}; floats printed with %.9g).  "null" when the request did not ask.  The scores inside the records are recomputed on the
+ * device for the returned hits only (k_explain).  Declined: explain together with phrase_boosts or a 1:n boost, explain on some leaves
+ * only, and explain on the flat / sharded paths.  Thread-local string. */
+const char* vq_result_explain_json(const vq_result*);
 void vq_result_free(vq_result*);
 
 /* ---------------------------------------------------------------- suggest

@@ -124,6 +124,19 @@ const char* vo_result_why_found_terms_json(const void* r) {
     s += '}';
     return s.c_str();
 }
+// explain (search.rs:86,96: result.explain.get(&hit.id)) as a JSON array parallel to the hits: null or the hit's records
+const char* vo_result_explain_json(const void* r) {
+    auto* box = const_cast<ResultBox*>(static_cast<const ResultBox*>(r));
+    std::string& s = box->explain_json;
+    s = "[";
+    for (size_t i = 0; i < box->r.data.size(); ++i) {
+        if (i) s += ',';
+        auto it = box->r.explain.find(box->r.data[i].id);
+        s += it == box->r.explain.end() ? std::string("null") : explain_json(it->second);
+    }
+    s += ']';
+    return s.c_str();
+}
 // suggest (search_field.rs:194-231): `json` is a Request with "suggest" parts, or a bare RequestSearchPart (then top / skip are the part's)
 struct SuggestBox {
     std::vector<SuggestEntry> e;

@@ -28,6 +28,40 @@ const BoostStore& Index::get_boost(const std::string& path) const {
     return it->second;
 }
 
+static void push_boost_record(ExplainMap* explain, uint32_t id, float v) {
+    if (!explain) return;
+    Explain e;
+    e.kind = Explain::Boost;
+    e.a = v;
+    (*explain)[id].push_back(e);
+}
+std::string explain_json(const std::vector<Explain>& records) {
+    auto f = [](float v) {
+        char buf[48];
+        std::snprintf(buf, sizeof buf, "%.9g", double(v));
+        return std::string(buf);
+    };
+    std::string out = "[";
+    for (size_t i = 0; i < records.size(); ++i) {
+        const Explain& e = records[i];
+        if (i) out += ",";
+        switch (e.kind) {
+            case Explain::Boost: out += "{\"Boost\":" + f(e.a) + "}"; break;
+            case Explain::MaxTokenToTextId: out += "{\"MaxTokenToTextId\":" + f(e.a) + "}"; break;
+            case Explain::OrSumOverDistinctTerms: out += "{\"OrSumOverDistinctTerms\":" + f(e.a) + "}"; break;
+            case Explain::TermToAnchor:
+                out += "{\"TermToAnchor\":{\"term_score\":" + f(e.a) + ",\"anchor_score\":" + f(e.b) + ",\"final_score\":" + f(e.c) + ",\"term_id\":" + std::to_string(e.term_id) + "}}";
+                break;
+            case Explain::LevenshteinScore:
+                out += "{\"LevenshteinScore\":{\"score\":" + f(e.a) + ",\"text_or_token_id\":";
+                vqjson::escape_to(out, e.text);
+                out += ",\"term_id\":" + std::to_string(e.term_id) + "}}";
+                break;
+        }
+    }
+    return out + "]";
+}
+
 static bool ends_with(const std::string& s, const char* suf) {
     size_t n = std::strlen(suf);
     return s.size() >= n && std::memcmp(s.data() + s.size() - n, suf, n) == 0;
@@ -233,6 +267,14 @@ SearchFieldResult get_term_ids_in_field(const Index& index, PlanRequestSearchPar
                 check_apply_top_n_sort(result.hits_scores, top_n_search, score_id_before, [&](const Hit& w) { worst_score = w.score; });
             }
             result.hits_scores.push_back(Hit{token_text_id, score});
+            if (is_explain(req)) {  // :334-343 (insert: a later hit with the same id would replace the entry)
+                Explain e;
+                e.kind = Explain::LevenshteinScore;
+                e.a = score;
+                e.term_id = token_text_id;
+                e.text = text_or_token;
+                result.explain[token_text_id] = std::vector<Explain>{e};
+            }
         }
         if (options.return_term || options.store_term_texts)  // :347-353 (not reached by a hit the top-n cut has just dropped, :324-327)
             result.terms[token_text_id] = options.return_term_lowercase ? vqtext::to_lower_utf8(text_or_token) : text_or_token;
@@ -335,6 +377,18 @@ SearchFieldResult resolve_token_to_anchor(const Index& index, const RequestSearc
             uint32_t id = store.anchors[i];
             if (should_filter(filter, id)) continue;
             float final_score = hit.score * (f16_bits_to_f32(store.scores_f16[i]) / 100.0f);  // :426
+            if (is_explain(options)) {  // :429-441
+                std::vector<Explain>& vecco = res.explain[id];
+                Explain e;
+                e.kind = Explain::TermToAnchor;
+                e.term_id = hit.id;
+                e.a = hit.score;
+                e.b = f16_bits_to_f32(store.scores_f16[i]) / 100.0f;
+                e.c = final_score;
+                vecco.push_back(e);
+                auto exp = result.explain.find(hit.id);  // the dictionary result's records of this term
+                if (exp != result.explain.end()) vecco.insert(vecco.end(), exp->second.begin(), exp->second.end());
+            }
             anchor_ids_hits.push_back(Hit{id, final_score});
         }
     }
@@ -409,6 +463,7 @@ static void sort_hits_by_id(std::vector<Hit>& v) {
 SearchFieldResult intersect_hits_score(std::vector<SearchFieldResult> and_results) {  // :368-446
     if (and_results.empty()) return SearchFieldResult{};
     if (and_results.size() == 1) return std::move(and_results[0]);
+    const bool should_explain = is_explain(and_results[0].request);  // :384 (the first operand, before the shortest one is taken out)
     TermIdHits term_id_hits_in_field = merge_term_id_hits(and_results);
     auto term_text_in_field = merge_term_id_texts(and_results);
     std::vector<size_t> lens;
@@ -458,6 +513,16 @@ SearchFieldResult intersect_hits_score(std::vector<SearchFieldResult> and_result
         }
     }
     SearchFieldResult res;
+    if (should_explain) {  // :421-433: the records of the operands that are left after the shortest one was taken out
+        for (const Hit& hit : intersected_hits)
+            for (auto& r : and_results) {
+                auto exp = r.explain.find(hit.id);
+                if (exp != r.explain.end()) {
+                    std::vector<Explain>& dst = res.explain[hit.id];
+                    dst.insert(dst.end(), exp->second.begin(), exp->second.end());
+                }
+            }
+    }
     res.term_id_hits_in_field = std::move(term_id_hits_in_field);
     res.term_text_in_field = std::move(term_text_in_field);
     res.hits_scores = std::move(intersected_hits);
@@ -493,6 +558,11 @@ SearchFieldResult union_hits_score(std::vector<SearchFieldResult> or_results) { 
     auto less = [](const MiniHit& a, const MiniHit& b) { return a.id < b.id; };
     KMerge<MiniHit, decltype(less)> mergo(sources, less);  // :159
 
+    const bool should_explain = is_explain(or_results[0].request);  // :120
+    ExplainMap explain_hits;
+    if (should_explain)  // :133-137 HashMap::extend: an operand's entry REPLACES the entry an earlier operand had under the same key
+        for (auto& r : or_results)
+            for (auto& kv : r.explain) explain_hits[kv.first] = kv.second;
     std::vector<Hit> union_hits;
     std::vector<float> max_scores_per_term(terms.size(), 0.0f);
     MiniHit el;
@@ -512,11 +582,27 @@ SearchFieldResult union_hits_score(std::vector<SearchFieldResult> or_results) { 
         for (float m : max_scores_per_term) sum += m;
         float s = sum * num_distinct_terms * num_distinct_terms;  // :183
         union_hits.push_back(Hit{id, s});
+        if (should_explain) {  // :187-195
+            Explain e;
+            e.kind = Explain::OrSumOverDistinctTerms;
+            e.a = sum;
+            explain_hits[id].push_back(e);
+        }
     }
+    if (should_explain)  // :199-208
+        for (const Hit& hit : union_hits)
+            for (auto& r : or_results) {
+                auto exp = r.explain.find(hit.id);
+                if (exp != r.explain.end()) {
+                    std::vector<Explain>& dst = explain_hits[hit.id];
+                    dst.insert(dst.end(), exp->second.begin(), exp->second.end());
+                }
+            }
     SearchFieldResult res;
     res.term_id_hits_in_field = std::move(term_id_hits_in_field);
     res.term_text_in_field = std::move(term_text_in_field);
     res.hits_scores = std::move(union_hits);
+    res.explain = std::move(explain_hits);
     res.request = or_results[0].request;  // :215
     return res;
 }
@@ -609,6 +695,7 @@ SearchFieldResult intersect_hits_ids(std::vector<SearchFieldResult> and_results)
 // A7 — multiplicative boosts by id lists (src/search/boost.rs:89-237, 380-402)
 // =====================================================================================
 SearchFieldResult apply_boost_from_iter(SearchFieldResult results, const std::function<bool(Hit&)>& next) {  // :197-237
+    const bool should_explain = is_explain(results.request);  // :200
     auto move_boost = [&](Hit& hit, Hit& hit_curr) {
         Hit b_hit;
         while (next(b_hit)) {
@@ -618,6 +705,7 @@ SearchFieldResult apply_boost_from_iter(SearchFieldResult results, const std::fu
             } else if (b_hit.id == hit.id) {
                 hit_curr = b_hit;
                 hit.score *= b_hit.score;
+                if (should_explain) push_boost_record(&results.explain, hit.id, b_hit.score);  // :213-217 (not for the entry the look-ahead rested on, :228)
             }
         }
     };
@@ -815,10 +903,14 @@ float score_expression(const std::string& expression, float rank) {  // expressi
     }
 }
 
-void apply_boost(Hit& hit, float boost_value, float boost_param, const std::optional<BoostFunction>& f, const std::optional<std::string>& expre) {  // :283-377
+void apply_boost(Hit& hit, float boost_value, float boost_param, const std::optional<BoostFunction>& f, const std::optional<std::string>& expre,
+                 ExplainMap* explain) {  // :283-377
     if (f) {
         switch (*f) {
-            case BoostFunction::Log10: hit.score *= std::log10(boost_value + boost_param); break;
+            case BoostFunction::Log10:
+                push_boost_record(explain, hit.id, std::log10(boost_value + boost_param));  // :297-300 (only this function records its factor)
+                hit.score *= std::log10(boost_value + boost_param);
+                break;
             case BoostFunction::Log2: hit.score *= std::log2(boost_value + boost_param); break;
             case BoostFunction::Multiply: hit.score *= boost_value + boost_param; break;
             case BoostFunction::Add: hit.score += boost_value + boost_param; break;
@@ -826,10 +918,12 @@ void apply_boost(Hit& hit, float boost_value, float boost_param, const std::opti
         }
     }
     if (expre) hit.score += score_expression(*expre, boost_value);
+    push_boost_record(explain, hit.id, hit.score);  // :371-374: the score after the boost
 }
 
 void apply_boost_values_anchor(SearchFieldResult& results, const RequestBoostPart& boost, const std::vector<Hit>& boost_values) {  // :255-281
     float boost_param = boost.param.value_or(0.0f);
+    ExplainMap* explain = is_explain(results.request) ? &results.explain : nullptr;  // :258
     size_t pos = 0;
     auto next = [&](Hit& h) {
         if (pos >= boost_values.size()) return false;
@@ -847,11 +941,11 @@ void apply_boost_values_anchor(SearchFieldResult& results, const RequestBoostPar
                         break;
                     } else if (b_hit.id == hit.id) {
                         hit_curr = b_hit;
-                        apply_boost(hit, b_hit.score, boost_param, boost.boost_fun, boost.expression);
+                        apply_boost(hit, b_hit.score, boost_param, boost.boost_fun, boost.expression, explain);
                     }
                 }
             } else if (hit_curr.id == hit.id) {
-                apply_boost(hit, hit_curr.score, boost_param, boost.boost_fun, boost.expression);
+                apply_boost(hit, hit_curr.score, boost_param, boost.boost_fun, boost.expression, explain);
             }
         }
     }
@@ -861,6 +955,7 @@ void add_boost(const Index& index, const RequestBoostPart& boost, SearchFieldRes
     const BoostStore& store = index.get_boost(boost.path + BOOST_VALID_TO_VALUE);
     float boost_param = boost.param.value_or(0.0f);
     std::vector<float> skip_when_score = boost.skip_when_score.value_or(std::vector<float>{});
+    ExplainMap* explain = is_explain(hits.request) ? &hits.explain : nullptr;  // :484
     for (Hit& hit : hits.hits_scores) {
         bool skip = false;
         for (float x : skip_when_score)
@@ -874,7 +969,7 @@ void add_boost(const Index& index, const RequestBoostPart& boost, SearchFieldRes
             float boost_value;
             uint32_t bits = *v;
             std::memcpy(&boost_value, &bits, 4);
-            apply_boost(hit, boost_value, boost_param, boost.boost_fun, boost.expression);
+            apply_boost(hit, boost_value, boost_param, boost.boost_fun, boost.expression, explain);
         }
     }
 }
@@ -1076,10 +1171,21 @@ struct PlanCtx {
             const uint32_t *b, *e;
             if (kv.get_values(id, &b, &e)) hits.insert(hits.end(), b, e);
         }
+        ExplainMap explain_hits;
+        if (is_explain(input.request))  // search.rs:288-305: the value ids' records are looked up under the INPUT ids — a panic when one has none
+            for (uint32_t id : input.hits_ids) {
+                const uint32_t *b, *e;
+                if (!kv.get_values(id, &b, &e)) continue;
+                auto exp = input.explain.find(id);
+                if (b != e && exp == input.explain.end())
+                    throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"explain with a 1:n boost: could not find explain for id " + std::to_string(id) + " (the reference panics)\" ");
+                for (const uint32_t* v = b; v != e; ++v) explain_hits.emplace(*v, exp->second);
+            }
         std::sort(hits.begin(), hits.end());
         hits.erase(std::unique(hits.begin(), hits.end()), hits.end());
         SearchFieldResult res = SearchFieldResult::new_from(input);
         res.hits_ids = std::move(hits);
+        res.explain = std::move(explain_hits);
         return res;
     }
     // boost.rs:432-468
@@ -1151,6 +1257,26 @@ SearchResult search(Request request, const Index& index) {
     request.top = request.top ? request.top : std::optional<size_t>(10);  // :146
     if (!request.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
 
+    if (request.explain) {  // execution_plan.rs:46-85: the header's flag goes into every part's options BEFORE the parts are collected (it is part of their equality)
+        auto merge_explain = [](std::optional<SearchRequestOptions>& o) {
+            if (!o) o = SearchRequestOptions{};
+            o->explain = true;
+        };
+        std::function<void(SearchRequest&)> walk = [&](SearchRequest& r) {
+            if (r.kind == SearchRequest::Search) merge_explain(r.part.options);
+            else {
+                merge_explain(r.tree.options);
+                for (auto& q : r.tree.queries) walk(q);
+            }
+        };
+        if (request.phrase_boosts)
+            for (auto& el : *request.phrase_boosts) {
+                merge_explain(el.search1.options);
+                merge_explain(el.search2.options);
+            }
+        walk(*request.search_req);
+        if (request.filter) walk(*request.filter);  // :98-103
+    }
     PlanCtx ctx(index, request);
     // collect_all_field_request_into_cache :91-106
     if (request.phrase_boosts)
@@ -1217,6 +1343,7 @@ SearchResult search(Request request, const Index& index) {
     }
 
     SearchResult search_result;
+    search_result.explain = res.explain;  // search.rs:174 — before the term boosts and the text locality add their records
     if (request.boost_term) res = apply_boost_term(index, std::move(res), *request.boost_term);  // :176-178
     if (request.text_locality) {  // :180-184
         std::vector<Hit> boost_anchor = boost_text_locality_all(index, res.term_id_hits_in_field);

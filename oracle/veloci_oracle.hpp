@@ -94,7 +94,18 @@ struct Hit {  // src/search.rs:53-57
 
 using TermIdHits = std::map<std::string, std::map<std::string, std::vector<uint32_t>>>;  // path -> term -> term ids
 
+struct Explain {  // src/search/result/explain.rs:2-21
+    enum Kind { Boost, MaxTokenToTextId, TermToAnchor, LevenshteinScore, OrSumOverDistinctTerms } kind = Boost;
+    float a = 0.0f, b = 0.0f, c = 0.0f;  // Boost(a) | TermToAnchor{term_score a, anchor_score b, final_score c} | LevenshteinScore{score a} | OrSum(a)
+    uint32_t term_id = 0;
+    std::string text;                    // LevenshteinScore.text_or_token_id
+};
+using ExplainMap = std::map<uint32_t, std::vector<Explain>>;  // FnvHashMap<u32, Vec<Explain>>: only looked up by key, never iterated for output
+std::string explain_json(const std::vector<Explain>& records);  // serde's externally tagged form, floats as %.9g
+inline bool is_explain(const RequestSearchPart& p) { return p.options && p.options->explain; }  // search_request.rs:182-184
+
 struct SearchFieldResult {  // src/search/result/field_result.rs:7-30
+    ExplainMap explain;
     std::vector<Hit> hits_scores;
     std::vector<uint32_t> hits_ids;
     std::vector<Hit> boost_ids;
@@ -105,6 +116,7 @@ struct SearchFieldResult {  // src/search/result/field_result.rs:7-30
     std::map<std::string, std::vector<std::string>> term_text_in_field;    // path -> matched term texts (why_found, :386-389)
     static SearchFieldResult new_from(const SearchFieldResult& o) {  // :42-52
         SearchFieldResult r;
+        r.explain = o.explain;  // :44 — keyed by whatever ids `o` had (term ids, when o is a dictionary result)
         r.request = o.request;
         r.phrase_boost = o.phrase_boost;
         r.term_id_hits_in_field = o.term_id_hits_in_field;
@@ -137,6 +149,7 @@ struct SearchResult {  // src/search/result/search_result.rs:9-26
     bool has_facets = false;
     std::vector<std::pair<std::string, std::vector<std::pair<std::string, uint64_t>>>> facets;  // request order
     std::map<std::string, std::vector<std::string>> why_found_terms;  // search.rs:186 (the reference's map and list orders are unspecified)
+    ExplainMap explain;                                               // search.rs:174; per hit: explain.get(&hit.id) (search.rs:86,96)
 };
 struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, Score, TermId)>
     std::string text;
@@ -270,7 +283,7 @@ std::vector<Hit> boost_text_locality_all(const Index&, TermIdHits& term_id_hits_
 // A10
 float score_expression(const std::string& expression, float rank);  // expression.rs:26-95
 void apply_boost(Hit& hit, float boost_value, float boost_param, const std::optional<BoostFunction>& f,
-                 const std::optional<std::string>& expre);  // boost.rs:283-377
+                 const std::optional<std::string>& expre, ExplainMap* explain = nullptr);  // boost.rs:283-377
 void apply_boost_values_anchor(SearchFieldResult& results, const RequestBoostPart& boost, const std::vector<Hit>& boost_values);  // boost.rs:255-281
 void add_boost(const Index&, const RequestBoostPart& boost, SearchFieldResult& hits);  // boost.rs:470-504
 // A11

@@ -54,6 +54,10 @@ def check_expectations(case, docs, info, run):
         assert i < len(ids), f"{name}: no hit {i} ({ids})"
         got = dig(docs[ids[i]], path)
         assert got == want, f"{name}: hits[{i}] is doc {ids[i]} with {path} = {got!r}, the reference asserts {want!r} (ids {ids}, scores {list(res.scores)})"
+    if "explain_len0" in exp:  # hits[0].explain.as_ref().unwrap().len()
+        assert res.explain and res.explain[0] is not None and len(res.explain[0]) == exp["explain_len0"], f"{name}: hits[0].explain {res.explain[0] if res.explain else None}"
+    if "explain_kinds0" in exp:
+        assert [next(iter(r)) for r in res.explain[0]] == exp["explain_kinds0"], f"{name}: {res.explain[0]}"
     facets = res.facets
     if facets is not None and not isinstance(facets, dict):
         facets = dict(facets)

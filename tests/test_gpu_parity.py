@@ -1293,11 +1293,52 @@ def test_query_generator_requests_match_the_reference_and_the_oracle():
             built[case["corpus"]] = (veloci_amd.Index(data, device=0), ora, docs, info)
         idx, ora, docs, info = built[case["corpus"]]
         request = dict(case["request"])
-        request.pop("explain", None)  # explain records: test_explain_records_match_the_oracle
-        res = refcases.check_expectations(dict(case, request=request), docs, info, lambda req: veloci_amd.search(req, idx))
-        assert_same(request, veloci_amd.search(request, idx), ora.search_json(json.dumps(request)))
+        res = refcases.check_expectations(case, docs, info, lambda req: veloci_amd.search(req, idx))
+        want = ora.search_json(json.dumps(request))
+        assert_same(request, res, want)
+        assert res.explain_json == (want.explain_json if request.get("explain") else "null"), case["name"]
+        request.pop("explain", None)
         for extra in ({"why_found": True}, {"top": 2, "skip": 1}):
             wide = dict(request, **extra)
             assert_same(wide, veloci_amd.search(wide, idx), ora.search_json(json.dumps(wide)))
         ran += 1
     assert ran == 23
+
+
+def test_explain_records_match_the_reference_and_the_oracle():
+    """the Explain records (src/search/result/explain.rs:2-21) of the returned hits — the reference's own assertions
+    (tests/golden/reference_explain.json), then the product's JSON == the oracle's, character for character (floats as %.9g of the f32), over
+    requests that reach every record-producing path; and what is declined is declined loudly."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    import refcases
+    import test_reference_integration as T
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    idx = veloci_amd.Index(data, device=0)
+    for case in T._load_explain()["cases"]:
+        res = refcases.check_expectations(case, docs, info, lambda req: veloci_amd.search(req, idx))
+        want = ora.search_json(json.dumps(case["request"]))
+        assert_same(case["request"], res, want)
+        assert res.explain_json == want.explain_json, case["name"]
+    reqs = T.explain_requests()
+    for req in reqs:
+        got, want = veloci_amd.search(req, idx), ora.search_json(json.dumps(req))
+        assert_same(req, got, want)
+        assert got.explain_json == want.explain_json, json.dumps(req)
+    batch = veloci_amd.search_batch(reqs + [{k: v for k, v in reqs[2].items() if k != "explain"}], idx)
+    for req, got in zip(reqs, batch):
+        assert got.explain_json == ora.search_json(json.dumps(req)).explain_json
+    assert batch[-1].explain_json == "null"
+    leaf = lambda **kw: {"search": kw}
+    declined = [
+        {"search_req": {"or": {"queries": [leaf(terms=["will"], path="meanings.eng[]", options={"explain": True}), leaf(terms=["urge"], path="meanings.eng[]")]}}},
+        {"search_req": {"or": {"queries": [leaf(terms=["will"], path="meanings.eng[]"), leaf(terms=["urge"], path="meanings.eng[]")]}}, "explain": True,
+         "phrase_boosts": [{"search1": {"terms": ["will"], "path": "meanings.eng[]"}, "search2": {"terms": ["urge"], "path": "meanings.eng[]"}}]},
+    ]
+    for req in declined:
+        with pytest.raises(veloci_amd.VelociError) as e:
+            veloci_amd.search(req, idx)
+        assert e.value.kind == "Unsupported" and "explain" in str(e.value), req

@@ -174,8 +174,69 @@ def test_oracle_reproduces_reference_query_generator_assertions():
             data.load_into(ora)
             oracles[case["corpus"]] = (ora, docs, info)
         ora, docs, info = oracles[case["corpus"]]
-        request = dict(case["request"])
-        request.pop("explain", None)  # the records are checked in test_explain (f-4); hits and scores do not depend on the flag
-        refcases.check_expectations(dict(case, request=request), docs, info, lambda req: ora.search_json(json.dumps(req)))
+        res = refcases.check_expectations(case, docs, info, lambda req: ora.search_json(json.dumps(req)))
+        if case["request"].get("explain"):  # hits and scores do not depend on the flag
+            plain = ora.search_json(json.dumps({k: v for k, v in case["request"].items() if k != "explain"}))
+            assert plain.ids.tolist() == res.ids.tolist() and plain.scores.tolist() == res.scores.tolist() and plain.explain == [None] * len(plain.ids)
         ran += 1
     assert ran == 23
+
+
+# ---------------------------------------------------------------- explain
+def _load_explain():
+    import os
+    with open(os.path.join(refcases.HERE, "golden", "reference_explain.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def explain_requests():
+    """Requests that walk every record-producing path of the reference (search_field.rs:334-343, 429-441; set_op.rs:132-137, 187-208, 421-433;
+    boost.rs:297-300, 371-374) on the `test_all` corpus — shared by the oracle's own checks and the GPU parity test."""
+    leaf = lambda **kw: {"search": kw}
+    ger, eng = "meanings.ger[]", "meanings.eng[]"
+    reqs = []
+    for top in ({}, {"top": 3, "skip": 1}):
+        reqs += [
+            dict({"search_req": leaf(terms=["majestät"], path=ger, levenshtein_distance=2), "explain": True}, **top),
+            dict({"search_req": leaf(terms=["will"], path=eng, starts_with=True, boost=2.5), "explain": True}, **top),
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=ger, levenshtein_distance=1), leaf(terms=["will"], path=eng), leaf(terms=["urge"], path=eng)]}}, "explain": True}, **top),
+            dict({"search_req": {"and": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["urge"], path=eng)]}}, "explain": True}, **top),
+            dict({"search_req": {"and": {"queries": [leaf(terms=["urge"], path=eng), leaf(terms=["will"], path=eng, levenshtein_distance=1), leaf(terms=["begeisterung"], path=ger, levenshtein_distance=1)]}},
+                  "explain": True}, **top),
+            dict({"search_req": {"or": {"queries": [{"and": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["urge"], path=eng)]}}, leaf(terms=["majestät"], path=ger),
+                                                    {"or": {"queries": [leaf(terms=["anblick"], path=ger, levenshtein_distance=1), leaf(terms=["will"], path=eng)]}}]}}, "explain": True}, **top),
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["majestät"], path=ger)]}}, "explain": True,
+                  "boost": [{"path": "commonness", "boost_fun": "Log10", "param": 1}, {"path": "commonness", "boost_fun": "Multiply", "skip_when_score": [3.0]}]}, **top),
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["majestät"], path=ger)]}}, "explain": True,
+                  "filter": {"search": {"terms": ["nice"], "path": "tags[]"}}, "boost_term": [{"terms": ["will"], "path": eng, "boost": 3.0}], "text_locality": True}, **top),
+            dict({"search_req": leaf(terms=[".*e.*"], path=ger, is_regex=True), "explain": True, "why_found": True}, **top),
+        ]
+    return reqs
+
+
+def test_oracle_reproduces_reference_explain_assertions_and_its_own_invariants():
+    from oracle import binding as O
+    fx = _load_explain()
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    for case in fx["cases"]:
+        refcases.check_expectations(case, docs, info, lambda req: ora.search_json(json.dumps(req)))
+    saw = set()
+    for req in explain_requests():
+        res = ora.search_json(json.dumps(req))
+        plain = ora.search_json(json.dumps({k: v for k, v in req.items() if k != "explain"}))
+        assert plain.ids.tolist() == res.ids.tolist() and plain.scores.tolist() == res.scores.tolist(), req
+        assert len(res.explain) == len(res.ids)
+        for recs in res.explain:
+            for r in recs or []:
+                kind = next(iter(r))
+                saw.add(kind)
+                if kind == "TermToAnchor":  # search_field.rs:426
+                    t = r[kind]
+                    assert np.float32(t["term_score"]) * np.float32(t["anchor_score"]) == np.float32(t["final_score"])
+    assert saw == {"TermToAnchor", "LevenshteinScore", "OrSumOverDistinctTerms", "Boost"}
+    # a plain single leaf: the hit's score IS the largest final_score among its records
+    res = ora.search_json(json.dumps({"search_req": {"search": {"terms": ["will"], "path": "meanings.eng[]", "levenshtein_distance": 1}}, "explain": True}))
+    for score, recs in zip(res.scores, res.explain):
+        assert np.float32(max(r["TermToAnchor"]["final_score"] for r in recs if "TermToAnchor" in r)) == score

@@ -60,6 +60,14 @@ struct vq_suggest_result {
     std::vector<SuggestEntry> e;
 };
 
+static void explain_json(std::string& s, const Result& R) {
+    s += '[';
+    for (size_t i = 0; i < R.explain.size(); ++i) {
+        if (i) s += ',';
+        s += R.explain[i].first ? explain_records_json(R.explain[i].second) : std::string("null");
+    }
+    s += ']';
+}
 static void why_found_terms_json(std::string& s, const std::map<std::string, std::vector<std::string>>& m) {
     s += '{';
     bool first = true;
@@ -267,11 +275,22 @@ const char* vq_result_to_json(const vq_result* r) {
         }
         s += '}';
     }
+    if (r->r.has_explain) {
+        s += ",\"explain\":";
+        explain_json(s, r->r);
+    }
     if (!r->r.why_found_terms.empty()) {
         s += ",\"why_found_terms\":";
         why_found_terms_json(s, r->r.why_found_terms);
     }
     s += '}';
+    return s.c_str();
+}
+const char* vq_result_explain_json(const vq_result* r) {
+    thread_local std::string s;
+    s.clear();
+    if (!r->r.has_explain) return "null";
+    explain_json(s, r->r);
     return s.c_str();
 }
 const char* vq_result_why_found_terms_json(const vq_result* r) {
@@ -328,6 +347,7 @@ static int run_batch(const vq_index* index, const vq_request* const* requests, s
         finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
     }  // (the batch's workspace is free again: deep requests scan on)
     complete_deep_requests(*index->idx, reqs.data(), n, results, st, errs);
+    complete_explain_requests(*index->idx, results, st, errs);
     for (size_t i = 0; i < n; ++i) {
         out[i] = nullptr;
         if (status) status[i] = st[i];
@@ -372,6 +392,16 @@ int vq_search_batch(const vq_index* index, const vq_request* const* requests, si
     });
 }
 
+// Explain records are produced by vq_search / vq_search_json / vq_search_batch: the flat outputs have no place for them, and on the sharded path a
+// rank only holds the postings of its own docs.
+static void decline_explain(std::vector<std::unique_ptr<Result>>& results, std::vector<int>& st, std::vector<std::string>& errs, const char* where) {
+    for (size_t i = 0; i < results.size(); ++i)
+        if (st[i] == 0 && results[i] && results[i]->explain_plan) {
+            st[i] = VQ_ERR_UNSUPPORTED;
+            errs[i] = std::string("unsupported on the MI355X query path: explain on ") + where;
+            results[i].reset();
+        }
+}
 static void copy_flat(const std::vector<std::unique_ptr<Result>>& results, const std::vector<int>& st, const std::vector<std::string>& errs, size_t base,
                       size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status) {
     for (size_t k = 0; k < results.size(); ++k) {
@@ -412,6 +442,7 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
                 finish_batch(*index->idx, *pb, nullptr, 1, results, st, errs);
             }
             complete_deep_requests(*index->idx, reqs.data(), n, results, st, errs);
+            decline_explain(results, st, errs, "the flat batch path");
             copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
             return;
         }
@@ -427,6 +458,7 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             std::vector<int> st;
             std::vector<std::string> errs;
             finish_batch(*index->idx, *inflight[c], nullptr, 1, results, st, errs);
+            decline_explain(results, st, errs, "the flat batch path");
             copy_flat(results, st, errs, bounds(c).first, stride, num_hits, counts, ids, scores, status);
             inflight[c].reset();
         };
@@ -478,6 +510,7 @@ int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
         decline_deep(results, st, errs);
+        decline_explain(results, st, errs, "the sharded partial / merge path");
         for (size_t i = 0; i < results.size(); ++i) {
             out[i] = nullptr;
             if (status) status[i] = st[i];
@@ -498,6 +531,7 @@ int vq_merge_partials_flat(const vq_index* index, vq_partial_batch* local, const
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
         decline_deep(results, st, errs);
+        decline_explain(results, st, errs, "the sharded partial / merge path");
         copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
     });
 }

@@ -133,7 +133,9 @@ struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:
     bool computed = false;
     std::vector<std::pair<uint32_t, float>> hits_scores;  // (term id, term score), ascending term id
     std::vector<uint32_t> hits_ids;                        // term ids
+    std::map<uint32_t, ExplainRecs> explain;               // options.explain: the dictionary result's records per term id (search_field.rs:334-343)
 };
+static bool part_explains(const RequestSearchPart& p) { return p.options && p.options->explain; }  // search_request.rs:182-184
 
 struct NodeInfo {
     std::string label;           // request.terms[0] carried by the node's result (set_op.rs:122,215,439)
@@ -145,6 +147,8 @@ struct NodeInfo {
     bool emitted = false;        // false: node produced no op of its own (single child / passthrough)
     uint32_t node_id = UINT32_MAX;  // preorder number inside search_req (stable between compilation passes)
     int root_op = -1;               // index of the op whose presence is this node's result
+    std::vector<int> ex_nodes;      // explain: the node(s) of the ExplainPlan behind this result (several: the members of a fused leaf) ...
+    std::vector<size_t> ex_pos;     // ... and their positions among the parent's operands
 };
 struct CountReq {
     uint32_t node_id;
@@ -169,8 +173,54 @@ struct Compiler {
     std::vector<CountReq> count_reqs;   // operands whose result sizes a count pre-pass must measure
     std::vector<CountReq> maybe_reqs;   // ... only if some OR needs the label of a two-operand AND
     bool label_wanted = false;
+    bool explain_on = false;                 // every leaf of the score tree carries options.explain (execution_plan.rs:46-85 after request.explain)
+    std::shared_ptr<ExplainPlan> xplan;
 
     Compiler(const Index& i, const Request& r, const FuzzyTable* f) : idx(i), req(r), fuzzy(f) {}
+
+    // ------------------------------------------------------------ explain plan
+    int ex_leaf(const Leaf* l) {  // l == nullptr: the empty result of an and/or without operands
+        ExplainNode n;
+        n.kind = XP_LEAF;
+        n.list_begin = uint32_t(xplan->lists.size());
+        if (l) {
+            const PostingStore& ps = posting_store(l->path);
+            for (auto& [tid, score] : l->hits_scores) {  // resolve_token_to_anchor walks the dictionary hits in this order (search_field.rs:419)
+                ExList x{};
+                if (tid < ps.num_tokens) {
+                    x.docs = ps.docs.as<uint32_t>() + ps.start[tid];
+                    x.scores = ps.scores.as<uint16_t>() + ps.start[tid];
+                    x.len = ps.len[tid];
+                }
+                x.term_score = score;
+                xplan->lists.push_back(x);
+                n.list_term.push_back(tid);
+            }
+            n.term_records = l->explain;
+        }
+        n.list_count = uint32_t(xplan->lists.size()) - n.list_begin;
+        xplan->nodes.push_back(std::move(n));
+        return int(xplan->nodes.size()) - 1;
+    }
+    void ex_emit(int node, uint32_t& depth, uint32_t& max_depth_seen) {
+        ExplainNode& n = xplan->nodes[size_t(node)];
+        ExOp op{};
+        op.kind = n.kind;
+        if (n.kind == XP_LEAF) {
+            op.a = n.list_begin;
+            op.b = n.list_count;
+        } else {
+            for (int c : n.children) ex_emit(c, depth, max_depth_seen);
+            op.nchild = uint32_t(n.children.size());
+            op.a = uint32_t(xplan->aux.size());
+            xplan->aux.insert(xplan->aux.end(), n.order.begin(), n.order.end());  // AND: summation order; OR: the operands' term slots
+            if (n.kind == XP_OR) op.b = uint32_t(*std::max_element(n.order.begin(), n.order.end())) + 1u;
+            depth -= op.nchild;
+        }
+        n.op = int(xplan->ops.size());
+        xplan->ops.push_back(op);
+        max_depth_seen = std::max(max_depth_seen, ++depth);
+    }
 
     // ------------------------------------------------------------ leaves
     void add_to_cache(const RequestSearchPart& part, bool ids_only) {  // execution_plan.rs:108-130
@@ -238,7 +288,6 @@ struct Compiler {
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
         const RequestSearchPart& p = l.part;
         if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
-        if (p.options && p.options->explain) unsupported("explain");
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
         l.path = p.path;
         if (!ends_with(l.path, TEXTINDEX)) l.path += TEXTINDEX;
@@ -307,6 +356,14 @@ struct Compiler {
                     }
                 }
                 l.hits_scores.push_back({id, score});
+                if (part_explains(p)) {  // :334-343 (kept for hits a later top-n cut drops again, as in the reference)
+                    ExplainRec e;
+                    e.kind = ExplainRec::LevenshteinScore;
+                    e.a = score;
+                    e.term_id = id;
+                    e.text = dict.terms[id];
+                    l.explain[id] = ExplainRecs{e};
+                }
             }
             if (l.return_term || l.store_term_texts)  // :347-353
                 l.terms.push_back({id, l.return_term_lowercase ? vqtext::to_lower_utf8(dict.terms[id]) : dict.terms[id]});
@@ -345,6 +402,16 @@ struct Compiler {
             if (cb.expr_op != EX_NONE) {
                 const float a = cb.expr_lkind == 0 ? v : cb.expr_lval, b = cb.expr_rkind == 0 ? v : cb.expr_rval;
                 score += cb.expr_op == EX_DIV ? a / b : cb.expr_op == EX_MUL ? a * b : cb.expr_op == EX_ADD ? a + b : a - b;
+            }
+            if (part_explains(l.part)) {  // boost.rs:297-300, 371-374
+                ExplainRec e;
+                e.kind = ExplainRec::Boost;
+                if (cb.fun == BF_LOG10) {
+                    e.a = std::log10(vp);
+                    l.explain[h.first].push_back(e);
+                }
+                e.a = score;
+                l.explain[h.first].push_back(e);
             }
             h.second = score;
         }
@@ -797,6 +864,8 @@ struct Compiler {
             Leaf& l = field_result(r.part);
             if (!is_filter) note_score_leaf(l);
             const RequestBoostPart* boost_1n = is_filter ? nullptr : find_boost_1n(r.part, boost);
+            if (boost_1n && explain_on)  // join_to_parent_ids looks the value ids' records up under the TEXT ids (search.rs:301): a panic unless the ids coincide
+                unsupported("explain with a 1:n boost (the reference panics in join_to_parent_ids, search.rs:301)");
             if (boost_1n) {  // the leaf, then a unary op that applies the per-anchor boost values
                 NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
                 leaf_info.node_id = my_id;
@@ -809,6 +878,7 @@ struct Compiler {
                 NodeInfo leaf_info = compile_leaf_scores(r, l, ops, sp);
                 leaf_info.node_id = my_id;
                 leaf_info.root_op = int(ops.size()) - 1;
+                if (explain_on) leaf_info.ex_nodes = {ex_leaf(&l)};
                 return leaf_info;
             }
             DOp op{};
@@ -841,6 +911,7 @@ struct Compiler {
             info.label_known = false;
             info.emitted = true;
             info.root_op = int(ops.size()) - 1;
+            if (explain_on && !is_filter) info.ex_nodes = {ex_leaf(nullptr)};
             return info;
         }
         // Operands of a scored OR that are plain leaves with the same term — the query generator's expansion of one term over the searched
@@ -854,7 +925,8 @@ struct Compiler {
             std::map<std::string, size_t> first_of;
             for (size_t i = 0; i < queries.size(); ++i) {
                 const SearchRequest& q = queries[i];
-                if (q.kind != SearchRequest::Search || q.part.terms.empty() || q.part.options || find_boost_1n(q.part, boost)) continue;
+                const bool own_options = q.part.options && (q.part.options->boost || q.part.options->top || q.part.options->skip);  // (explain alone changes nothing here)
+                if (q.kind != SearchRequest::Search || q.part.terms.empty() || own_options || find_boost_1n(q.part, boost)) continue;
                 auto [it, fresh] = first_of.emplace(q.part.terms[0], i);
                 fuse_with[it->second].push_back(i);
                 skip[i] = !fresh;
@@ -875,6 +947,11 @@ struct Compiler {
                     members.push_back(&l);
                 }
                 NodeInfo fused = compile_leaf_lists(q.part.terms[0], members, ops, sp);
+                if (explain_on)
+                    for (size_t k = 0; k < members.size(); ++k) {
+                        fused.ex_nodes.push_back(ex_leaf(members[k]));
+                        fused.ex_pos.push_back(fuse_with[qi][k]);
+                    }
                 fused.node_id = first_id;
                 fused.root_op = int(ops.size()) - 1;
                 ch.push_back(std::move(fused));
@@ -883,6 +960,7 @@ struct Compiler {
             std::vector<RequestBoostPart> child_boost = boost;  // merge_vec execution_plan.rs:263-270
             if (q.get_options() && q.get_options()->boost) child_boost.insert(child_boost.end(), q.get_options()->boost->begin(), q.get_options()->boost->end());
             ch.push_back(compile_node(q, is_filter, ops, sp, child_boost));
+            if (explain_on && !is_filter) ch.back().ex_pos = {qi};
             if (is_filter && ch.size() >= 2) {
                 // presence only: AND/OR are associative, fold pairwise so the stack stays shallow
                 DOp op{};
@@ -928,11 +1006,13 @@ struct Compiler {
                 // The summation order (set_op.rs:388-416) and the label of the result (:439) follow the operands' result sizes, which only
                 // exist at run time here: ask for a count pre-pass (presence only) and compile again with its numbers.
                 // (two operands: the sum of two floats does not depend on the order; only the label does, and an OR that needs it says so)
-                if (counts && n > 2) unsupported("AND whose operand sizes are still unknown after the count pre-pass (internal)");
+                // (explain: the records of the shortest operand are the ones left out, :393,:421-433 — its identity matters for two operands as well)
+                const bool sizes_needed = n > 2 || explain_on;
+                if (counts && sizes_needed) unsupported("AND whose operand sizes are still unknown after the count pre-pass (internal)");
                 if (!counts) {
-                    if (n > 2 && !idx.can_sum_over_shards())
+                    if (sizes_needed && !idx.can_sum_over_shards())
                         unsupported("AND of 3+ operands whose result sizes are only known at run time, on a sharded index without vq_index_set_allreduce");
-                    auto& dst = n > 2 ? count_reqs : maybe_reqs;
+                    auto& dst = sizes_needed ? count_reqs : maybe_reqs;
                     for (auto& c : ch)
                         if (!c.len_known) dst.push_back({c.node_id, c.root_op});
                 }
@@ -983,6 +1063,27 @@ struct Compiler {
         push_op(ops, op, sp);
         info.emitted = true;
         info.root_op = int(ops.size()) - 1;
+        if (explain_on) {
+            ExplainNode xn;
+            xn.kind = r.kind == SearchRequest::And ? XP_AND : XP_OR;
+            if (r.kind == SearchRequest::And) {
+                for (size_t i = 0; i < n; ++i) {
+                    xn.children.push_back(ch[i].ex_nodes.at(0));
+                    xn.order.push_back(op.and_order[i]);
+                }
+            } else {  // the operands in request order, every member of a fused leaf with the leaf's term slot
+                std::vector<std::tuple<size_t, int, uint16_t>> operands;
+                for (size_t i = 0; i < n; ++i)
+                    for (size_t k = 0; k < ch[i].ex_nodes.size(); ++k) operands.emplace_back(ch[i].ex_pos.at(k), ch[i].ex_nodes[k], uint16_t(op.child_slot[i]));
+                std::sort(operands.begin(), operands.end());
+                for (auto& [pos, node, slot] : operands) {
+                    xn.children.push_back(node);
+                    xn.order.push_back(slot);
+                }
+            }
+            xplan->nodes.push_back(std::move(xn));
+            info.ex_nodes = {int(xplan->nodes.size()) - 1};
+        }
         return info;
     }
 
@@ -1472,7 +1573,6 @@ struct Compiler {
     void run() {
         if (req.has_select) unsupported("select");
         if (req.why_found && req.has_select) unsupported("why_found with select (why_found_info: highlighting of the returned documents)");
-        if (req.explain) unsupported("explain");
         if (req.has_suggest) unsupported("suggest");
         if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
         const uint64_t top64 = req.top.value_or(10), skip64 = req.skip.value_or(0);  // :146
@@ -1504,6 +1604,24 @@ struct Compiler {
                 leaf(el.search2).get_ids = true;
             }
 
+        {  // explain: the reference's set operations look at the flag of ONE operand's request (set_op.rs:120,384); supported when
+           // all leaves agree — request.explain, or a single leaf with options.explain (tests/all/tests.rs:348-364)
+            size_t leaves = 0, flagged = 0;
+            std::function<void(const SearchRequest&)> walk = [&](const SearchRequest& r) {
+                if (r.kind == SearchRequest::Search) {
+                    ++leaves;
+                    flagged += part_explains(r.part) ? 1 : 0;
+                } else
+                    for (auto& q : r.tree.queries) walk(q);
+            };
+            walk(*req.search_req);
+            if (flagged && flagged != leaves) unsupported("explain on a part of the query tree");
+            explain_on = flagged != 0;
+            if (explain_on && req.phrase_boosts)  // apply_boost_from_iter records a boost or not depending on where its look-ahead rests (boost.rs:213-228): on ALL hits
+                unsupported("explain with phrase_boosts");
+            if (explain_on) xplan = std::make_shared<ExplainPlan>();
+        }
+
         // filter tree (ids only), then the score tree
         uint32_t sp = 0;
         if (req.filter) {
@@ -1530,6 +1648,14 @@ struct Compiler {
                 cq.algorithmic_bytes += 0;  // 4 B gather per hit, unknown until run time
             }
         cq.n_top_cols = uint32_t(cq.cols.size());
+        if (explain_on) {
+            xplan->root = root.ex_nodes.at(0);
+            xplan->cols = cq.cols;  // (the request-level boosts only: 1:n boosts are declined above)
+            uint32_t depth = 0, deepest = 0;
+            ex_emit(xplan->root, depth, deepest);
+            if (deepest > kExStack) unsupported("explain: more than " + std::to_string(kExStack) + " operands alive at once");
+            cq.explain_plan = xplan;
+        }
         if (!cq.leaf_cols.empty()) {  // parameters of the OP_BOOST1N ops live behind the request-level boosts
             if (cq.cols.size() + cq.leaf_cols.size() > 255) unsupported("more than 255 boosts in one query");
             for (DOp& op : cq.ops)
@@ -2015,8 +2141,47 @@ void collect_fuzzy_probes(const Index& idx, const Request& req, FuzzyTable& tabl
         for (auto& p : *req.boost_term) probe_part(idx, p, table);
 }
 
-CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts,
+// request.explain goes into the options of every part before the parts are collected — it is part of their equality (execution_plan.rs:46-106)
+static void propagate_explain(Request& request) {
+    auto merge_explain = [](std::optional<SearchRequestOptions>& o) {
+        if (!o) o = SearchRequestOptions{};
+        o->explain = true;
+    };
+    std::function<void(SearchRequest&)> walk = [&](SearchRequest& r) {
+        if (r.kind == SearchRequest::Search) merge_explain(r.part.options);
+        else {
+            merge_explain(r.tree.options);
+            for (auto& q : r.tree.queries) walk(q);
+        }
+    };
+    if (request.phrase_boosts)
+        for (auto& el : *request.phrase_boosts) {
+            merge_explain(el.search1.options);
+            merge_explain(el.search2.options);
+        }
+    if (request.search_req) walk(*request.search_req);
+    if (request.filter) walk(*request.filter);
+}
+bool request_wants_explain(const vqreq::Request& req) {
+    if (req.explain) return true;
+    bool any = false;
+    std::function<void(const SearchRequest&)> walk = [&](const SearchRequest& r) {
+        if (r.kind == SearchRequest::Search) any = any || part_explains(r.part);
+        else
+            for (auto& q : r.tree.queries) walk(q);
+    };
+    if (req.search_req) walk(*req.search_req);
+    return any;
+}
+
+CompiledQuery compile_query(const Index& idx, const vqreq::Request& req_in, const FuzzyTable* fuzzy, const UnionTable* unions, const QueryCounts* counts,
                             const RangeTable* ranges, Boost1nCache* boost_cache, const LocalityTable* localities) {
+    std::unique_ptr<Request> explained;
+    if (req_in.explain) {
+        explained = std::make_unique<Request>(req_in);
+        propagate_explain(*explained);
+    }
+    const vqreq::Request& req = explained ? *explained : req_in;
     Compiler c(idx, req, fuzzy);
     c.boost_cache = boost_cache;
     c.localities = localities;

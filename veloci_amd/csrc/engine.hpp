@@ -443,8 +443,37 @@ struct FacetOut {
     uint32_t num_values = 0;
 };
 
+// ---- explain (src/search/result/explain.rs:2-21)
+struct ExplainRec {
+    enum Kind : uint8_t { Boost, MaxTokenToTextId, TermToAnchor, LevenshteinScore, OrSumOverDistinctTerms } kind = Boost;
+    float a = 0.0f, b = 0.0f, c = 0.0f;  // Boost(a) | TermToAnchor{term_score a, anchor_score b, final_score c} | LevenshteinScore{score a} | OrSum(a)
+    uint32_t term_id = 0;
+    std::string text;  // LevenshteinScore.text_or_token_id
+};
+using ExplainRecs = std::vector<ExplainRec>;
+struct ExplainNode {  // one node of the request's score tree, as the reference executes it (no leaf fusion, no materialised unions)
+    uint32_t kind = 0;               // XP_LEAF / XP_AND / XP_OR
+    int op = -1;                     // its op in ExplainPlan::ops
+    std::vector<int> children;       // request order
+    std::vector<uint16_t> order;     // AND: the operands in summation order (set_op.rs:393), the shortest one last
+    // leaf: one list per matched term, in the order of the dictionary result's hits (search_field.rs:419)
+    uint32_t list_begin = 0, list_count = 0;
+    std::vector<uint32_t> list_term;
+    std::map<uint32_t, ExplainRecs> term_records;  // the dictionary result's explain map, keyed by TERM id (search_field.rs:336-343; field_result.rs:44 copies it
+                                                   // into the anchor-keyed result: an anchor whose id is one of these keys starts with that term's records)
+};
+struct ExplainPlan {
+    std::vector<ExplainNode> nodes;
+    int root = -1;
+    std::vector<ExList> lists;
+    std::vector<ExOp> ops;
+    std::vector<uint16_t> aux;
+    std::vector<DColBoost> cols;  // the request-level column boosts (boost.rs:470-504), request order
+};
+
 struct CompiledQuery {
     int status = 0;
+    std::shared_ptr<const ExplainPlan> explain_plan;  // request.explain: what complete_explain_requests needs for the returned hits
     std::string error;
     std::vector<RangeJob> range_requests;  // status == kStatusNeedsRanges
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
@@ -495,6 +524,10 @@ void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStrea
 struct Result;
 // Deep requests (top + skip > kMaxTopK) of an unsharded batch: results[i] holds page 0; fetch the following pages (each one scan that
 // ranks only keys below the previous page's last) and cut the requested window.
+// explain records of the returned hits (k_explain + host formatting); requests without `explain` are left alone
+void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Result>>& results, std::vector<int>& status, std::vector<std::string>& errors);
+bool request_wants_explain(const vqreq::Request& req);
+std::string explain_records_json(const ExplainRecs& records);
 void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
                             std::vector<int>& status, std::vector<std::string>& errors);
 
@@ -511,6 +544,9 @@ struct Result {
     std::vector<ResultFacet> facets;
     bool has_facets = false;
     std::map<std::string, std::vector<std::string>> why_found_terms;
+    std::shared_ptr<const ExplainPlan> explain_plan;
+    bool has_explain = false;
+    std::vector<std::pair<bool, ExplainRecs>> explain;  // per returned hit: (the reference's map has an entry for the hit, its records) — search.rs:86,96
     bool deep = false;  // holds the first page of a deep request (see CompiledQuery::deep)
     mutable std::string json;
 };

@@ -1266,6 +1266,212 @@ void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs,
     }
 }
 
+// ---- explain: Explain records of the returned hits.  k_explain recomputes each hit's score through the request's tree and
+// writes every value the records quote; what follows here is the reference's bookkeeping of WHICH records a hit collects, in which order.
+std::string explain_records_json(const ExplainRecs& records) {  // serde's externally tagged enum (explain.rs:1-21), floats as %.9g (round-trips f32)
+    auto f = [](float v) {
+        char buf[48];
+        std::snprintf(buf, sizeof buf, "%.9g", double(v));
+        return std::string(buf);
+    };
+    std::string out = "[";
+    for (size_t i = 0; i < records.size(); ++i) {
+        const ExplainRec& e = records[i];
+        if (i) out += ",";
+        switch (e.kind) {
+            case ExplainRec::Boost: out += "{\"Boost\":" + f(e.a) + "}"; break;
+            case ExplainRec::MaxTokenToTextId: out += "{\"MaxTokenToTextId\":" + f(e.a) + "}"; break;
+            case ExplainRec::OrSumOverDistinctTerms: out += "{\"OrSumOverDistinctTerms\":" + f(e.a) + "}"; break;
+            case ExplainRec::TermToAnchor:
+                out += "{\"TermToAnchor\":{\"term_score\":" + f(e.a) + ",\"anchor_score\":" + f(e.b) + ",\"final_score\":" + f(e.c) + ",\"term_id\":" + std::to_string(e.term_id) + "}}";
+                break;
+            case ExplainRec::LevenshteinScore:
+                out += "{\"LevenshteinScore\":{\"score\":" + f(e.a) + ",\"text_or_token_id\":";
+                vqjson::escape_to(out, e.text);
+                out += ",\"term_id\":" + std::to_string(e.term_id) + "}}";
+                break;
+        }
+    }
+    return out + "]";
+}
+
+namespace {
+struct ExplainEval {
+    bool has = false;  // the node's explain map holds an entry for the doc
+    ExplainRecs recs;
+};
+inline float trace_f32(uint32_t bits) {
+    float v;
+    std::memcpy(&v, &bits, 4);
+    return v;
+}
+// The explain map entry of `doc` in the result of `node` — leaf: search_field.rs:419-441 on top of field_result.rs:44; and: set_op.rs:421-433;
+// or: set_op.rs:132-137, 187-208.
+ExplainEval explain_node(const ExplainPlan& P, int node, uint32_t doc, const uint32_t* T) {
+    const ExplainNode& n = P.nodes[size_t(node)];
+    ExplainEval out;
+    if (n.kind == XP_LEAF) {
+        auto stray = n.term_records.find(doc);  // new_from() copied the dictionary result's map: `doc` may be one of its TERM ids
+        if (stray != n.term_records.end()) {
+            out.has = true;
+            out.recs = stray->second;
+        }
+        for (uint32_t j = 0; j < n.list_count; ++j) {
+            const uint32_t* t = T + 3u * (n.list_begin + j);
+            if (t[0] == 0xFFFFFFFFu) continue;
+            out.has = true;
+            ExplainRec e;
+            e.kind = ExplainRec::TermToAnchor;
+            e.term_id = n.list_term[j];
+            e.a = P.lists[n.list_begin + j].term_score;
+            e.b = trace_f32(t[1]);
+            e.c = trace_f32(t[2]);
+            out.recs.push_back(e);
+            auto tr = n.term_records.find(n.list_term[j]);
+            if (tr != n.term_records.end()) out.recs.insert(out.recs.end(), tr->second.begin(), tr->second.end());
+        }
+        return out;
+    }
+    const uint32_t* t_op = T + 3u * uint32_t(P.lists.size()) + 3u * uint32_t(n.op);
+    const bool present = t_op[0] != 0;
+    if (n.kind == XP_AND) {
+        if (!present) return out;  // the result's map only has entries of its hits
+        for (size_t k = 0; k + 1 < n.order.size(); ++k) {  // the operands left after the shortest one was taken out, in their new order (:393)
+            ExplainEval c = explain_node(P, n.children[n.order[k]], doc, T);
+            if (!c.has) continue;
+            out.has = true;
+            out.recs.insert(out.recs.end(), c.recs.begin(), c.recs.end());
+        }
+        return out;
+    }
+    std::vector<ExplainEval> ch;
+    for (int c : n.children) ch.push_back(explain_node(P, c, doc, T));
+    for (auto& c : ch)
+        if (c.has) {  // HashMap::extend (:135): a later operand's entry replaces an earlier one's
+            out.has = true;
+            out.recs = c.recs;
+        }
+    if (present) {
+        out.has = true;
+        ExplainRec e;
+        e.kind = ExplainRec::OrSumOverDistinctTerms;
+        e.a = trace_f32(t_op[2]);
+        out.recs.push_back(e);
+        for (auto& c : ch)
+            if (c.has) out.recs.insert(out.recs.end(), c.recs.begin(), c.recs.end());
+    }
+    return out;
+}
+}  // namespace
+
+void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Result>>& results, std::vector<int>& status, std::vector<std::string>& errors) {
+    std::vector<ExQuery> queries;
+    std::vector<size_t> owner;
+    std::vector<uint32_t> doc_query, docs;
+    std::vector<ExOp> ops;
+    std::vector<uint16_t> aux;
+    std::vector<ExList> lists;
+    std::vector<DColBoost> cols;
+    size_t trace_words = 0;
+    for (size_t i = 0; i < results.size(); ++i) {
+        if (status[i] != 0 || !results[i] || !results[i]->explain_plan) continue;
+        Result& R = *results[i];
+        const ExplainPlan& P = *R.explain_plan;
+        R.has_explain = true;
+        R.explain.assign(R.ids.size(), {});
+        if (R.ids.empty()) continue;
+        ExQuery q{};
+        q.op_begin = uint32_t(ops.size());
+        q.n_ops = uint32_t(P.ops.size());
+        q.list_begin = uint32_t(lists.size());
+        q.n_lists = uint32_t(P.lists.size());
+        q.col_begin = uint32_t(cols.size());
+        q.n_col = uint32_t(P.cols.size());
+        q.doc_begin = uint32_t(docs.size());
+        q.trace_begin = uint32_t(trace_words);
+        for (ExOp op : P.ops) {
+            if (op.kind != XP_LEAF) op.a += uint32_t(aux.size());
+            ops.push_back(op);
+        }
+        aux.insert(aux.end(), P.aux.begin(), P.aux.end());
+        lists.insert(lists.end(), P.lists.begin(), P.lists.end());
+        cols.insert(cols.end(), P.cols.begin(), P.cols.end());
+        docs.insert(docs.end(), R.ids.begin(), R.ids.end());
+        doc_query.insert(doc_query.end(), R.ids.size(), uint32_t(queries.size()));
+        trace_words += R.ids.size() * size_t(explain_trace_words(q.n_lists, q.n_ops, q.n_col));
+        if (trace_words > (1ull << 30)) {
+            status[i] = ERR_UNSUPPORTED;
+            errors[i] = "unsupported on the MI355X query path: explain trace of more than 4 GiB";
+            results[i].reset();
+            return;
+        }
+        queries.push_back(q);
+        owner.push_back(i);
+    }
+    if (docs.empty()) return;
+    VQ_HIP(hipSetDevice(idx.device));
+    // one upload area: [queries][doc_query][docs][ops][aux][lists][cols], then the trace
+    size_t off = 0;
+    auto place = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 64);
+        return at;
+    };
+    const size_t o_q = place(queries.size() * sizeof(ExQuery)), o_dq = place(doc_query.size() * 4), o_d = place(docs.size() * 4), o_ops = place(ops.size() * sizeof(ExOp)),
+                 o_aux = place(aux.size() * 2), o_l = place(lists.size() * sizeof(ExList)), o_c = place(cols.size() * sizeof(DColBoost));
+    std::vector<uint8_t> up(off);
+    std::memcpy(up.data() + o_q, queries.data(), queries.size() * sizeof(ExQuery));
+    std::memcpy(up.data() + o_dq, doc_query.data(), doc_query.size() * 4);
+    std::memcpy(up.data() + o_d, docs.data(), docs.size() * 4);
+    std::memcpy(up.data() + o_ops, ops.data(), ops.size() * sizeof(ExOp));
+    if (!aux.empty()) std::memcpy(up.data() + o_aux, aux.data(), aux.size() * 2);
+    if (!lists.empty()) std::memcpy(up.data() + o_l, lists.data(), lists.size() * sizeof(ExList));
+    if (!cols.empty()) std::memcpy(up.data() + o_c, cols.data(), cols.size() * sizeof(DColBoost));
+    DevBuf d_up, d_trace;
+    d_up.ensure(off);
+    d_trace.ensure(trace_words * 4);
+    hipStream_t st = idx.stream;
+    VQ_HIP(hipMemcpyAsync(d_up.p, up.data(), off, hipMemcpyHostToDevice, st));
+    const uint8_t* du = d_up.as<uint8_t>();
+    launch_explain(st, uint32_t(docs.size()), reinterpret_cast<const ExQuery*>(du + o_q), reinterpret_cast<const uint32_t*>(du + o_dq), reinterpret_cast<const uint32_t*>(du + o_d),
+                   reinterpret_cast<const ExOp*>(du + o_ops), reinterpret_cast<const uint16_t*>(du + o_aux), reinterpret_cast<const ExList*>(du + o_l),
+                   reinterpret_cast<const DColBoost*>(du + o_c), d_trace.as<uint32_t>());
+    VQ_HIP(hipGetLastError());
+    std::vector<uint32_t> trace(trace_words);
+    VQ_HIP(hipMemcpyAsync(trace.data(), d_trace.p, trace_words * 4, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    for (size_t k = 0; k < queries.size(); ++k) {
+        const ExQuery& q = queries[k];
+        Result& R = *results[owner[k]];
+        const ExplainPlan& P = *R.explain_plan;
+        const uint32_t words = explain_trace_words(q.n_lists, q.n_ops, q.n_col);
+        for (size_t h = 0; h < R.ids.size(); ++h) {
+            const uint32_t* T = trace.data() + q.trace_begin + h * size_t(words);
+            const uint32_t* t_cols = T + 3u * (q.n_lists + q.n_ops);
+            if (t_cols[3u * q.n_col] == 0) {  // a returned hit is a hit of the tree
+                status[owner[k]] = ERR_UNSUPPORTED;
+                errors[owner[k]] = "internal: explain did not reproduce hit " + std::to_string(R.ids[h]);
+                break;
+            }
+            ExplainEval e = explain_node(P, P.root, R.ids[h], T);
+            for (uint32_t c = 0; c < q.n_col; ++c) {  // add_boost (boost.rs:470-504) -> apply_boost's records (:297-300, :371-374)
+                if (t_cols[3u * c] == 0) continue;
+                e.has = true;
+                ExplainRec b;
+                b.kind = ExplainRec::Boost;
+                if (P.cols[c].fun == BF_LOG10) {
+                    b.a = trace_f32(t_cols[3u * c + 1u]);
+                    e.recs.push_back(b);
+                }
+                b.a = trace_f32(t_cols[3u * c + 2u]);
+                e.recs.push_back(b);
+            }
+            R.explain[h] = {e.has, std::move(e.recs)};
+        }
+        if (status[owner[k]] != 0) results[owner[k]].reset();
+    }
+}
+
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
                   std::vector<int>& status, std::vector<std::string>& errors) {
     const size_t n = pb.queries.size();
@@ -1370,6 +1576,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         key_off += cq.top_k;
         if (!cq.facet_out.empty()) r->has_facets = true;
         r->why_found_terms = cq.why_found_terms;
+        r->explain_plan = cq.explain_plan;
         for (size_t f = 0; f < cq.facet_out.size(); ++f, ++job) {
             const FacetOut& fo = cq.facet_out[f];
             ResultFacet rf;

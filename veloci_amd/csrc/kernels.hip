@@ -3547,4 +3547,116 @@ void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* b
                        span_keys, num_hits, hist);
 }
 
+// ------------------------------------------------------------------------------------ explain
+// One lane per returned hit: the request's score tree evaluated for that one doc from the posting lists of every matched term (binary search:
+// tens of docs, no tiles), every value the reference's Explain records quote written to the doc's trace — TermToAnchor's anchor and final score
+// (search_field.rs:426-437), OrSumOverDistinctTerms (set_op.rs:190), Boost (boost.rs:297-300, 371-374).  The host only formats the records.
+__global__ __launch_bounds__(64) void k_explain(uint32_t n_docs, const ExQuery* __restrict__ queries, const uint32_t* __restrict__ doc_query,
+                                                const uint32_t* __restrict__ docs, const ExOp* __restrict__ ops, const uint16_t* __restrict__ aux,
+                                                const ExList* __restrict__ lists, const DColBoost* __restrict__ cols, uint32_t* __restrict__ trace) {
+    const uint32_t d = blockIdx.x * 64u + threadIdx.x;
+    if (d >= n_docs) return;
+    const ExQuery Q = queries[doc_query[d]];
+    const uint32_t doc = docs[d];
+    uint32_t* T = trace + Q.trace_begin + (size_t)(d - Q.doc_begin) * explain_trace_words(Q.n_lists, Q.n_ops, Q.n_col);
+    uint32_t* T_ops = T + 3u * Q.n_lists;
+    uint32_t* T_cols = T_ops + 3u * Q.n_ops;
+    float stack[kExStack];
+    bool pres[kExStack];
+    uint32_t sp = 0;
+    for (uint32_t o = 0; o < Q.n_ops; ++o) {
+        const ExOp op = ops[Q.op_begin + o];
+        float s = 0.0f, extra = 0.0f;
+        bool present = false;
+        if (op.kind == XP_LEAF) {
+            for (uint32_t j = 0; j < op.b; ++j) {
+                const ExList L = lists[Q.list_begin + op.a + j];
+                uint32_t lo = 0, hi = L.len;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (L.docs[mid] < doc) lo = mid + 1u;
+                    else hi = mid;
+                }
+                uint32_t* t = T + 3u * (op.a + j);
+                if (lo < L.len && L.docs[lo] == doc) {
+                    const uint16_t raw = L.scores[lo];
+                    const float anchor = __half2float(__ushort_as_half(raw)) / 100.0f;  // search_field.rs:426
+                    const float v = L.term_score * anchor;
+                    t[0] = raw;
+                    t[1] = __float_as_uint(anchor);
+                    t[2] = __float_as_uint(v);
+                    if (!present || v > s) s = v;  // dedup keeps the max (search_field.rs:455-461)
+                    present = true;
+                } else {
+                    t[0] = 0xFFFFFFFFu;
+                    t[1] = 0u;
+                    t[2] = 0u;
+                }
+            }
+        } else if (op.kind == XP_AND) {
+            const uint32_t base = sp - op.nchild;
+            present = true;
+            for (uint32_t k = 0; k < op.nchild; ++k) present = present && pres[base + k];
+            if (present)
+                for (uint32_t k = 0; k < op.nchild; ++k) s += stack[base + aux[op.a + k]];  // set_op.rs:415-416, the shortest operand last
+            sp = base;
+        } else {
+            const uint32_t base = sp - op.nchild;
+            float sum = 0.0f, nd = 0.0f;
+            for (uint32_t slot = 0; slot < op.b; ++slot) {  // set_op.rs:169-186
+                float m = 0.0f;
+                for (uint32_t k = 0; k < op.nchild; ++k)
+                    if (aux[op.a + k] == slot && pres[base + k]) {
+                        present = true;
+                        m = fmaxf(m, stack[base + k]);
+                    }
+                if (m >= 0.00001f) nd += 1.0f;
+                sum += m;
+            }
+            s = sum * nd * nd;
+            extra = sum;
+            sp = base;
+        }
+        T_ops[3u * o] = present ? 1u : 0u;
+        T_ops[3u * o + 1u] = __float_as_uint(s);
+        T_ops[3u * o + 2u] = __float_as_uint(extra);
+        stack[sp] = s;
+        pres[sp] = present;
+        ++sp;
+    }
+    const bool root = sp != 0 && pres[0];
+    float score = sp != 0 ? stack[0] : 0.0f;
+    const float tree_score = score;
+    for (uint32_t k = 0; k < Q.n_col; ++k) {  // add_boost (boost.rs:470-504)
+        const DColBoost& cb = cols[Q.col_begin + k];
+        bool apply = root;
+        for (uint32_t sk = 0; sk < cb.nskip; ++sk)
+            if (fabsf(cb.skip[sk] - score) < 0.00001f) apply = false;
+        uint32_t row = 0;
+        if (apply) {
+            apply = doc >= cb.key_base && doc - cb.key_base < cb.num_keys;
+            row = doc - cb.key_base;
+        }
+        if (apply && cb.present) apply = ((cb.present[row >> 5] >> (row & 31u)) & 1u) != 0u;
+        float factor = 0.0f;
+        if (apply) {
+            const float v = cb.values[row];
+            if (cb.fun == BF_LOG10) factor = log10_f32(v + cb.param);  // boost.rs:297-300: only Log10 records its factor
+            score = apply_boost_value(score, cb, v);
+        }
+        T_cols[3u * k] = apply ? 1u : 0u;
+        T_cols[3u * k + 1u] = __float_as_uint(factor);
+        T_cols[3u * k + 2u] = __float_as_uint(score);
+    }
+    uint32_t* T_end = T_cols + 3u * Q.n_col;
+    T_end[0] = root ? 1u : 0u;
+    T_end[1] = __float_as_uint(tree_score);
+    T_end[2] = __float_as_uint(score);
+}
+void launch_explain(hipStream_t st, uint32_t n_docs, const ExQuery* queries, const uint32_t* doc_query, const uint32_t* docs, const ExOp* ops, const uint16_t* aux,
+                    const ExList* lists, const DColBoost* cols, uint32_t* trace) {
+    if (!n_docs) return;
+    hipLaunchKernelGGL(k_explain, dim3((n_docs + 63u) / 64u), dim3(64), 0, st, n_docs, queries, doc_query, docs, ops, aux, lists, cols, trace);
+}
+
 }  // namespace vq

@@ -92,6 +92,30 @@ size_t seg_sort_u32(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* o
 size_t seg_sort_u64(void* tmp, size_t tmp_bytes, const unsigned long long* in, unsigned long long* out, uint32_t n, uint32_t nseg, const uint32_t* seg_begin,
                     const uint32_t* seg_end, hipStream_t st);
 
+// ---- explain: the returned hits' scores recomputed step by step, every intermediate value written to a trace
+struct ExList {  // one posting list of one matched term (search_field.rs:419-444)
+    const uint32_t* docs;
+    const uint16_t* scores;
+    uint32_t len;
+    float term_score;
+};
+constexpr uint32_t XP_LEAF = 0, XP_AND = 1, XP_OR = 2;
+struct ExOp {  // postfix program of the request's score tree (not limited by the scan kernels' descriptor sizes)
+    uint32_t kind, nchild;
+    uint32_t a;  // LEAF: first list | AND: offset of the summation order in aux[] | OR: offset of the operands' term slots in aux[]
+    uint32_t b;  // LEAF: lists | OR: term slots
+};
+struct ExQuery {
+    uint32_t op_begin, n_ops, list_begin, n_lists, col_begin, n_col;
+    uint32_t doc_begin, trace_begin;  // first doc of the query in docs[]; first trace word of that doc
+};
+constexpr uint32_t kExStack = 256;  // operands alive at once
+// trace of one doc, 3 words per entry: lists {f16 bits or 0xFFFFFFFF, anchor score, final score}, ops {present, value, OR: sum over the term slots},
+// column boosts {applied, log10 factor, score after}, then {root present, tree score, final score}
+__host__ __device__ inline uint32_t explain_trace_words(uint32_t n_lists, uint32_t n_ops, uint32_t n_col) { return 3u * (n_lists + n_ops + n_col + 1u); }
+void launch_explain(hipStream_t st, uint32_t n_docs, const ExQuery* queries, const uint32_t* doc_query, const uint32_t* docs, const ExOp* ops, const uint16_t* aux,
+                    const ExList* lists, const DColBoost* cols, uint32_t* trace);
+
 #ifdef VQ_STAMP
 void debug_read_stamps(unsigned long long* out, int reset);
 #endif

@@ -76,6 +76,8 @@ def _take_result(L, h):
                                                                    for i in range(fl)]
         res = SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
         res.why_found_terms = json.loads(L.vq_result_why_found_terms_json(h).decode())
+        res.explain_json = L.vq_result_explain_json(h).decode()  # per hit: null or its Explain records (src/search.rs:86,96); "null" without `explain`
+        res.explain = json.loads(res.explain_json)
         return res
     finally:
         L.vq_result_free(h)
