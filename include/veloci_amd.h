@@ -146,6 +146,13 @@ typedef struct vq_request vq_request;
 
 int vq_request_parse(const char* json, size_t len, vq_request** out);
 void vq_request_free(vq_request*);
+/* What the parser understood: every field of search::Request (src/search/request/mod.rs:15-87, search_request.rs:6-179, boost_request.rs:4-33,
+ * facet_request.rs:2-11) in declaration order, absent Options as null, `select` / `snippet_info` as "present" booleans, f32 values as their bit
+ * patterns (u32).  Pinned by tests/golden/request_parse.json against an independent restatement of serde's rules.  Thread-local string. */
+const char* vq_request_to_json(const vq_request*);
+/* str::to_lowercase as the dictionary side applies it (src/search/search_field.rs:284,312).  Returns the byte length written to `out`, or
+ * (size_t)-1 when `cap` is too small.  Diagnostic: swept over every code point by tests/test_request_parse.py. */
+size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap);
 
 /* ---------------------------------------------------------------- results
  *

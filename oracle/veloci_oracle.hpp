@@ -14,6 +14,12 @@
 //   * itertools 0.12 kmerge_by           -> binary-heap k-way merge (tie order restated)
 //   * half 2.3.1                         -> IEEE binary16 round-to-nearest-even
 //   * fst 0.4.7                          -> sorted string table, ordinal == term id
+//
+// Shared with the product, and pinned on its own because of that: the request structs + JSON parser (request.hpp, json.hpp) and the Unicode
+// lowercasing table (text.hpp) are included from veloci_amd/csrc — data-format plumbing, no query arithmetic.  A defect there would be
+// invisible to product-vs-oracle parity, so tests/test_request_parse.py checks the parser against tests/golden/request_parse.json (what serde
+// makes of 140+ request texts, derived by an independent restatement over Python's json module, tests/reqparse.py) and sweeps the lowercasing
+// over every code point against Python's str.lower.
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -1,0 +1,80 @@
+"""The request parser against golden fixtures derived WITHOUT it: tests/golden/request_parse.json holds request texts and what
+serde's derive(Deserialize) makes of them, restated over Python's json module (tests/reqparse.py).  The product's parser — which the oracle shares —
+must understand every text the same way (vq_request_to_json) and reject what serde_json rejects.  Also: the Unicode lowercasing both sides share
+(veloci_amd/csrc/text.hpp) against Python's str.lower over every code point."""
+import ctypes as C
+import json
+import os
+import unicodedata
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cases():
+    with open(os.path.join(HERE, "golden", "request_parse.json"), encoding="utf-8") as f:
+        return json.load(f)["cases"]
+
+
+def _parse(L, text):
+    h = C.c_void_p()
+    raw = text.encode("utf-8")
+    rc = L.vq_request_parse(raw, len(raw), C.byref(h))
+    if rc != 0:
+        return rc, L.vq_last_error().decode("utf-8", "replace")
+    try:
+        return 0, L.vq_request_to_json(h).decode("utf-8")
+    finally:
+        L.vq_request_free(h)
+
+
+def test_fixture_is_reproducible_from_the_restatement():
+    import reqparse
+    for c in _cases():
+        if "error" in c:
+            with pytest.raises(reqparse.ParseError):
+                reqparse.canonical(c["text"])
+        else:
+            assert reqparse.canonical(c["text"]) == c["parsed"]
+
+
+def test_parser_understands_every_fixture_as_serde_does():
+    from veloci_amd import _lib
+    L = _lib.lib()
+    cases = _cases()
+    assert len(cases) > 120 and sum(1 for c in cases if "error" in c) >= 25
+    for c in cases:
+        rc, out = _parse(L, c["text"])
+        if "error" in c:
+            assert rc == 7, (c["text"], rc, out)  # VQ_ERR_JSON
+        else:
+            assert rc == 0, (c["text"], out)
+            assert out == c["parsed"], c["text"]
+
+
+def test_lowercasing_agrees_with_an_independent_implementation_on_every_code_point():
+    """str::to_lowercase (search_field.rs:284,312) as text.hpp implements it vs Python's str.lower — both follow UnicodeData's simple mappings plus
+    SpecialCasing's unconditional U+0130.  Differences are allowed only where the two Unicode versions differ (listed, not silently skipped) and for
+    the context-sensitive final sigma, which text.hpp documents it does not reproduce."""
+    from veloci_amd import _lib
+    L = _lib.lib()
+    buf = C.create_string_buffer(64)
+
+    def low(s):
+        raw = s.encode("utf-8")
+        n = L.vq_debug_to_lowercase(raw, len(raw), buf, 64)
+        assert n != C.c_size_t(-1).value
+        return buf.raw[:n].decode("utf-8")
+
+    differ = []
+    for cp in range(0x110000):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        ch = chr(cp)
+        if low(ch) != ch.lower():
+            differ.append(cp)
+    # code points whose lowercase mapping this interpreter's Unicode tables (unicodedata.unidata_version) do not have yet, or have since gained
+    assert all(unicodedata.category(chr(cp)) in ("Cn", "Lu", "Lt", "Ll", "Lo") for cp in differ) and len(differ) <= 64, [hex(c) for c in differ[:80]]
+    assert low("AbÇ ΔΣ İ") in ("abç δσ i̇", "abç δς i̇")  # final sigma: Rust lowercases a word-final Σ to ς; text.hpp always gives σ
+    assert low("STRASSE ẞ Ǆ") == "strasse ß ǆ"

@@ -6,6 +6,7 @@
 
 #include "../../include/veloci_amd.h"
 #include "engine.hpp"
+#include "text.hpp"
 
 using namespace vq;
 using vqreq::Request;
@@ -84,6 +85,135 @@ static void why_found_terms_json(std::string& s, const std::map<std::string, std
     }
     s += '}';
 }
+
+// ---- canonical dump of a parsed request: every field of search::Request in declaration order, absent options as null, f32 values as their bit
+// patterns — what the parser understood, for the golden request-parse fixtures (tests/golden/request_parse.json)
+namespace {
+void dump_f32(std::string& s, float f) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    s += std::to_string(b);
+}
+template <class T, class F>
+void dump_opt(std::string& s, const std::optional<T>& v, F f) {
+    if (v) f(s, *v);
+    else s += "null";
+}
+void dump_usize(std::string& s, size_t v) { s += std::to_string(v); }
+void dump_bool(std::string& s, bool v) { s += v ? "true" : "false"; }
+void dump_str(std::string& s, const std::string& v) { vqjson::escape_to(s, v); }
+void dump_boost_part(std::string& s, const vqreq::RequestBoostPart& b) {
+    static const char* const names[] = {"Log2", "Log10", "Multiply", "Add", "Replace"};
+    s += "{\"path\":";
+    dump_str(s, b.path);
+    s += ",\"boost_fun\":";
+    if (b.boost_fun) s += std::string("\"") + names[int(*b.boost_fun)] + "\"";
+    else s += "null";
+    s += ",\"param\":";
+    dump_opt(s, b.param, dump_f32);
+    s += ",\"skip_when_score\":";
+    if (b.skip_when_score) {
+        s += '[';
+        for (size_t i = 0; i < b.skip_when_score->size(); ++i) {
+            if (i) s += ',';
+            dump_f32(s, (*b.skip_when_score)[i]);
+        }
+        s += ']';
+    } else s += "null";
+    s += ",\"expression\":";
+    dump_opt(s, b.expression, dump_str);
+    s += '}';
+}
+void dump_boost_list(std::string& s, const std::optional<std::vector<vqreq::RequestBoostPart>>& v) {
+    if (!v) {
+        s += "null";
+        return;
+    }
+    s += '[';
+    for (size_t i = 0; i < v->size(); ++i) {
+        if (i) s += ',';
+        dump_boost_part(s, (*v)[i]);
+    }
+    s += ']';
+}
+void dump_options(std::string& s, const std::optional<vqreq::SearchRequestOptions>& o) {
+    if (!o) {
+        s += "null";
+        return;
+    }
+    s += "{\"explain\":";
+    dump_bool(s, o->explain);
+    s += ",\"top\":";
+    dump_opt(s, o->top, dump_usize);
+    s += ",\"skip\":";
+    dump_opt(s, o->skip, dump_usize);
+    s += ",\"boost\":";
+    dump_boost_list(s, o->boost);
+    s += '}';
+}
+void dump_part(std::string& s, const vqreq::RequestSearchPart& p) {
+    s += "{\"path\":";
+    dump_str(s, p.path);
+    s += ",\"terms\":[";
+    for (size_t i = 0; i < p.terms.size(); ++i) {
+        if (i) s += ',';
+        dump_str(s, p.terms[i]);
+    }
+    s += "],\"levenshtein_distance\":";
+    if (p.levenshtein_distance) s += std::to_string(*p.levenshtein_distance);
+    else s += "null";
+    s += ",\"starts_with\":";
+    dump_bool(s, p.starts_with);
+    s += ",\"is_regex\":";
+    dump_bool(s, p.is_regex);
+    s += ",\"token_value\":";
+    if (p.token_value) dump_boost_part(s, *p.token_value);
+    else s += "null";
+    s += ",\"boost\":";
+    dump_opt(s, p.boost, dump_f32);
+    s += ",\"ignore_case\":";
+    dump_opt(s, p.ignore_case, dump_bool);
+    s += ",\"snippet\":";
+    dump_opt(s, p.snippet, dump_bool);
+    s += ",\"snippet_info\":";
+    dump_bool(s, p.has_snippet_info);
+    s += ",\"top\":";
+    dump_opt(s, p.top, dump_usize);
+    s += ",\"skip\":";
+    dump_opt(s, p.skip, dump_usize);
+    s += ",\"options\":";
+    dump_options(s, p.options);
+    s += '}';
+}
+void dump_search_request(std::string& s, const vqreq::SearchRequest& r) {
+    if (r.kind == vqreq::SearchRequest::Search) {
+        s += "{\"search\":";
+        dump_part(s, r.part);
+        s += '}';
+        return;
+    }
+    s += r.kind == vqreq::SearchRequest::Or ? "{\"or\":{\"queries\":[" : "{\"and\":{\"queries\":[";
+    for (size_t i = 0; i < r.tree.queries.size(); ++i) {
+        if (i) s += ',';
+        dump_search_request(s, r.tree.queries[i]);
+    }
+    s += "],\"options\":";
+    dump_options(s, r.tree.options);
+    s += "}}";
+}
+void dump_parts(std::string& s, const std::optional<std::vector<vqreq::RequestSearchPart>>& v) {
+    if (!v) {
+        s += "null";
+        return;
+    }
+    s += '[';
+    for (size_t i = 0; i < v->size(); ++i) {
+        if (i) s += ',';
+        dump_part(s, (*v)[i]);
+    }
+    s += ']';
+}
+}  // namespace
 
 extern "C" {
 
@@ -234,6 +364,72 @@ int vq_request_parse(const char* json, size_t len, vq_request** out) {
         }
         *out = r;
     });
+}
+const char* vq_request_to_json(const vq_request* r) {
+    thread_local std::string s;
+    s.clear();
+    if (!r) return "null";
+    const Request& q = r->req;
+    s += "{\"search_req\":";
+    if (q.search_req) dump_search_request(s, *q.search_req);
+    else s += "null";
+    s += ",\"suggest\":";
+    dump_parts(s, q.suggest);
+    s += ",\"boost\":";
+    dump_boost_list(s, q.boost);
+    s += ",\"boost_term\":";
+    dump_parts(s, q.boost_term);
+    s += ",\"facets\":";
+    if (q.facets) {
+        s += '[';
+        for (size_t i = 0; i < q.facets->size(); ++i) {
+            if (i) s += ',';
+            s += "{\"field\":";
+            dump_str(s, (*q.facets)[i].field);
+            s += ",\"top\":";
+            dump_opt(s, (*q.facets)[i].top, dump_usize);
+            s += '}';
+        }
+        s += ']';
+    } else s += "null";
+    s += ",\"phrase_boosts\":";
+    if (q.phrase_boosts) {
+        s += '[';
+        for (size_t i = 0; i < q.phrase_boosts->size(); ++i) {
+            if (i) s += ',';
+            s += "{\"search1\":";
+            dump_part(s, (*q.phrase_boosts)[i].search1);
+            s += ",\"search2\":";
+            dump_part(s, (*q.phrase_boosts)[i].search2);
+            s += '}';
+        }
+        s += ']';
+    } else s += "null";
+    s += ",\"select\":";
+    dump_bool(s, q.has_select);
+    s += ",\"filter\":";
+    if (q.filter) dump_search_request(s, *q.filter);
+    else s += "null";
+    s += ",\"top\":";
+    dump_opt(s, q.top, dump_usize);
+    s += ",\"skip\":";
+    dump_opt(s, q.skip, dump_usize);
+    s += ",\"why_found\":";
+    dump_bool(s, q.why_found);
+    s += ",\"text_locality\":";
+    dump_bool(s, q.text_locality);
+    s += ",\"explain\":";
+    dump_bool(s, q.explain);
+    s += '}';
+    return s.c_str();
+}
+// Unicode lowercasing as the dictionary side applies it (str::to_lowercase, search_field.rs:284,312): for the code-point sweep against an
+// independent implementation (tests/test_request_parse.py).  Returns the length, or (size_t)-1 when `cap` is too small.
+size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap) {
+    const std::string low = vqtext::to_lower_utf8(std::string(utf8 ? utf8 : "", utf8 ? len : 0));
+    if (low.size() > cap) return size_t(-1);
+    std::memcpy(out, low.data(), low.size());
+    return low.size();
 }
 void vq_request_free(vq_request* r) { delete r; }
 

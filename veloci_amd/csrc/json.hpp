@@ -25,7 +25,7 @@ struct Value {
     bool is_integer = false;
     std::string str;
     std::vector<Value> arr;
-    std::vector<Member> obj;  // insertion order kept; duplicate keys: last wins on lookup (serde errors; we are lenient)
+    std::vector<Member> obj;  // insertion order kept; a key looked up by get() must be unique (serde: "duplicate field")
 
     bool is_null() const { return kind == Null; }
     bool is_object() const { return kind == Object; }
@@ -34,19 +34,24 @@ struct Value {
     bool is_number() const { return kind == Number; }
     bool is_bool() const { return kind == Bool; }
 
-    const Value* get(const char* key) const {
-        if (kind != Object) return nullptr;
-        const Value* found = nullptr;
-        for (const auto& m : obj)
-            if (m.first == key) found = &m.second;
-        return found;
-    }
+    inline const Value* get(const char* key) const;
 };
 
 struct ParseError : std::runtime_error {
     size_t pos;
     ParseError(const std::string& m, size_t p) : std::runtime_error(m), pos(p) {}
 };
+// a field of a struct: serde's derive rejects a second occurrence of a KNOWN field (unknown keys are skipped, duplicated or not)
+inline const Value* Value::get(const char* key) const {
+    if (kind != Object) return nullptr;
+    const Value* found = nullptr;
+    for (const auto& m : obj)
+        if (m.first == key) {
+            if (found) throw ParseError(std::string("duplicate field `") + key + "`", 0);
+            found = &m.second;
+        }
+    return found;
+}
 
 class Parser {
 public:
@@ -155,6 +160,7 @@ private:
         bool integer = true;
         if (i_ < n_ && s_[i_] == '-') ++i_;
         if (i_ >= n_ || !(s_[i_] >= '0' && s_[i_] <= '9')) fail("bad number");
+        if (s_[i_] == '0' && i_ + 1 < n_ && s_[i_ + 1] >= '0' && s_[i_ + 1] <= '9') fail("bad number: leading zero");  // RFC 8259 int = zero / digit1-9 *DIGIT
         while (i_ < n_ && s_[i_] >= '0' && s_[i_] <= '9') ++i_;
         if (i_ < n_ && s_[i_] == '.') {
             integer = false;

@@ -245,7 +245,11 @@ inline RequestSearchPart search_part_from_json(const vqjson::Value& v) {
     if (!terms) json_fail("missing field `terms`");
     if (!terms->is_array()) json_fail("terms: expected a sequence");
     for (auto& t : terms->arr) p.terms.push_back(j_string(t, "terms"));
-    if (const vqjson::Value* l = v.get("levenshtein_distance"); l && !l->is_null()) p.levenshtein_distance = uint32_t(j_usize(*l, "levenshtein_distance"));
+    if (const vqjson::Value* l = v.get("levenshtein_distance"); l && !l->is_null()) {
+        const size_t d = j_usize(*l, "levenshtein_distance");
+        if (d > 0xFFFFFFFFull) json_fail("invalid value for levenshtein_distance, expected u32");
+        p.levenshtein_distance = uint32_t(d);
+    }
     if (const vqjson::Value* s = v.get("starts_with"); s) p.starts_with = j_bool(*s, "starts_with");
     if (const vqjson::Value* s = v.get("is_regex"); s) p.is_regex = j_bool(*s, "is_regex");
     if (const vqjson::Value* t = v.get("token_value"); t && !t->is_null()) p.token_value = boost_part_from_json(*t);
@@ -334,7 +338,11 @@ inline Request request_from_json(const vqjson::Value& v) {
         }
         r.phrase_boosts = out;
     }
-    if (const vqjson::Value* s = v.get("select"); s && !s->is_null()) r.has_select = true;
+    if (const vqjson::Value* s = v.get("select"); s && !s->is_null()) {  // Option<Vec<String>>
+        if (!s->is_array()) json_fail("select: expected a sequence");
+        for (auto& e : s->arr) (void)j_string(e, "select");
+        r.has_select = true;
+    }
     if (const vqjson::Value* f = v.get("filter"); f && !f->is_null()) r.filter = search_request_from_json(*f);
     if (const vqjson::Value* t = v.get("top"); t) {
         if (t->is_null()) r.top = std::nullopt;
