@@ -247,6 +247,19 @@ int vq_merge_partials(const vq_index*, vq_partial_batch* local, const void* gath
 /* Same merge with flat output (see vq_search_batch_flat). */
 int vq_merge_partials_flat(const vq_index*, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t stride,
                            uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status);
+/* One collective per step while the step still runs as a pipeline of chunks (the host compiles chunk c+1 while the GPU scans chunk c):
+ * every chunk is searched with `vq_search_batch_partial_at` into its own workspace `slot` (0 .. vq_partial_slots()-1) with its partial placed at
+ * `arena_offset` of the index's partial arena (`vq_index_partial_arena_ptr`; offsets are multiples of 256, chunk c+1 starts at
+ * arena_offset_c + round_up(vq_partial_total_bytes(chunk c), 256); VQ_ERR_UNSUPPORTED when the arena — 64 MiB — is too small).  The caller
+ * all-gathers the arena's used prefix [0, S) ONCE, then merges every chunk with `vq_merge_partials_flat_strided(gathered + arena_offset_c,
+ * num_shards, shard_stride = S)`.  Chunks with facet histograms still need their all-reduce (vq_partial_hist_*), so a caller would keep such
+ * steps on the per-chunk path. */
+int vq_search_batch_partial_at(const vq_index*, const vq_request* const* requests, size_t n, int slot, size_t arena_offset, vq_partial_batch** out);
+int vq_partial_slots(void);
+void* vq_index_partial_arena_ptr(const vq_index*);
+size_t vq_partial_total_bytes(const vq_partial_batch*);
+int vq_merge_partials_flat_strided(const vq_index*, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t shard_stride,
+                                   size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status);
 void vq_partial_free(vq_partial_batch*);
 
 /* ------------------------------------------------------------ measurement */

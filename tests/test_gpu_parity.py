@@ -1218,9 +1218,23 @@ def test_rccl_collective_path_with_one_rank(corpus):
                 assert np.array_equal(np.asarray(g.scores, np.float32).view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
                 assert sorted(map(repr, (g.facets or {}).items())) == sorted(map(repr, (w.facets or {}).items()))
         plain = [r for r in reqs if "facets" not in r]
-        f_got = searcher.search_batch_flat(plain * 8, stride=25)  # >= 512 requests: the chunked pipeline, one all-gather per chunk
         f_want = veloci_amd.search_batch_flat(plain * 8, idx, stride=25)
-        for a, b in zip(f_got, f_want):
+        for per_chunk in (False, True, False):  # >= 512 requests: a pipeline of 4 chunks — their partials in the arena and ONE all-gather; or one per chunk
+            if per_chunk:
+                os.environ["VQ_PER_CHUNK_COLLECTIVE"] = "1"
+            else:
+                os.environ.pop("VQ_PER_CHUNK_COLLECTIVE", None)
+            f_got = searcher.search_batch_flat(plain * 8, stride=25)
+            for a, b in zip(f_got, f_want):
+                assert np.array_equal(a, b)
+        for chunks in (2, 3):
+            for a, b in zip(searcher.search_batch_flat(plain * 8, stride=25, chunks=chunks), f_want):
+                assert np.array_equal(a, b)
+        # chunks with facet histograms fall back to the per-chunk exchange (all-gather + all-reduce each)
+        with_facets = (reqs * 6)[:560]
+        m_got = searcher.search_batch_flat(with_facets, stride=25)
+        m_want = veloci_amd.search_batch_flat(with_facets, idx, stride=25)
+        for a, b in zip(m_got, m_want):
             assert np.array_equal(a, b)
         v = np.array([1, 2, 2**40 + 7], dtype=np.uint64)
         searcher._sum_over_ranks(v)

@@ -20,6 +20,7 @@ SYMBOLS = [
     "vq_suggest_json", "vq_suggest_len", "vq_suggest_text", "vq_suggest_score", "vq_suggest_term_id", "vq_suggest_free",
     "vq_search_batch", "vq_search_batch_flat", "vq_search_batch_partial", "vq_partial_bytes", "vq_partial_device_ptr", "vq_partial_hist_bytes",
     "vq_partial_hist_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
+    "vq_search_batch_partial_at", "vq_partial_slots", "vq_index_partial_arena_ptr", "vq_partial_total_bytes", "vq_merge_partials_flat_strided",
     "vq_profile_read", "vq_profile_enable", "vq_profile_json", "vq_debug_div100_mismatches", "vq_version",
 ]
 
@@ -109,6 +110,11 @@ def lib():
         "vq_merge_partials": (i, [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(i)]),
         "vq_merge_partials_flat": (i, [vp, vp, vp, u32, sz, vp, vp, vp, vp, vp]),
         "vq_partial_free": (None, [vp]),
+        "vq_search_batch_partial_at": (i, [vp, C.POINTER(vp), sz, i, sz, C.POINTER(vp)]),
+        "vq_partial_slots": (i, []),
+        "vq_index_partial_arena_ptr": (vp, [vp]),
+        "vq_partial_total_bytes": (sz, [vp]),
+        "vq_merge_partials_flat_strided": (i, [vp, vp, vp, u32, sz, sz, vp, vp, vp, vp, vp]),
         "vq_profile_read": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
         "vq_profile_enable": (i, [vp, i]),
     }

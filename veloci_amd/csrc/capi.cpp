@@ -326,7 +326,8 @@ void vq_index_free(vq_index* i) { delete i; }
 int vq_index_set_stream(vq_index* i, void* hip_stream) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_stream: null index");
-        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
+        std::vector<std::unique_lock<std::mutex>> quiet;  // no batch in flight
+        for (auto& w : i->idx->ws) quiet.emplace_back(w.mu);
         i->idx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_stream;
         i->idx->fin_stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : i->idx->own_fin_stream;
     });
@@ -335,7 +336,8 @@ int vq_index_set_streams(vq_index* i, void* scan_stream, void* finish_stream) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_streams: null index");
         if (!scan_stream || !finish_stream) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_streams: null stream (vq_index_set_stream(index, NULL) restores the index's own)");
-        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
+        std::vector<std::unique_lock<std::mutex>> quiet;  // no batch in flight
+        for (auto& w : i->idx->ws) quiet.emplace_back(w.mu);
         i->idx->stream = static_cast<hipStream_t>(scan_stream);
         i->idx->fin_stream = static_cast<hipStream_t>(finish_stream);
     });
@@ -343,7 +345,8 @@ int vq_index_set_streams(vq_index* i, void* scan_stream, void* finish_stream) {
 int vq_index_set_allreduce(vq_index* i, vq_allreduce_u64_fn fn, void* ctx) {
     return guard([&] {
         if (!i) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_index_set_allreduce: null index");
-        std::unique_lock<std::mutex> g0(i->idx->ws[0].mu), g1(i->idx->ws[1].mu);  // no batch in flight
+        std::vector<std::unique_lock<std::mutex>> quiet;  // no batch in flight
+        for (auto& w : i->idx->ws) quiet.emplace_back(w.mu);
         i->idx->allreduce_fn = fn;
         i->idx->allreduce_ctx = ctx;
     });
@@ -683,6 +686,33 @@ int vq_search_batch_partial(const vq_index* index, const vq_request* const* requ
         *out = h;
     });
 }
+// A chunk of a sharded step whose chunks share ONE collective: workspace `slot` (0 .. VQ_PARTIAL_SLOTS-1, one per chunk in flight), partial placed at
+// `arena_offset` (a multiple of 256) of the index's partial arena.
+int vq_search_batch_partial_at(const vq_index* index, const vq_request* const* requests, size_t n, int slot, size_t arena_offset, vq_partial_batch** out) {
+    return guard([&] {
+        if (!index || !out || (n && !requests)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_partial_at: null argument");
+        if (slot < 0 || slot >= vq::kWorkspaces) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_search_batch_partial_at: slot out of range");
+        *out = nullptr;
+        std::vector<const Request*> reqs(n);
+        for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
+        auto pb = run_partial(*index->idx, reqs.data(), n, slot, int64_t(arena_offset));
+        if (index->idx->stream == index->idx->own_stream) VQ_HIP(hipStreamSynchronize(index->idx->stream));
+        auto* h = new vq_partial_batch();
+        h->pb = std::move(pb);
+        *out = h;
+    });
+}
+int vq_partial_slots(void) { return vq::kWorkspaces; }
+void* vq_index_partial_arena_ptr(const vq_index* i) {
+    if (!i) return nullptr;
+    if (guard([&] {
+            VQ_HIP(hipSetDevice(i->idx->device));
+            i->idx->arena.ensure(vq::Index::kArenaBytes);
+        }) != 0)
+        return nullptr;
+    return i->idx->arena.p;
+}
+size_t vq_partial_total_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.bytes) : 0; }
 size_t vq_partial_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.off_hist) : 0; }
 void* vq_partial_device_ptr(vq_partial_batch* p) { return p ? p->pb->d_partial : nullptr; }
 size_t vq_partial_hist_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.total_hist) * 4 : 0; }
@@ -726,6 +756,19 @@ int vq_merge_partials_flat(const vq_index* index, vq_partial_batch* local, const
         std::vector<int> st;
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
+        decline_deep(results, st, errs);
+        decline_explain(results, st, errs, "the sharded partial / merge path");
+        copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);
+    });
+}
+int vq_merge_partials_flat_strided(const vq_index* index, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t shard_stride,
+                                   size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status) {
+    return guard([&] {
+        if (!index || !local || !num_hits || !counts || !ids || !scores) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_merge_partials_flat_strided: null argument");
+        std::vector<std::unique_ptr<Result>> results;
+        std::vector<int> st;
+        std::vector<std::string> errs;
+        finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs, shard_stride);
         decline_deep(results, st, errs);
         decline_explain(results, st, errs, "the sharded partial / merge path");
         copy_flat(results, st, errs, 0, stride, num_hits, counts, ids, scores, status);

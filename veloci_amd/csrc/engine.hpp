@@ -19,6 +19,7 @@
 #include "device_types.hpp"
 #include "kernels.hpp"
 #include "request.hpp"
+#include "hostpool.hpp"
 
 namespace vq {
 
@@ -303,7 +304,7 @@ struct PinnedBuf {  // page-locked host staging
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-constexpr int kWorkspaces = 2;  // batches in flight per index (host compile of one overlaps the scan of the other)
+constexpr int kWorkspaces = 4;  // batches in flight per index (host compile of one overlaps the scan of the others; the chunks of one sharded step: one each)
 
 // Kernels the profiler accounts separately (vq_profile_json): the pre-passes, one entry per scan class, the merges.
 enum KernelId : int {
@@ -361,21 +362,6 @@ struct LaunchTimer {
 
 // A few persistent host threads for the per-request work of a batch (query compilation): spawning threads per chunk costs more
 // than compiling a small chunk.
-class HostPool {
-public:
-    explicit HostPool(size_t workers);
-    ~HostPool();
-    void run(size_t parts, const std::function<void(size_t)>& fn);  // fn(0..parts-1), the caller takes part; returns when all are done
-private:
-    void worker();
-    std::vector<std::thread> threads_;
-    std::mutex mu_, run_mu_;
-    std::condition_variable cv_start_, cv_done_;
-    const std::function<void(size_t)>* fn_ = nullptr;
-    size_t parts_ = 0, next_ = 0, pending_ = 0;
-    uint64_t generation_ = 0;
-    bool stop_ = false;
-};
 
 struct Index {
     int device = 0;
@@ -414,6 +400,11 @@ struct Index {
     mutable Profile profile;
     mutable Workspace ws[kWorkspaces];
     mutable std::atomic<uint32_t> next_ws{0};
+    // Sharded step run as a pipeline of chunks with ONE collective: the chunks' partials are placed back to back in this arena (run_partial's
+    // arena_offset), so a single all-gather of its used prefix exchanges them all; every chunk then merges out of the gathered copy with the
+    // prefix's size as the shard stride.  Fixed size: a step that does not fit is told so and takes the per-chunk path.
+    mutable DevBuf arena;
+    static constexpr size_t kArenaBytes = 64ull << 20;
     ~Index();
     bool is_anchor_identity(const std::string& textindex_path) const;
 };
@@ -573,8 +564,9 @@ struct PartialBatch {
     std::chrono::steady_clock::time_point t0;
 };
 
-std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot = -1);
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot = -1, int64_t arena_offset = -1);
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
-                  std::vector<int>& status, std::vector<std::string>& errors);
+                  std::vector<int>& status, std::vector<std::string>& errors, size_t shard_stride = 0);  // shard_stride: bytes between the shards'
+                                                                                                         // copies in `gathered_device` (0: the partial's own size)
 
 }  // namespace vq

@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "engine.hpp"
+
 #include "text.hpp"
 
 namespace vq {
@@ -54,53 +55,6 @@ LaunchTimer::~LaunchTimer() {
     if (ws) (void)hipEventRecord(ws->ev_pool[ws->timed[slot].ev_end], st);
 }
 
-HostPool::HostPool(size_t workers) {
-    for (size_t i = 0; i < workers; ++i) threads_.emplace_back([this] { worker(); });
-}
-HostPool::~HostPool() {
-    {
-        std::lock_guard<std::mutex> g(mu_);
-        stop_ = true;
-    }
-    cv_start_.notify_all();
-    for (auto& t : threads_) t.join();
-}
-void HostPool::worker() {
-    uint64_t seen = 0;
-    while (true) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_start_.wait(lk, [&] { return stop_ || generation_ != seen; });
-        if (stop_) return;
-        seen = generation_;
-        while (next_ < parts_) {
-            const size_t part = next_++;
-            lk.unlock();
-            (*fn_)(part);
-            lk.lock();
-            if (--pending_ == 0) cv_done_.notify_all();
-        }
-    }
-}
-void HostPool::run(size_t parts, const std::function<void(size_t)>& fn) {
-    if (parts == 0) return;
-    std::lock_guard<std::mutex> one(run_mu_);
-    std::unique_lock<std::mutex> lk(mu_);
-    fn_ = &fn;
-    parts_ = parts;
-    next_ = 0;
-    pending_ = parts;
-    ++generation_;
-    cv_start_.notify_all();
-    while (next_ < parts_) {  // the caller works too
-        const size_t part = next_++;
-        lk.unlock();
-        fn(part);
-        lk.lock();
-        --pending_;
-    }
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-}
 // host threads per index for request compilation (the caller counts as one): VQ_HOST_THREADS, else the machine's, at most 16 (a GPU's share of
 // the host on an 8-GPU node)
 static size_t host_threads() {
@@ -733,7 +687,7 @@ static bool timing_enabled() {
 }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot) {
+std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot, int64_t arena_offset) {
     const double t_start = now_ms();
     auto pb = std::make_unique<PartialBatch>();
     pb->index = &idx;
@@ -769,7 +723,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
-        const size_t parts = std::min<size_t>(2 * host_threads(), n / 16);  // (parts are pulled dynamically: uneven requests balance out)
+        // parts are claimed dynamically and kept small (8 requests): a worker that wakes late — an idle core takes ~0.1 ms, a third of the whole
+        // job — still finds work, and nobody waits long for the last part
+        const size_t parts = host_threads() > 1 ? n / 8 : 1;
         host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
@@ -1089,8 +1045,15 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
 
     VQ_HIP(hipMemcpyAsync(dup, hup, up_bytes, hipMemcpyHostToDevice, st));
     ws.d_span_keys.ensure(size_t(total_span_keys) * 8 + 16);
-    ws.d_partial.ensure(lay.bytes);
-    pb->d_partial = ws.d_partial.as<uint8_t>();
+    if (arena_offset >= 0) {  // a chunk of a sharded step with one collective: its partial lives in the index's arena
+        if (size_t(arena_offset) % 256 || size_t(arena_offset) + lay.bytes > Index::kArenaBytes)
+            throw VelociError(ERR_UNSUPPORTED, "partial arena: the step's partials do not fit (" + std::to_string(size_t(arena_offset) + lay.bytes) + " bytes)");
+        idx.arena.ensure(Index::kArenaBytes);
+        pb->d_partial = idx.arena.as<uint8_t>() + arena_offset;
+    } else {
+        ws.d_partial.ensure(lay.bytes);
+        pb->d_partial = ws.d_partial.as<uint8_t>();
+    }
     VQ_HIP(hipMemsetAsync(pb->d_partial, 0, lay.bytes, st));
 
     // ---- the scan
@@ -1473,7 +1436,7 @@ void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Res
 }
 
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
-                  std::vector<int>& status, std::vector<std::string>& errors) {
+                  std::vector<int>& status, std::vector<std::string>& errors, size_t shard_stride) {
     const size_t n = pb.queries.size();
     out.clear();
     out.resize(n);
@@ -1506,7 +1469,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         const bool prof = pb.profiled;
         {
             LaunchTimer t(prof, ws, st, K_FINALIZE, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, nq);
-            launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, lay, reinterpret_cast<uint32_t*>(dd + o_ids),
+            launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, shard_stride ? shard_stride : size_t(lay.off_hist), lay, reinterpret_cast<uint32_t*>(dd + o_ids),
                             reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
         }
         VQ_HIP(hipGetLastError());

@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_spans(const uint8_t* __
 
 // gathered: the all-gathered parts (hit counts, counters, keys: PartialLayout::off_hist bytes each) of num_shards packed partial buffers, shard-major.
 __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
-                                                     const uint8_t* __restrict__ gathered, uint32_t num_shards, PartialLayout lay,
+                                                     const uint8_t* __restrict__ gathered, uint32_t num_shards, size_t shard_stride, PartialLayout lay,
                                                      uint32_t* __restrict__ res_ids, float* __restrict__ res_scores, uint32_t* __restrict__ res_n,
                                                      unsigned long long* __restrict__ res_hits) {
     __shared__ unsigned long long cand[kCandCap];
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     __syncthreads();
     unsigned long long hits = 0;
     for (uint32_t s = 0; s < num_shards; ++s) {
-        const uint8_t* pb = gathered + (size_t)s * lay.off_hist;
+        const uint8_t* pb = gathered + (size_t)s * shard_stride;
         const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(pb + lay.off_keys) + H->part_keys_off;
         hits += reinterpret_cast<const unsigned long long*>(pb + lay.off_hits)[q];
         if (*cs.n + top_k > (uint32_t)kCandCap) cand_prune(cs, top_k);  // uniform: *cs.n is stable here
@@ -1393,9 +1393,9 @@ void launch_merge_spans(hipStream_t st, uint32_t nq, const uint8_t* blobs, const
     hipLaunchKernelGGL(k_merge_spans, dim3(nq), dim3(kMergeThreads), 0, st, blobs, blob_off, span_keys, part_keys);
 }
 void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const uint32_t* blob_off, const uint8_t* gathered, uint32_t num_shards,
-                     const PartialLayout& lay, uint32_t* res_ids, float* res_scores, uint32_t* res_n, unsigned long long* res_hits) {
+                     size_t shard_stride, const PartialLayout& lay, uint32_t* res_ids, float* res_scores, uint32_t* res_n, unsigned long long* res_hits) {
     if (!nq) return;
-    hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(kBlock), 0, st, blobs, blob_off, gathered, num_shards, lay, res_ids, res_scores, res_n, res_hits);
+    hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(kBlock), 0, st, blobs, blob_off, gathered, num_shards, shard_stride, lay, res_ids, res_scores, res_n, res_hits);
 }
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n) {

@@ -5,6 +5,8 @@ New surface — the reference has no sharding.  The collective is the only excha
 per batch each rank contributes `PartialBatch.nbytes` bytes to one all-gather (top-(top+skip) keys and hit counts
 of every query, identical in size on every rank) and sums the batch's facet histograms with one all-reduce.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -99,6 +101,8 @@ class ShardedSearcher:
         self.collective = self.world > 1 or always_collective
         self.stream = None
         self._views = {}
+        from . import _lib
+        self.slots = int(_lib.lib().vq_partial_slots())
         if self.collective and dist.get_backend(group) == "nccl":
             # scans on one side stream, RCCL all-gather + merge on another that waits for the batch's scan through an event:
             # no host synchronisation between the shard scan and the collective.  (Not torch's default stream: its handle
@@ -162,6 +166,50 @@ class ShardedSearcher:
         torch.cuda.synchronize()
         return gathered
 
+    def _one_collective(self, subs, stride, out):
+        """A step as a pipeline of chunks with ONE exchange: every chunk scans into its own workspace with its partial placed in the index's
+        arena, back to back; when the last scan is queued the arena's used prefix is all-gathered once and every chunk merges out of the
+        gathered copy.  (The host compiles chunk c+1 while the GPU scans chunk c; only chunks without facet histograms — those are summed by
+        an all-reduce per chunk.)  -> False when the step has to take the per-chunk path (nothing was written to `out`)."""
+        import torch.distributed as dist
+        from .search import PartialBatch
+        from . import _lib
+        pbs, arena_off = [], 0
+        try:
+            for c, sb in enumerate(subs):
+                pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)
+                pbs.append(pb)
+                arena_off += (pb.total_nbytes + 255) // 256 * 256
+        except _lib.VelociError as e:
+            if e.kind != "Unsupported":
+                raise
+            for pb in pbs:
+                pb.close()
+            return False
+        if any(pb.hist_nbytes for pb in pbs):
+            for pb in pbs:
+                pb.close()
+            return False
+        self._ev = (self._ev + 1) % len(self._events)
+        scanned = self._events[self._ev]
+        scanned.record(self.stream)
+        self.fin_stream.wait_event(scanned)
+        with torch.cuda.stream(self.fin_stream):
+            key = ("arena", arena_off)
+            ent = self._views.get(key)
+            if ent is None:
+                if len(self._views) > 8:
+                    self._views.clear()
+                local = device_view(self.index.partial_arena_ptr, arena_off)
+                ent = self._views[key] = (local, torch.empty(self.world * arena_off, dtype=torch.uint8, device=local.device))
+            dist.all_gather_into_tensor(ent[1], ent[0], group=self.group)
+        base, offset = ent[1].data_ptr(), 0
+        for pb, sb in zip(pbs, subs):
+            pb.merge_flat(base + pb.arena_offset, self.world, stride, out, offset, shard_stride=arena_off)
+            pb.close()
+            offset += sb.n
+        return True
+
     def search_batch(self, requests):
         from .search import PartialBatch
         pb = self._partial(requests)
@@ -177,11 +225,10 @@ class ShardedSearcher:
         from .search import PartialBatch, RequestBatch
         batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
         if chunks is None:
-            # pipelining pays while a chunk's scan is long next to the fixed cost of a chunk (compile hand-over, the collective's host side):
-            # on small shards one chunk per batch is fastest (measured: 12.5 M docs per shard 550 k q/s with 1 chunk, 430-490 k with 2-4; from
-            # 25 M docs on 2-4 chunks win).  Decided from the GLOBAL doc count and the world size: identical on every rank.
             per_shard = self.index.num_anchors // max(self.world, 1)
             chunks = 1 if (batch.n < 512 or (self.collective and per_shard < 20_000_000)) else 4
+            if os.environ.get("VQ_SHARD_CHUNKS"):
+                chunks = int(os.environ["VQ_SHARD_CHUNKS"])
         subs = batch.split(chunks)
 
         n = batch.n  # every chunk writes its rows of one set of output arrays
@@ -195,6 +242,10 @@ class ShardedSearcher:
                 pb.merge_flat(gathered.data_ptr(), self.world, stride, out, offset)
             pb.close()
 
+        if self.collective and self.stream is not None and 1 < len(subs) <= self.slots and not os.environ.get("VQ_PER_CHUNK_COLLECTIVE"):
+            done = self._one_collective(subs, stride, out)
+            if done:
+                return out
         inflight, offset = [], 0
         for sb in subs:
             if len(inflight) >= 2:

@@ -183,6 +183,14 @@ class Index:
     def device_bytes(self):
         return int(self.L.vq_index_device_bytes(self.h))
 
+    @property
+    def partial_arena_ptr(self):
+        """device address of the partial arena (vq_index_partial_arena_ptr): where the chunks of a one-collective sharded step put their partials"""
+        p = self.L.vq_index_partial_arena_ptr(self.h)
+        if not p:
+            _lib.check(5)
+        return int(p)
+
     def profile_enable(self, on=True):
         _lib.check(self.L.vq_profile_enable(self.h, int(on)))
 

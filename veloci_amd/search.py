@@ -172,9 +172,12 @@ def search_batch_flat(batch, index, stride=10):
 class PartialBatch:
     """Shard-local partial results of a batch, resident in HBM (`vq_partial_batch`)."""
 
-    def __init__(self, index, requests):
+    def __init__(self, index, requests, slot=None, arena_offset=None):
+        """slot / arena_offset: a chunk of a sharded step with one collective (vq_search_batch_partial_at) — its partial is placed at
+        `arena_offset` of the index's partial arena instead of its workspace's own buffer."""
         self.L = _lib.lib()
         self.index = index
+        self.arena_offset = arena_offset
         if isinstance(requests, RequestBatch):
             self.reqs, n, arr = requests.reqs, requests.n, requests.arr
         else:
@@ -182,13 +185,21 @@ class PartialBatch:
             n = len(self.reqs)
             arr = (C.c_void_p * n)(*[r.h for r in self.reqs])
         h = C.c_void_p()
-        _lib.check(self.L.vq_search_batch_partial(index.h, arr, n, C.byref(h)))
+        if arena_offset is None:
+            _lib.check(self.L.vq_search_batch_partial(index.h, arr, n, C.byref(h)))
+        else:
+            _lib.check(self.L.vq_search_batch_partial_at(index.h, arr, n, slot, arena_offset, C.byref(h)))
         self.h = h
         self.n = n
 
     @property
     def nbytes(self):
         return int(self.L.vq_partial_bytes(self.h))
+
+    @property
+    def total_nbytes(self):
+        """all-gathered part + histograms: what the partial occupies"""
+        return int(self.L.vq_partial_total_bytes(self.h))
 
     @property
     def device_ptr(self):
@@ -217,7 +228,7 @@ class PartialBatch:
                 results.append(_take_result(self.L, C.c_void_p(outs[i])))
         return results
 
-    def merge_flat(self, gathered_device_ptr=None, num_shards=1, stride=10, out=None, offset=0):
+    def merge_flat(self, gathered_device_ptr=None, num_shards=1, stride=10, out=None, offset=0, shard_stride=0):
         """out: (num_hits, counts, ids, scores, status) arrays of a larger batch; this partial's rows start at `offset` (a pipeline of
         chunks fills one set of arrays instead of concatenating per-chunk ones)."""
         n = self.n
@@ -226,6 +237,10 @@ class PartialBatch:
             offset = 0
         num_hits, counts, ids, scores, status = out
         at = lambda a, row: C.c_void_p(a.ctypes.data + row * a.strides[0])
+        if shard_stride:  # the shards' copies of this partial lie `shard_stride` bytes apart (one gathered arena holds several partials)
+            _lib.check(self.L.vq_merge_partials_flat_strided(self.index.h, self.h, C.c_void_p(gathered_device_ptr), num_shards, shard_stride, stride,
+                                                             at(num_hits, offset), at(counts, offset), at(ids, offset), at(scores, offset), at(status, offset)))
+            return out
         _lib.check(self.L.vq_merge_partials_flat(self.index.h, self.h, C.c_void_p(gathered_device_ptr) if gathered_device_ptr else None, num_shards, stride,
                                                  at(num_hits, offset), at(counts, offset), at(ids, offset), at(scores, offset), at(status, offset)))
         return out
