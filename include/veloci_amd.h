@@ -153,6 +153,10 @@ const char* vq_request_to_json(const vq_request*);
 /* str::to_lowercase as the dictionary side applies it (src/search/search_field.rs:284,312).  Returns the byte length written to `out`, or
  * (size_t)-1 when `cap` is too small.  Diagnostic: swept over every code point by tests/test_request_parse.py. */
 size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap);
+/* Compile a request against an index without launching anything (host-only): 0 = ready to scan, negative = a pre-pass would run first (-1 union /
+ * locality jobs, -2 count pre-pass, -3 range jobs), otherwise the error code the search would return.  Diagnostic: the CPU sanitizer build (`make asan`) runs it over the
+ * request fixtures; tools/compile_bench.py times it. */
+int vq_debug_compile(const vq_index*, const vq_request*);
 
 /* ---------------------------------------------------------------- results
  *

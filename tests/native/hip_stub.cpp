@@ -1,0 +1,105 @@
+// TEST INFRASTRUCTURE — the device layer stubbed for the CPU sanitizer build (`make -C veloci_amd/csrc asan`, tests/test_host_asan.py): the HIP
+// runtime calls the host side makes are mapped to host memory, every kernel launcher throws.  What this build can run is everything in front of
+// the first launch: index staging (index.cpp), request parsing, query compilation (compile.cpp), the C ABI's argument handling — under
+// AddressSanitizer + UndefinedBehaviorSanitizer.  Never linked into the product library.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "../../veloci_amd/csrc/engine.hpp"
+
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n) {
+    *p = std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    std::memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    std::memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t n) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) {
+    *s = reinterpret_cast<hipStream_t>(std::malloc(8));
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    std::free(s);
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) {
+    *e = reinterpret_cast<hipEvent_t>(std::malloc(8));
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { return hipEventCreate(e); }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) {
+    std::free(e);
+    return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {
+    *ms = 0.0f;
+    return hipSuccess;
+}
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "stubbed HIP runtime"; }
+hipError_t hipGetDeviceCount(int* n) {
+    *n = 1;
+    return hipSuccess;
+}
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+}
+
+namespace vq {
+[[noreturn]] static void no_device(const char* what) { throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("device layer stubbed: ") + what); }
+size_t tile_scan_lds_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool, uint32_t) { return 0; }
+size_t scan_simple_lds_bytes(uint32_t, uint32_t, uint32_t, bool) { return 0; }
+size_t scan_wide_lds_bytes(uint32_t, uint32_t, uint32_t) { return 0; }
+uint32_t debug_div100_mismatches() { no_device("debug_div100_mismatches"); }
+void launch_tile_scan(hipStream_t, uint32_t, size_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*,
+                      unsigned long long*, uint32_t*, bool, uint32_t, bool) { no_device("k_tile_scan"); }
+void launch_scan_leaf_f32(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*, uint32_t*) {
+    no_device("k_scan_leaf_f32");
+}
+void launch_scan_simple(hipStream_t, bool, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*,
+                        uint32_t*, bool) { no_device("k_scan_simple"); }
+void launch_scan_wide(hipStream_t, uint32_t, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*,
+                      unsigned long long*) { no_device("k_scan_wide"); }
+void launch_merge_spans(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const unsigned long long*, unsigned long long*) { no_device("k_merge_spans"); }
+void launch_finalize(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const uint8_t*, uint32_t, size_t, const PartialLayout&, uint32_t*, float*, uint32_t*, unsigned long long*) {
+    no_device("k_finalize");
+}
+void launch_facet_select(hipStream_t, uint32_t, const FacetJob*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*) { no_device("k_facet_select"); }
+void launch_range_hits(hipStream_t, uint32_t, const UList*, const RangeTask*, unsigned long long*) { no_device("k_range_hits"); }
+void launch_union(hipStream_t, bool, uint32_t, const UList*, const UTask*, const uint32_t*, uint32_t*, const uint64_t*, uint32_t*, float*, uint32_t*) { no_device("k_union"); }
+void launch_scan_union(hipStream_t, bool, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*) {
+    no_device("k_scan_union");
+}
+void launch_dict_scan(hipStream_t, const DictProbe*, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t, uint32_t*, uint32_t, DictMatch*) { no_device("k_dict_scan"); }
+void launch_loc_gather(hipStream_t, const LocRow*, uint32_t, const uint32_t*, uint32_t*) { no_device("k_loc_gather"); }
+void launch_loc_expand(hipStream_t, bool, const LocJob*, uint32_t, const uint32_t*, uint32_t, uint32_t*, unsigned long long*) { no_device("k_loc_expand"); }
+void launch_loc_compact(hipStream_t, const LocJob*, uint32_t, const unsigned long long*, uint32_t*, float*, uint32_t*) { no_device("k_loc_compact"); }
+size_t seg_sort_u32(void*, size_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) { no_device("seg_sort_u32"); }
+size_t seg_sort_u64(void*, size_t, const unsigned long long*, unsigned long long*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) { no_device("seg_sort_u64"); }
+void launch_explain(hipStream_t, uint32_t, const ExQuery*, const uint32_t*, const uint32_t*, const ExOp*, const uint16_t*, const ExList*, const DColBoost*, uint32_t*) { no_device("k_explain"); }
+}  // namespace vq

@@ -434,6 +434,19 @@ size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap
     std::memcpy(out, low.data(), low.size());
     return low.size();
 }
+// Compile `request` against `index` without launching anything: 0 when the query is ready to scan, negative when a pre-pass would run first
+// (-1 union / locality jobs, -2 count pre-pass, -3 range jobs), or the error code the search would return (message in vq_last_error).  Host-only work —
+// what the CPU sanitizer build exercises, and what tools/compile_bench.py times.
+int vq_debug_compile(const vq_index* index, const vq_request* request) {
+    int status = 0;
+    const int rc = guard([&] {
+        if (!index || !request) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_debug_compile: null argument");
+        vq::CompiledQuery cq = vq::compile_query(*index->idx, request->req, nullptr, nullptr, nullptr, nullptr, nullptr);
+        status = cq.status;
+        if (cq.status != 0) g_err = cq.error;
+    });
+    return rc != 0 ? rc : status;
+}
 void vq_request_free(vq_request* r) { delete r; }
 
 // ------------------------------------------------------------------ results

@@ -60,6 +60,7 @@ bool cp_eq(uint32_t a, uint32_t b, bool ci) { return a == b || (ci && vqtext::lo
 // over the lower-cased term with transpositions at cost one; beyond its maximum it falls back to the plain
 // character Levenshtein distance in u8 (255 for strings of 255 bytes or more).
 uint8_t scoring_distance(const std::string& lower_hit, const std::string& lower_term, uint32_t dfa_max) {
+    if (lower_hit == lower_term) return 0;  // (both distances of equal strings: the exact-match leaf, the common case)
     const auto h = vqtext::decode_utf8(lower_hit), t = vqtext::decode_utf8(lower_term);
     const size_t n = h.size(), m = t.size(), w = m + 1;
     std::vector<uint32_t> osa((n + 1) * w), lev((n + 1) * w);
@@ -125,7 +126,8 @@ void parse_expression(const std::string& expression, DColBoost& cb) {
 }
 
 struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:16-44, plan_steps.rs:137-148)
-    RequestSearchPart part;
+    const RequestSearchPart* part = nullptr;  // the request's own part (it outlives the compilation)
+    std::string key;                          // part->key(), built once
     std::string path;  // with ".textindex"
     bool get_scores = false, get_ids = false, store_term_id_hits = false;
     bool return_term = false, return_term_lowercase = false, store_term_texts = false;  // execution_plan.rs:16-44
@@ -160,6 +162,7 @@ struct Compiler {
     const Request& req;
     CompiledQuery cq;
     std::map<std::string, Leaf> cache;  // FieldRequestCache
+    std::vector<std::pair<const RequestSearchPart*, Leaf*>> by_address;
     std::map<std::string, std::map<std::string, std::vector<uint32_t>>> term_id_hits;  // path -> term -> term ids
     uint32_t max_depth = 0;
 
@@ -224,17 +227,15 @@ struct Compiler {
 
     // ------------------------------------------------------------ leaves
     void add_to_cache(const RequestSearchPart& part, bool ids_only) {  // execution_plan.rs:108-130
-        auto it = cache.find(part.key());
-        if (it != cache.end()) {
-            it->second.get_ids |= ids_only;
-            it->second.get_scores |= !ids_only;
-            return;
+        auto [it, fresh] = cache.try_emplace(part.key());
+        Leaf& l = it->second;
+        if (fresh) {
+            l.part = &part;
+            l.key = it->first;
         }
-        Leaf l;
-        l.part = part;
-        l.get_scores = !ids_only;
-        l.get_ids = ids_only;
-        cache.emplace(part.key(), std::move(l));
+        l.get_ids |= ids_only;
+        l.get_scores |= !ids_only;
+        by_address.emplace_back(&part, &l);  // (std::map nodes do not move)
     }
     void collect(const SearchRequest& r, bool ids_only) {
         if (r.kind == SearchRequest::Search) add_to_cache(r.part, ids_only);
@@ -242,6 +243,8 @@ struct Compiler {
             for (auto& q : r.tree.queries) collect(q, ids_only);
     }
     Leaf& leaf(const RequestSearchPart& part) {
+        for (auto& pr : by_address)  // the parts of this request, by identity: building a key costs more than compiling a leaf
+            if (pr.first == &part) return *pr.second;
         auto it = cache.find(part.key());
         if (it == cache.end()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"PlanCreator: Could not find request in field_search_cache\" ");
         return it->second;
@@ -286,15 +289,15 @@ struct Compiler {
 
     // get_term_ids_in_field (search_field.rs:277-398) — dictionary side only
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
-        const RequestSearchPart& p = l.part;
+        const RequestSearchPart& p = *l.part;
         if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
         l.path = p.path;
         if (!ends_with(l.path, TEXTINDEX)) l.path += TEXTINDEX;
         const std::string lower_term = vqtext::to_lower_utf8(p.terms[0]);
-        const auto lower_cps = vqtext::decode_utf8(lower_term);
         uint32_t lev = 0;
         if (p.levenshtein_distance) {  // :285-287
+            const auto lower_cps = vqtext::decode_utf8(lower_term);
             if (lower_cps.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"empty term with levenshtein_distance\" ");
             lev = std::min<uint32_t>(*p.levenshtein_distance, uint32_t(lower_cps.size()) - 1);
         }
@@ -302,7 +305,8 @@ struct Compiler {
         if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "field does not exist " + l.path + " (fst not found)");
         const Dictionary& dict = dit->second;
         const bool ci = p.ignore_case.value_or(true);  // search_field.rs:88
-        const auto query_cps = vqtext::decode_utf8(p.terms[0]);
+        const bool query_ascii = vqtext::is_ascii(p.terms[0].data(), p.terms[0].size());
+        std::vector<uint32_t> query_cps;  // decoded when a comparison needs code points
         std::vector<uint32_t> cand;
         const FuzzyProbe* probe = nullptr;
         const bool regex = p.is_regex;
@@ -332,10 +336,17 @@ struct Compiler {
         for (size_t ci_ = 0; ci_ < cand.size(); ++ci_) {  // ascending ids == FST stream order
             const uint32_t id = cand[ci_];
             if (!scan && !regex) {
-                const auto cps = vqtext::decode_utf8(dict.terms[id]);
-                if (cps.size() != query_cps.size()) continue;
+                const std::string& cand_term = dict.terms[id];
                 bool eq = true;
-                for (size_t i = 0; i < cps.size() && eq; ++i) eq = cp_eq(cps[i], query_cps[i], ci);
+                if (query_ascii && vqtext::is_ascii(cand_term.data(), cand_term.size())) {  // bytes are code points
+                    eq = cand_term.size() == p.terms[0].size();
+                    for (size_t i = 0; i < cand_term.size() && eq; ++i) eq = cp_eq(uint8_t(cand_term[i]), uint8_t(p.terms[0][i]), ci);
+                } else {
+                    const auto cps = vqtext::decode_utf8(cand_term);
+                    if (query_cps.empty() && !p.terms[0].empty()) query_cps = vqtext::decode_utf8(p.terms[0]);
+                    eq = cps.size() == query_cps.size();
+                    for (size_t i = 0; i < cps.size() && eq; ++i) eq = cp_eq(cps[i], query_cps[i], ci);
+                }
                 if (!eq) continue;
             }
             if (get_ids) l.hits_ids.push_back(id);
@@ -403,7 +414,7 @@ struct Compiler {
                 const float a = cb.expr_lkind == 0 ? v : cb.expr_lval, b = cb.expr_rkind == 0 ? v : cb.expr_rval;
                 score += cb.expr_op == EX_DIV ? a / b : cb.expr_op == EX_MUL ? a * b : cb.expr_op == EX_ADD ? a + b : a - b;
             }
-            if (part_explains(l.part)) {  // boost.rs:297-300, 371-374
+            if (part_explains(*l.part)) {  // boost.rs:297-300, 371-374
                 ExplainRec e;
                 e.kind = ExplainRec::Boost;
                 if (cb.fun == BF_LOG10) {
@@ -542,7 +553,7 @@ struct Compiler {
             if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
         if (!(nonempty > union_min() || (nonempty > 1 && req.search_req && has_wide_and(*req.search_req)))) return std::string();
         // (the matched terms and their scores follow from the leaf's request alone: its key identifies the merged list)
-        return "u|" + l.path + "|" + l.part.key();
+        return "u|" + l.path + "|" + (l.key.empty() ? l.part->key() : l.key);
     }
 
     // score leaf: the posting lists of the matched terms (resolve_token_to_anchor, search_field.rs:400-504)
@@ -583,7 +594,7 @@ struct Compiler {
             if (members.size() == 1) ukey = leaf_union_key(*members[0]);
             else {
                 ukey = "u|fused";
-                for (Leaf* l : members) ukey += "|" + l->path + "|" + l->part.key();
+                for (Leaf* l : members) ukey += "|" + l->path + "|" + (l->key.empty() ? l->part->key() : l->key);
             }
             const UnionJob* done = nullptr;
             if (unions) {
@@ -1718,7 +1729,7 @@ struct Compiler {
         if (req.boost_term)
             for (auto& part : *req.boost_term) {
                 Leaf l;
-                l.part = part;
+                l.part = &part;
                 lookup_terms(idx, l, false, true);
                 const float mult = part.boost.value_or(2.0f);  // boost.rs:393
                 for (uint32_t li : ids_to_anchor_lists(l, true)) {
@@ -2046,7 +2057,7 @@ std::vector<SuggestEntry> suggest_part(const Index& idx, const RequestSearchPart
     Request dummy;
     Compiler c(idx, dummy, fuzzy);
     Leaf l;
-    l.part = part;
+    l.part = &part;
     l.get_scores = true;
     l.return_term = true;
     l.return_term_lowercase = true;
