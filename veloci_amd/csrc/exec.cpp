@@ -202,6 +202,11 @@ void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStr
         if (bmp) {
             P.lm = uint32_t(lcps.size());
             for (size_t j = 0; j < lcps.size(); ++j) P.lquery[j] = uint16_t(lcps[j]);
+            // a case-insensitive scan matches with the very string it scores with, over the very image: the kernel then scores a hit from the
+            // tables it already holds in LDS instead of re-reading the probe from HBM character by character
+            bool same = fp.ci && lcps.size() == fp.query.size();
+            for (size_t j = 0; same && j < lcps.size(); ++j) same = lcps[j] == fp.query[j];
+            if (same) P.flags |= 4u;
         } else {
             P.lm = 0xFFFFFFFFu;
             host_scored[i] = 1;
@@ -243,12 +248,24 @@ void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStr
             cap = count;
             continue;
         }
+        if (std::getenv("VQ_TIMING")) {
+            std::fprintf(stderr, "[vq timing] dictionary scan: %zu probes, %u matches\n", todo.size(), count);
+        }
         recs.resize(count);
         if (count) {
             VQ_HIP(hipMemcpyAsync(recs.data(), d_out.p, size_t(count) * sizeof(DictMatch), hipMemcpyDeviceToHost, st));
             VQ_HIP(hipStreamSynchronize(st));
         }
         break;
+    }
+    if (std::getenv("VQ_TIMING")) {  // the distribution of matches over the probes (a few short probes can hold most of them)
+        std::vector<uint32_t> per(todo.size(), 0);
+        for (auto& r : recs) per[r.probe]++;
+        std::vector<uint32_t> sorted = per;
+        std::sort(sorted.begin(), sorted.end(), std::greater<uint32_t>());
+        std::string top;
+        for (size_t i = 0; i < sorted.size() && i < 8; ++i) top += " " + std::to_string(sorted[i]);
+        std::fprintf(stderr, "[vq timing] dictionary scan: most matches per probe:%s\n", top.c_str());
     }
     // bucket by probe, ascending term ids (== FST stream order, which is the reference's callback order)
     std::sort(recs.begin(), recs.end(), [](const DictMatch& a, const DictMatch& b) { return a.probe != b.probe ? a.probe < b.probe : a.term < b.term; });

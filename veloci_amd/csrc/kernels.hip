@@ -2662,8 +2662,10 @@ namespace vq {
 // Myers / Hyyrö bit-vector recurrence over the term's code points, in 32-bit words when the pattern has <= 32 code points (half the VALU
 // work).  Whole-term matching leaves the loop as soon as the distance can no longer come back under max_d (the last row of the DP table falls
 // by at most one per text character): most terms of a dictionary are out after two or three characters.
+// (`text` is either the LDS stage or the HBM image: the two callers are separate instantiations on purpose — a pointer selected at run time
+// between the two becomes a FLAT load, which costs several hundred cycles per character of every surviving pair)
 template <class Word>
-__device__ __forceinline__ bool dict_match(uint32_t m, uint32_t max_d, bool transposition, bool prefix, uint32_t n, const uint16_t* staged, const uint16_t* global,
+__device__ __forceinline__ bool dict_match(uint32_t m, uint32_t max_d, bool transposition, bool prefix, uint32_t n, const uint16_t* text,
                                            const unsigned long long* peq_p, const uint16_t* q) {
     const Word one = 1;
     const Word top = one << (m - 1);
@@ -2671,7 +2673,7 @@ __device__ __forceinline__ bool dict_match(uint32_t m, uint32_t max_d, bool tran
     uint32_t score = m;
     uint32_t best = m;  // distance of the empty prefix
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t c = staged ? staged[i] : global[i];
+        const uint32_t c = text[i];
         Word Eq;
         if (c < 128u) Eq = (Word)peq_p[c];
         else {
@@ -2698,16 +2700,21 @@ __device__ __forceinline__ bool dict_match(uint32_t m, uint32_t max_d, bool tran
 
 // Distance the reference SCORES a hit with (search_field.rs:691-732): full bit-vector recurrence of the lower-cased term (pattern, <= 64 code
 // points) over the lower-cased hit; TRANS: adjacent transpositions cost one (the scoring automaton), else plain Levenshtein (its fallback).
+// (peq_q: the pattern's match-mask table for code points < 128, or null)
 template <bool TRANS>
-__device__ uint32_t dict_full_distance(const uint16_t* q, uint32_t m, const uint16_t* __restrict__ text, uint32_t n) {
+__device__ __forceinline__ uint32_t dict_full_distance(const uint16_t* q, const unsigned long long* peq_q, uint32_t m, const uint16_t* __restrict__ text, uint32_t n) {
     if (m == 0) return n;
     const unsigned long long top = 1ull << (m - 1);
     unsigned long long Pv = m == 64 ? ~0ull : ((1ull << m) - 1ull), Mv = 0ull, prevEq = 0ull, prevD0 = ~0ull;
     uint32_t score = m;
     for (uint32_t i = 0; i < n; ++i) {
         const uint16_t c = text[i];
-        unsigned long long Eq = 0ull;
-        for (uint32_t j = 0; j < m; ++j) Eq |= (unsigned long long)(q[j] == c) << j;
+        unsigned long long Eq;
+        if (peq_q && c < 128u) Eq = peq_q[c];
+        else {
+            Eq = 0ull;
+            for (uint32_t j = 0; j < m; ++j) Eq |= (unsigned long long)(q[j] == c) << j;
+        }
         unsigned long long D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
         if (TRANS) D0 |= (((~prevD0) & Eq) << 1) & prevEq;
         unsigned long long Ph = Mv | ~(D0 | Pv);
@@ -2725,12 +2732,59 @@ __device__ uint32_t dict_full_distance(const uint16_t* q, uint32_t m, const uint
 }
 
 constexpr uint32_t kDictGroup = 16;    // probes one block answers per pass over its terms
-constexpr uint32_t kDictStage = 4096;  // code points of the block's 256 terms staged in LDS (longer stretches are read from HBM)
+constexpr uint32_t kDictStage = 4096;  // code points of a round's 256 terms staged in LDS (longer stretches are read from HBM)
+constexpr uint32_t kDictRounds = 8;    // rounds of 256 consecutive terms per block: the probes' match-mask tables are built once for all of them
 
-// One block = 256 consecutive dictionary terms (their code points are one contiguous stretch of the CSR image: staged into LDS with coalesced
+// One block = kDictRounds rounds of 256 consecutive dictionary terms (a round's code points are one contiguous stretch of the CSR image: staged into LDS with coalesced
 // loads) x a group of kDictGroup probes.  Per probe a match-mask table Peq[c] (bit j: query[j] == c) for c < 128 lives in LDS, so the per-character
 // step of the bit-vector recurrence is one LDS read instead of an m-step compare loop; other code points take the compare loop.
 // All probes of a launch scan the same dictionary image (the host groups them).
+// The recurrence for a term of <= kDictShort ASCII code points staged in LDS: all its characters, then all their match masks, are read in two
+// batches of independent LDS loads — the character-by-character loop of dict_match pays two dependent LDS round trips per character.
+constexpr uint32_t kDictShort = 12;
+template <class Word>
+__device__ __forceinline__ bool dict_match_short(uint32_t m, uint32_t max_d, bool transposition, bool prefix, uint32_t n, const uint16_t* text,
+                                                 const unsigned long long* peq_p, bool* ascii) {
+    uint32_t c[kDictShort];
+    bool all_ascii = true;
+#pragma unroll
+    for (uint32_t i = 0; i < kDictShort; ++i) {
+        c[i] = i < n ? (uint32_t)text[i] : 0u;
+        all_ascii = all_ascii && c[i] < 128u;
+    }
+    *ascii = all_ascii;
+    if (!all_ascii) return false;
+    Word eq[kDictShort];
+#pragma unroll
+    for (uint32_t i = 0; i < kDictShort; ++i) eq[i] = (Word)peq_p[c[i]];
+    const Word one = 1;
+    const Word top = one << (m - 1);
+    Word Pv = m == sizeof(Word) * 8 ? ~Word(0) : ((one << m) - one), Mv = 0, prevEq = 0, prevD0 = ~Word(0);
+    uint32_t score = m, best = m;
+    bool dead = false;
+#pragma unroll
+    for (uint32_t i = 0; i < kDictShort; ++i) {
+        if (i < n && !dead) {
+            const Word Eq = eq[i];
+            Word D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv;
+            if (transposition) D0 |= (((~prevD0) & Eq) << 1) & prevEq;
+            Word Ph = Mv | ~(D0 | Pv);
+            Word Mh = Pv & D0;
+            if (Ph & top) ++score;
+            else if (Mh & top) --score;
+            Ph = (Ph << 1) | one;
+            Mh <<= 1;
+            Pv = Mh | ~(D0 | Ph);
+            Mv = Ph & D0;
+            prevEq = Eq;
+            prevD0 = D0;
+            best = score < best ? score : best;
+            if (!prefix && score > max_d + (n - 1u - i)) dead = true;
+        }
+    }
+    return !dead && (prefix ? best : score) <= max_d;
+}
+
 __global__ __launch_bounds__(256) void k_dict_scan(const DictProbe* __restrict__ probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* __restrict__ off,
                                                    const uint16_t* __restrict__ chars, const uint16_t* __restrict__ low_chars, uint32_t num_terms,
                                                    uint32_t* __restrict__ out_count, uint32_t out_cap, DictMatch* __restrict__ out) {
@@ -2738,62 +2792,187 @@ __global__ __launch_bounds__(256) void k_dict_scan(const DictProbe* __restrict__
     __shared__ uint16_t stage[kDictStage];
     __shared__ uint16_t qch[kDictGroup][64];
     __shared__ uint32_t pm[kDictGroup], pmaxd[kDictGroup], pflags[kDictGroup];
+    __shared__ unsigned long long psig[kDictGroup];
+    __shared__ uint32_t soff[257];                   // a round's term offsets, relative to its first code point
+    __shared__ uint16_t queue[256 * kDictGroup];     // (term in round | probe << 8) pairs that passed the filters
+    __shared__ uint32_t qn;
+    VQ_STAMP_INIT
+    VQ_STAMP_COUNT(8)
     const uint32_t tid = threadIdx.x;
     const uint32_t p0 = blockIdx.y * kDictGroup;
     const uint32_t np = n_probes - p0 < kDictGroup ? n_probes - p0 : kDictGroup;
-    const uint32_t t0 = blockIdx.x * 256u;
-    const uint32_t t_end = t0 + 256u < num_terms ? t0 + 256u : num_terms;
     for (uint32_t x = tid; x < np * 64u; x += 256u) qch[x >> 6][x & 63u] = probes[p0 + (x >> 6)].query[x & 63u];
-    if (tid < np) {
-        pm[tid] = probes[p0 + tid].m;
-        pmaxd[tid] = probes[p0 + tid].max_d;
-        pflags[tid] = probes[p0 + tid].flags;
+    if (tid < kDictGroup) {
+        pm[tid] = tid < np ? probes[p0 + tid].m : 0u;
+        pmaxd[tid] = tid < np ? probes[p0 + tid].max_d : 0u;
+        pflags[tid] = tid < np ? probes[p0 + tid].flags : 0u;
     }
-    const uint32_t base = off[t0], stretch = off[t_end] - base;
-    const uint32_t staged = stretch < kDictStage ? stretch : kDictStage;
-    for (uint32_t x = tid; x < staged; x += 256u) stage[x] = chars[base + x];
+    for (uint32_t x = tid; x < kDictGroup * 128u; x += 256u) peq[x >> 7][x & 127u] = 0ull;
     __syncthreads();
-    for (uint32_t x = tid; x < np * 128u; x += 256u) {
-        const uint32_t p = x >> 7, c = x & 127u, m = pm[p];
-        unsigned long long mask = 0ull;
-        for (uint32_t j = 0; j < m; ++j) mask |= (unsigned long long)(qch[p][j] == c) << j;
-        peq[p][c] = mask;
+    // the probes' tables, built once per block and used for all its kDictRounds x 256 terms: Peq[c] bit j = (query[j] == c), one LDS atomic
+    // per character of a query
+    for (uint32_t x = tid; x < np * 64u; x += 256u) {
+        const uint32_t p = x >> 6, j = x & 63u;
+        if (j < pm[p] && qch[p][j] < 128u) atomicOr(&peq[p][qch[p][j]], 1ull << j);
+    }
+    // Character-set filter in front of the recurrence: every edit (insert, delete, substitute; a transposition none) takes at most ONE distinct
+    // character of the query out of the term, so a term within max_d of the query — or with a prefix that is — lacks at most max_d of the
+    // query's distinct characters.  Characters are hashed into a 64-bit signature (collisions only hide a lacking character: the count is a
+    // lower bound, no match is lost); a random dictionary term fails this test on a few register operations, without touching LDS.
+    if (tid < kDictGroup) {
+        unsigned long long sq = 0ull;
+        for (uint32_t j = 0; j < pm[tid]; ++j) sq |= 1ull << (((uint32_t)qch[tid][j] * 2654435761u) >> 26);
+        psig[tid] = sq;
     }
     __syncthreads();
-    const uint32_t t = t0 + tid;
-    if (t >= num_terms) return;
-    const uint32_t b = off[t] - base, e = off[t + 1] - base;
-    const uint32_t n = e - b;
-    const bool in_stage = e <= staged;
-    for (uint32_t p = 0; p < np; ++p) {  // uniform
-        const uint32_t m = pm[p], max_d = pmaxd[p];
-        const bool transposition = pflags[p] & 1u, prefix = pflags[p] & 2u;
-        if (!prefix && (n > m + max_d || n + max_d < m)) continue;  // length filter
-        bool match;
-        if (m == 0) match = prefix || n <= max_d;
-        else if (m <= 32u) match = dict_match<uint32_t>(m, max_d, transposition, prefix, n, in_stage ? stage + b : nullptr, chars + base + b, peq[p], qch[p]);
-        else match = dict_match<unsigned long long>(m, max_d, transposition, prefix, n, in_stage ? stage + b : nullptr, chars + base + b, peq[p], qch[p]);
-        if (match) {  // rare: what the hit's score needs is computed here, on the lower-cased image
-            const DictProbe& P = probes[p0 + p];
-            uint32_t info = 0;
-            const uint32_t lm = P.lm;
-            if (lm != 0xFFFFFFFFu) {
-                const uint16_t* text = low_chars + base + b;
-                const uint32_t osa = dict_full_distance<true>(P.lquery, lm, text, n), lev = dict_full_distance<false>(P.lquery, lm, text, n);
-                bool starts = n >= lm;
-                for (uint32_t i = 0; starts && i < lm; ++i) starts = text[i] == P.lquery[i];
-                info = (osa < 255u ? osa : 255u) | ((lev < 255u ? lev : 255u) << 8) | ((starts ? 1u : 0u) << 16);
-            }
-            const uint32_t pos = atomicAdd(out_count, 1u);
-            if (pos < out_cap) out[pos] = DictMatch{probe_base + p0 + p, t, info};
+    // the group's parameters in scalar registers: the filter loop below touches no memory at all
+    uint32_t pk[kDictGroup], sg_lo[kDictGroup], sg_hi[kDictGroup];  // pk: m | max_d << 8 | flags << 16 | valid << 31
+#pragma unroll
+    for (uint32_t p = 0; p < kDictGroup; ++p) {
+        pk[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pm[p] | (pmaxd[p] << 8) | (pflags[p] << 16) | (p < np ? 0x80000000u : 0u)));
+        sg_lo[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)psig[p]);
+        sg_hi[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(psig[p] >> 32));
+    }
+    // A round's inputs — 257 offsets and up to kDictStage code points — are loaded into registers one round AHEAD: the block's rounds are
+    // consecutive stretches of the image, so the next stretch starts where this one ends, and its loads are in flight while this round's
+    // pairs are filtered and matched.
+    const uint32_t total_chars = off[num_terms];
+    const uint32_t first_t0 = blockIdx.x * kDictRounds * 256u;
+    uint32_t n_off0 = 0, n_off1 = 0;
+    uint16_t n_ch[kDictStage / 256];
+    auto prefetch = [&](uint32_t t0, uint32_t base) {
+        if (t0 >= num_terms) return;  // uniform
+        const uint32_t last = num_terms;  // off[] has num_terms + 1 entries
+        n_off0 = off[t0 + tid <= last ? t0 + tid : last];
+        if (tid == 0) n_off1 = off[t0 + 256u <= last ? t0 + 256u : last];
+#pragma unroll
+        for (uint32_t k = 0; k < kDictStage / 256u; ++k) {
+            const uint32_t at = base + k * 256u + tid;
+            n_ch[k] = at < total_chars ? chars[at] : (uint16_t)0;
         }
+    };
+    uint32_t next_base = first_t0 < num_terms ? off[first_t0] : 0u;
+    prefetch(first_t0, next_base);
+    VQ_STAMP_AT(0)
+    for (uint32_t round = 0; round < kDictRounds; ++round) {
+        const uint32_t t0 = first_t0 + round * 256u;
+        if (t0 >= num_terms) break;  // uniform
+        const uint32_t t_end = t0 + 256u < num_terms ? t0 + 256u : num_terms;
+        const uint32_t base = next_base;
+        __syncthreads();  // the previous round's readers of `stage` / `soff` / `queue` are done
+        soff[tid] = n_off0 - base;
+        if (tid == 0) {
+            soff[256] = n_off1 - base;
+            qn = 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kDictStage / 256u; ++k) stage[k * 256u + tid] = n_ch[k];
+        __syncthreads();
+        const uint32_t stretch = soff[t_end - t0];
+        const uint32_t staged = stretch < kDictStage ? stretch : kDictStage;
+        next_base = base + stretch;
+        prefetch(t0 + 256u, next_base);
+        VQ_STAMP_AT(1)
+        VQ_STAMP_COUNT(7)
+        // phase A — one lane per term: the cheap filters against every probe of the group (registers only); the survivors (about 2 % of the
+        // pairs) of a wave are queued with one reservation
+        uint32_t pmask = 0u;  // bit p: this lane's term survived against probe p
+        if (t0 + tid < t_end) {
+            const uint32_t b = soff[tid], n = soff[tid + 1] - b;
+            const bool in_stage = b + n <= staged;
+            unsigned long long sig_t = 0ull;
+            if (in_stage)
+                for (uint32_t i = 0; i < n; ++i) sig_t |= 1ull << (((uint32_t)stage[b + i] * 2654435761u) >> 26);
+            else
+                for (uint32_t i = 0; i < n; ++i) sig_t |= 1ull << (((uint32_t)chars[base + b + i] * 2654435761u) >> 26);
+            const uint32_t nt_lo = ~(uint32_t)sig_t, nt_hi = ~(uint32_t)(sig_t >> 32);
+#pragma unroll
+            for (uint32_t p = 0; p < kDictGroup; ++p) {
+                const uint32_t m = pk[p] & 0xFFu, max_d = (pk[p] >> 8) & 0xFFu;
+                const bool prefix = (pk[p] >> 17) & 1u, valid = pk[p] >> 31;
+                const bool len_ok = prefix || !(n > m + max_d || n + max_d < m);
+                const uint32_t lacking = (uint32_t)__popc(sg_lo[p] & nt_lo) + (uint32_t)__popc(sg_hi[p] & nt_hi);
+                pmask |= (valid && len_ok && lacking <= max_d) ? (1u << p) : 0u;
+            }
+        }
+        {
+            uint32_t total;
+            const uint32_t excl = wave_excl_scan_u32((uint32_t)__popc(pmask), &total);
+            uint32_t wbase = 0u;
+            if (total) {  // uniform
+                if ((tid & 63u) == 0u) wbase = atomicAdd(&qn, total);
+                wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            }
+            uint32_t w = wbase + excl;
+            while (pmask) {
+                const uint32_t p = (uint32_t)__ffs(pmask) - 1u;
+                pmask &= pmask - 1u;
+                queue[w++] = (uint16_t)(tid | (p << 8));
+            }
+        }
+        __syncthreads();
+        VQ_STAMP_AT(2)
+        // phase B — one lane per surviving (term, probe) pair: the recurrence runs with every lane busy instead of once per probe for a wave in
+        // which one lane survived
+        const uint32_t pairs = qn;
+#ifdef VQ_STAMP
+        _acc[11] += pairs;
+#endif
+        for (uint32_t x = tid; x < pairs; x += 256u) {
+            const uint32_t lt = queue[x] & 255u, p = queue[x] >> 8;
+            const uint32_t b = soff[lt], n = soff[lt + 1] - b;
+            const bool in_stage = b + n <= staged;
+            const uint32_t m = pm[p], max_d = pmaxd[p];
+            const bool transposition = pflags[p] & 1u, prefix = pflags[p] & 2u;
+            bool match, done = false;
+            if (m == 0) {
+                match = prefix || n <= max_d;
+                done = true;
+            } else if (in_stage && n <= kDictShort) {
+                if (m <= 32u) match = dict_match_short<uint32_t>(m, max_d, transposition, prefix, n, &stage[b], peq[p], &done);
+                else match = dict_match_short<unsigned long long>(m, max_d, transposition, prefix, n, &stage[b], peq[p], &done);
+            }
+            if (!done) {
+                if (in_stage) {
+                    if (m <= 32u) match = dict_match<uint32_t>(m, max_d, transposition, prefix, n, &stage[b], peq[p], qch[p]);
+                    else match = dict_match<unsigned long long>(m, max_d, transposition, prefix, n, &stage[b], peq[p], qch[p]);
+                } else {
+                    if (m <= 32u) match = dict_match<uint32_t>(m, max_d, transposition, prefix, n, chars + base + b, peq[p], qch[p]);
+                    else match = dict_match<unsigned long long>(m, max_d, transposition, prefix, n, chars + base + b, peq[p], qch[p]);
+                }
+            }
+            if (match) {  // rare: what the hit's score needs is computed here, on the lower-cased image
+                uint32_t info = 0;
+                if ((pflags[p] & 4u) && in_stage) {  // scored with the string and over the image it was matched with: everything is in LDS already
+                    const uint16_t* text = &stage[b];
+                    const uint32_t osa = dict_full_distance<true>(qch[p], peq[p], m, text, n), lev = dict_full_distance<false>(qch[p], peq[p], m, text, n);
+                    bool starts = n >= m;
+                    for (uint32_t i = 0; starts && i < m; ++i) starts = text[i] == qch[p][i];
+                    info = (osa < 255u ? osa : 255u) | ((lev < 255u ? lev : 255u) << 8) | ((starts ? 1u : 0u) << 16);
+                } else {
+                    const DictProbe& P = probes[p0 + p];
+                    const uint32_t lm = P.lm;
+                    if (lm != 0xFFFFFFFFu) {
+                        const uint16_t* text = low_chars + base + b;
+                        const uint32_t osa = dict_full_distance<true>(P.lquery, nullptr, lm, text, n), lev = dict_full_distance<false>(P.lquery, nullptr, lm, text, n);
+                        bool starts = n >= lm;
+                        for (uint32_t i = 0; starts && i < lm; ++i) starts = text[i] == P.lquery[i];
+                        info = (osa < 255u ? osa : 255u) | ((lev < 255u ? lev : 255u) << 8) | ((starts ? 1u : 0u) << 16);
+                    }
+                }
+                const uint32_t pos = atomicAdd(out_count, 1u);
+                if (pos < out_cap) out[pos] = DictMatch{probe_base + p0 + p, t0 + lt, info};
+            }
+        }
+        VQ_STAMP_AT(3)
     }
+    VQ_STAMP_FLUSH
 }
 
 void launch_dict_scan(hipStream_t st, const DictProbe* d_probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* off, const uint16_t* chars, const uint16_t* low_chars,
                       uint32_t num_terms, uint32_t* out_count, uint32_t out_cap, DictMatch* out) {
     if (!n_probes || !num_terms) return;
-    hipLaunchKernelGGL(k_dict_scan, dim3((num_terms + 255u) / 256u, (n_probes + kDictGroup - 1u) / kDictGroup), dim3(256), 0, st, d_probes, probe_base, n_probes, off, chars,
+    hipLaunchKernelGGL(k_dict_scan, dim3((num_terms + 256u * kDictRounds - 1u) / (256u * kDictRounds), (n_probes + kDictGroup - 1u) / kDictGroup), dim3(256), 0, st, d_probes, probe_base, n_probes, off, chars,
                        low_chars, num_terms, out_count, out_cap, out);
 }
 
