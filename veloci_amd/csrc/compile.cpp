@@ -16,6 +16,7 @@
 #include "text.hpp"
 
 namespace vq {
+std::atomic<uint64_t> g_compile_ns[6];  // 0 lookup_terms, 1 resolve_boost_1n, 2 emit_boost_1n rest, 3 leaf lists, 4 the longest single compile_query, 5 total
 
 using namespace vqreq;
 
@@ -136,6 +137,28 @@ struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:
     std::vector<std::pair<uint32_t, float>> hits_scores;  // (term id, term score), ascending term id
     std::vector<uint32_t> hits_ids;                        // term ids
     std::map<uint32_t, ExplainRecs> explain;               // options.explain: the dictionary result's records per term id (search_field.rs:334-343)
+};
+// VQ_TIMING: where request compilation spends its time (summed over threads, printed per batch by exec.cpp)
+struct PhaseTimer {
+    static bool on() {
+        static const bool v = std::getenv("VQ_TIMING") != nullptr;
+        return v;
+    }
+    int slot;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(int s) : slot(s) {
+        if (on()) t0 = std::chrono::steady_clock::now();
+    }
+    ~PhaseTimer() {
+        if (!on()) return;
+        const uint64_t ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+        g_compile_ns[slot] += ns;
+        if (slot == 5) {  // the longest single request: what bounds a parallel pass from below
+            uint64_t cur = g_compile_ns[4].load();
+            while (ns > cur && !g_compile_ns[4].compare_exchange_weak(cur, ns)) {
+            }
+        }
+    }
 };
 static bool part_explains(const RequestSearchPart& p) { return p.options && p.options->explain; }  // search_request.rs:182-184
 
@@ -289,6 +312,7 @@ struct Compiler {
 
     // get_term_ids_in_field (search_field.rs:277-398) — dictionary side only
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
+        PhaseTimer pt(0);
         const RequestSearchPart& p = *l.part;
         if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
@@ -568,6 +592,7 @@ struct Compiler {
     // maximum over its operands (set_op.rs:169-177), i.e. the same maximum over the same values; hits and scores are unchanged, the node keeps
     // one operand per distinct term.
     NodeInfo compile_leaf_lists(const std::string& label, const std::vector<Leaf*>& members, std::vector<DOp>& ops, uint32_t& sp) {
+        PhaseTimer pt(3);
         NodeInfo info;
         DOp op{};
         op.kind = OP_LEAF;
@@ -685,6 +710,7 @@ struct Compiler {
 
     // matched terms -> text ids -> value ids of the 1:n object -> (anchor, boost value) of every boosted value id (boost.rs:432-468)
     std::vector<std::pair<uint32_t, float>> resolve_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b) {
+        PhaseTimer pt(1);
         std::vector<uint32_t> ids;
         auto cit = idx.columns.find(part.path);
         const bool tokenized = cit != idx.columns.end() && cit->second.tokenize;
@@ -722,52 +748,74 @@ struct Compiler {
     // BoostToAnchor + ApplyAnchorBoost (plan_steps.rs:174-219): matched terms -> text ids -> value ids of the 1:n object ->
     // boost value and anchor of each value id (boost.rs:432-468), applied to the leaf's hits by anchor (boost.rs:255-281).
     void emit_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b, std::vector<DOp>& ops, uint32_t& sp) {
-        const std::string cache_key = part.key() + "|" + b.path;
-        std::shared_ptr<const std::vector<std::pair<uint32_t, float>>> cached;
-        if (boost_cache) {
-            std::lock_guard<std::mutex> g(boost_cache->mu);
-            auto it = boost_cache->map.find(cache_key);
-            if (it != boost_cache->map.end()) cached = it->second;
+        PhaseTimer pt(2);
+        // Everything below that is proportional to the boost list — resolving it, checking its order, cutting it into layers — is done ONCE per
+        // (leaf request, boost path) and batch: by whichever request gets there first, for all compilation passes and all requests that share
+        // the leaf (Boost1nCache).  What remains per request is copying the layers' arrays into its blob.
+        const std::string cache_key = (l.key.empty() ? part.key() : l.key) + "|" + b.path;
+        std::shared_ptr<Boost1nEntry> entry;
+        Boost1nCache local;
+        Boost1nCache& cache = boost_cache ? *boost_cache : local;
+        {
+            std::lock_guard<std::mutex> g(cache.mu);
+            auto& slot = cache.map[cache_key];
+            if (!slot) slot = std::make_shared<Boost1nEntry>();
+            entry = slot;
         }
-        if (!cached) {
-            auto fresh = std::make_shared<std::vector<std::pair<uint32_t, float>>>(resolve_boost_1n(part, l, b));
-            cached = fresh;
-            if (boost_cache) {
-                std::lock_guard<std::mutex> g(boost_cache->mu);
-                boost_cache->map.emplace(cache_key, cached);
+        auto make_layers = [&](const std::vector<std::vector<std::pair<uint32_t, float>>>& layers) {
+            auto out = std::make_shared<std::vector<Boost1nEntry::Layer>>();
+            for (auto& layer : layers) {
+                Boost1nEntry::Layer L;
+                L.global_len = layer.size();
+                L.docs.reserve(layer.size());
+                L.vals.reserve(layer.size());
+                for (auto& pr : layer)
+                    if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi) {
+                        L.docs.push_back(pr.first);
+                        L.vals.push_back(pr.second);
+                    }
+                out->push_back(std::move(L));
             }
-        }
-        const std::vector<std::pair<uint32_t, float>>& pairs = *cached;  // (anchor, boost value) in value-id order
-        bool several = false;
-        for (size_t i = 1; i < pairs.size(); ++i) {
-            if (pairs[i].first < pairs[i - 1].first) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
-            several = several || pairs[i].first == pairs[i - 1].first;
-        }
-        // layers[r]: the (r+1)-th value applied to an anchor — each layer is a sorted unique list, applied in order
-        std::vector<std::vector<std::pair<uint32_t, float>>> layers(1);
-        if (!several) layers[0] = pairs;
-        else {
+            return out;
+        };
+        std::call_once(entry->resolved, [&] {
+            entry->pairs = resolve_boost_1n(part, l, b);  // (anchor, boost value) in value-id order
+            const auto& pairs = entry->pairs;
+            for (size_t i = 1; i < pairs.size(); ++i) {
+                if (pairs[i].first < pairs[i - 1].first) entry->ascending = false;
+                entry->several = entry->several || pairs[i].first == pairs[i - 1].first;
+            }
+            if (!entry->ascending) return;
+            if (!entry->several) entry->layers = make_layers({pairs});
+            else
+                for (auto& pr : pairs)
+                    if (entry->anchors.empty() || entry->anchors.back() != pr.first) entry->anchors.push_back(pr.first);
+        });
+        if (!entry->ascending) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
+        std::shared_ptr<const std::vector<Boost1nEntry::Layer>> layers = entry->layers;
+        if (entry->several) {
             // Several boosted values on one anchor.  The reference walks the boost list against the leaf's hits with one look-ahead
             // entry (boost.rs:262-279): an anchor reached while the look-ahead already rests on its first entry gets that entry ONLY
             // (the rest is skipped at the next hit); reached by scanning forward, it gets ALL its entries.  With the entry anchors
             // a_0 < a_1 < ...: a_j is met resting on its first entry iff it is the very first entry, or the leaf has a hit strictly
             // between a_(j-1) and a_j, or a_(j-1) is a hit that was NOT met that way (its scan stopped on a_j's first entry).
             if (req.filter) unsupported("1:n field boost with several boosted values on one anchor, under a filter (" + b.path + ")");
-            std::vector<uint32_t> anchors;
-            for (auto& pr : pairs)
-                if (anchors.empty() || anchors.back() != pr.first) anchors.push_back(pr.first);
-            const std::string key = part.key() + "|" + b.path;
+            const std::vector<uint32_t>& anchors = entry->anchors;
+            const auto& pairs = entry->pairs;
             const RangeJob* done = nullptr;
             if (ranges) {
-                auto it = ranges->find(key);
+                auto it = ranges->find(cache_key);
                 if (it != ranges->end()) done = &it->second;
             }
             if (!done) {  // ask for the leaf's hits at every entry anchor and between neighbouring ones; compiled again afterwards
                 RangeJob job;
-                job.key = key;
+                job.key = cache_key;
                 job.store_path = l.path + TO_ANCHOR_ID_SCORE;
                 job.union_key = leaf_union_key(l);
+                job.tokens.reserve(l.hits_scores.size());
                 for (auto& h : l.hits_scores) job.tokens.push_back(h.first);
+                job.lo.reserve(2 * anchors.size());
+                job.hi.reserve(2 * anchors.size());
                 for (size_t j = 0; j < anchors.size(); ++j) {
                     job.lo.push_back(anchors[j]);
                     job.hi.push_back(anchors[j] + 1u);
@@ -775,47 +823,46 @@ struct Compiler {
                     job.hi.push_back(j ? anchors[j] : 0u);
                 }
                 cq.range_requests.push_back(std::move(job));
-                layers[0] = pairs;  // (placeholder: this compilation is thrown away)
-                layers[0].erase(std::unique(layers[0].begin(), layers[0].end(), [](auto& x, auto& y) { return x.first == y.first; }), layers[0].end());
+                // (placeholder: this compilation is thrown away)
+                static const auto empty = std::make_shared<const std::vector<Boost1nEntry::Layer>>(1);
+                layers = empty;
             } else {
                 if (done->counts.size() != 2 * anchors.size()) unsupported("1:n field boost: range pre-pass does not match the boost list (internal)");
-                bool prev_hit = false, prev_first_only = false;
-                size_t p = 0;
-                for (size_t j = 0; j < anchors.size(); ++j) {
-                    const bool hit = done->counts[2 * j] != 0, between = j && done->counts[2 * j + 1] != 0;
-                    const bool first_only = j == 0 || between || (prev_hit && !prev_first_only);
-                    size_t e = p;
-                    while (e < pairs.size() && pairs[e].first == anchors[j]) ++e;
-                    const size_t take = first_only ? 1 : e - p;
-                    if (hit)
-                        for (size_t r = 0; r < take; ++r) {
-                            if (layers.size() <= r) layers.emplace_back();
-                            layers[r].push_back(pairs[p + r]);
-                        }
-                    p = e;
-                    prev_hit = hit;
-                    prev_first_only = first_only;
-                }
-                if (layers.size() > 8) unsupported("1:n field boost with more than 8 boosted values on one anchor (" + b.path + ")");
+                std::call_once(entry->layered, [&] {
+                    std::vector<std::vector<std::pair<uint32_t, float>>> cut(1);
+                    bool prev_hit = false, prev_first_only = false;
+                    size_t p = 0;
+                    for (size_t j = 0; j < anchors.size(); ++j) {
+                        const bool hit = done->counts[2 * j] != 0, between = j && done->counts[2 * j + 1] != 0;
+                        const bool first_only = j == 0 || between || (prev_hit && !prev_first_only);
+                        size_t e = p;
+                        while (e < pairs.size() && pairs[e].first == anchors[j]) ++e;
+                        const size_t take = first_only ? 1 : e - p;
+                        if (hit)
+                            for (size_t r = 0; r < take; ++r) {
+                                if (cut.size() <= r) cut.emplace_back();
+                                cut[r].push_back(pairs[p + r]);
+                            }
+                        p = e;
+                        prev_hit = hit;
+                        prev_first_only = first_only;
+                    }
+                    entry->layers = make_layers(cut);
+                });
+                layers = entry->layers;
+                if (layers->size() > 8) unsupported("1:n field boost with more than 8 boosted values on one anchor (" + b.path + ")");
             }
         }
-        for (auto& layer : layers) {
-            std::vector<uint32_t> docs;
-            std::vector<float> vals;
-            for (auto& pr : layer)
-                if (pr.first >= idx.doc_lo && pr.first < idx.doc_hi) {
-                    docs.push_back(pr.first);
-                    vals.push_back(pr.second);
-                }
+        for (const Boost1nEntry::Layer& layer : *layers) {
             HList h;
-            h.len = uint32_t(docs.size());
-            h.global_len = layer.size();
+            h.len = uint32_t(layer.docs.size());
+            h.global_len = layer.global_len;
             h.flags = LIST_HAS_SCORES | LIST_F32;
             h.term_score = 1.0f;
             h.inline_idx = int(cq.inline_lists.size());
             h.inline_val_idx = int(cq.inline_vals.size());
-            cq.inline_lists.push_back(std::move(docs));
-            cq.inline_vals.push_back(std::move(vals));
+            cq.inline_lists.push_back(layer.docs);
+            cq.inline_vals.push_back(layer.vals);
             const uint32_t li = add_list(h);
             cq.algorithmic_bytes += 8ull * h.len;
             DColBoost cb{};
@@ -831,6 +878,7 @@ struct Compiler {
             push_op(ops, op, sp);
         }
     }
+
 
     NodeInfo compile_node(const SearchRequest& r, bool is_filter, std::vector<DOp>& ops, uint32_t& sp, const std::vector<RequestBoostPart>& boost) {
         NodeInfo info = compile_node_inner(r, is_filter, ops, sp, boost, is_filter ? UINT32_MAX : next_node++);
@@ -2193,6 +2241,7 @@ CompiledQuery compile_query(const Index& idx, const vqreq::Request& req_in, cons
         propagate_explain(*explained);
     }
     const vqreq::Request& req = explained ? *explained : req_in;
+    PhaseTimer pt(5);
     Compiler c(idx, req, fuzzy);
     c.boost_cache = boost_cache;
     c.localities = localities;

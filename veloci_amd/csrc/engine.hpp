@@ -189,9 +189,24 @@ struct RangeJob {
 };
 using RangeTable = std::map<std::string, RangeJob>;
 // (anchor, boost value) lists of 1:n field boosts resolved on the host, shared by the requests and compilation passes of one batch
+// One 1:n boost list of a batch (boost.rs:432-468 resolved for one leaf request and boost path), shared by the compilation passes and by every
+// request of the batch with that leaf: the (anchor, value) pairs, what the compiler needs to know about their order, and — once known — the
+// layers the device applies (one sorted unique list per applied value of an anchor).
+struct Boost1nEntry {
+    struct Layer {
+        std::vector<uint32_t> docs;
+        std::vector<float> vals;
+        uint64_t global_len = 0;
+    };
+    std::once_flag resolved, layered;
+    std::vector<std::pair<uint32_t, float>> pairs;
+    bool ascending = true, several = false;
+    std::vector<uint32_t> anchors;  // several: the distinct anchors, ascending
+    std::shared_ptr<const std::vector<Layer>> layers;
+};
 struct Boost1nCache {
     std::mutex mu;
-    std::unordered_map<std::string, std::shared_ptr<const std::vector<std::pair<uint32_t, float>>>> map;
+    std::unordered_map<std::string, std::shared_ptr<Boost1nEntry>> map;
 };
 // Text locality of a field whose text ids are not anchors (boost.rs:34-87), resolved before the final compilation by the K7 pre-pass: the
 // token -> text rows of the query's terms are gathered and sorted, texts occurring c > 1 times are expanded to their anchors with the boost

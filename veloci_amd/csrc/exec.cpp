@@ -698,6 +698,7 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
     }
 }
 
+extern std::atomic<uint64_t> g_compile_ns[6];
 static bool timing_enabled() {
     static const bool on = std::getenv("VQ_TIMING") != nullptr;
     return on;
@@ -740,9 +741,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
-        // parts are claimed dynamically and kept small (8 requests): a worker that wakes late — an idle core takes ~0.1 ms, a third of the whole
-        // job — still finds work, and nobody waits long for the last part
-        const size_t parts = host_threads() > 1 ? n / 8 : 1;
+        // parts are claimed dynamically, two requests at a time: a worker that wakes late — an idle core takes ~0.1 ms, a third of the whole job —
+        // still finds work, and requests of very different cost (a prefix leaf with a 1:n boost list takes 1000x a plain AND) balance out
+        const size_t parts = host_threads() > 1 ? n / 2 : 1;
         host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
@@ -794,8 +795,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 }
             }
         };
-        if (again.size() >= 32) {
-            const size_t parts = std::min<size_t>(2 * host_threads(), again.size() / 8);
+        if (again.size() >= 8 && host_threads() > 1) {
+            const size_t parts = again.size() / 2;
             host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
         } else recompile(0, again.size());
     }
@@ -1154,6 +1155,12 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], spans generic/simple/and/rich/union %u/%u/%u/%u/%u, pack+launch %.3f ms\n", n,
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
                      t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense + spans_leaf, now_ms() - t_compiled);
+    if (timing_enabled()) {  // thread-time inside compile_query since the last batch (all passes, all threads)
+        uint64_t v[6];
+        for (int k = 0; k < 6; ++k) v[k] = g_compile_ns[k].exchange(0);
+        std::fprintf(stderr, "[vq timing] compile thread-ms: total %.3f = dictionary lookups %.3f + 1:n resolve %.3f + 1:n layers %.3f + leaf lists %.3f + rest %.3f; longest request %.3f\n", v[5] * 1e-6,
+                     v[0] * 1e-6, v[1] * 1e-6, (v[2] - v[1]) * 1e-6, v[3] * 1e-6, (double(v[5]) - double(v[0]) - double(v[2]) - double(v[3])) * 1e-6, v[4] * 1e-6);
+    }
     return pb;
 }
 

@@ -1335,25 +1335,53 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
     __syncthreads();
     const uint32_t* h = hist + job.hist_off;
     const uint32_t k = job.top;
-    // four values per thread and round (the batch's histogram area is 4-byte aligned only: values are read one by one, but a round of 256
-    // mostly-zero entries costs one ballot instead of four push loops)
-    for (uint32_t base = 0; base < job.num_values; base += 4u * kBlock) {  // uniform trip count
-        uint32_t c4[4];
+    // Few entries wanted out of many (top 10 of 65 536 tag values): pass 1 keeps each lane's largest key in a register; the k-th largest of the 64
+    // lane maxima is a lower bound of the answer's smallest key (at least k keys reach it), so pass 2 pushes only the keys at or above it — a
+    // handful — instead of feeding every non-zero count through the candidate buffer and its prunes.  kFacetPerRound loads are in flight together.
+    constexpr uint32_t kFacetPerRound = 16;
+    auto key_of = [](uint32_t count, uint32_t v) { return ((unsigned long long)count << 32) | (unsigned long long)(0xFFFFFFFFu - v); };  // count desc, value id asc
+    unsigned long long bound = 1ull;  // (zero counts never enter)
+    if (k >= 1u && k <= (uint32_t)kBlock && job.num_values > 8u * (uint32_t)kBlock) {
+        unsigned long long mx = 0ull;
+        for (uint32_t base = 0; base < job.num_values; base += kFacetPerRound * kBlock) {
+            uint32_t c[kFacetPerRound];
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t v = base + j * kBlock + threadIdx.x;
-            c4[j] = v < job.num_values ? h[v] : 0u;
-        }
-        if (!__syncthreads_or((c4[0] | c4[1] | c4[2] | c4[3]) != 0u)) continue;  // uniform: nothing counted in these 256 values
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t v = base + j * kBlock + threadIdx.x;
-            unsigned long long key = 0ull;
-            bool pending = false;
-            if (c4[j]) {
-                key = ((unsigned long long)c4[j] << 32) | (unsigned long long)(0xFFFFFFFFu - v);  // count desc, value id asc
-                pending = key > *cs.thr;
+            for (uint32_t j = 0; j < kFacetPerRound; ++j) {
+                const uint32_t v = base + j * kBlock + threadIdx.x;
+                c[j] = v < job.num_values ? h[v] : 0u;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < kFacetPerRound; ++j)
+                if (c[j]) {
+                    const unsigned long long key = key_of(c[j], base + j * kBlock + threadIdx.x);
+                    mx = key > mx ? key : mx;
+                }
+        }
+        uint32_t rank = 0;  // position of this lane's maximum among the 64 (ties: lower lane first)
+        for (uint32_t l = 0; l < (uint32_t)kBlock; ++l) {
+            const unsigned long long o = shfl_u64(mx, l);
+            rank += (o > mx || (o == mx && l < threadIdx.x)) ? 1u : 0u;
+        }
+        const unsigned long long pick = __ballot(rank == k - 1u);
+        const unsigned long long kth = shfl_u64(mx, (uint32_t)__ffsll((long long)pick) - 1u);
+        if (kth > bound) bound = kth;
+    }
+    for (uint32_t base = 0; base < job.num_values; base += kFacetPerRound * kBlock) {  // uniform trip count
+        uint32_t c[kFacetPerRound];
+        bool any = false;
+#pragma unroll
+        for (uint32_t j = 0; j < kFacetPerRound; ++j) {
+            const uint32_t v = base + j * kBlock + threadIdx.x;
+            c[j] = v < job.num_values ? h[v] : 0u;
+            any = any || (c[j] && key_of(c[j], v) >= bound);
+        }
+        if (!__syncthreads_or(any)) continue;  // uniform: nothing of this round can enter
+#pragma unroll
+        for (uint32_t j = 0; j < kFacetPerRound; ++j) {
+            const uint32_t v = base + j * kBlock + threadIdx.x;
+            const unsigned long long key = c[j] ? key_of(c[j], v) : 0ull;
+            bool pending = key >= bound && key > *cs.thr;
+            if (!__syncthreads_or(pending)) continue;  // uniform
             while (true) {
                 if (pending) {
                     uint32_t pos = atomicAdd(cs.n, 1u);
