@@ -709,12 +709,12 @@ struct Compiler {
     }
 
     // matched terms -> text ids -> value ids of the 1:n object -> (anchor, boost value) of every boosted value id (boost.rs:432-468)
-    std::vector<std::pair<uint32_t, float>> resolve_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b) {
-        PhaseTimer pt(1);
+    // the text ids a leaf's matched terms stand for (resolve_token_hits_to_text_id_ids_only, search_field.rs:640-689)
+    std::vector<uint32_t> boost_1n_text_ids(const RequestSearchPart& part, Leaf& l) {
         std::vector<uint32_t> ids;
         auto cit = idx.columns.find(part.path);
         const bool tokenized = cit != idx.columns.end() && cit->second.tokenize;
-        if (tokenized) {  // search_field.rs:640-689
+        if (tokenized) {
             const KVStore& t2t = kv_store(l.path + TOKENS_TO_TEXT_ID);
             for (auto& h : l.hits_scores) {
                 const uint32_t *rb, *re;
@@ -724,6 +724,11 @@ struct Compiler {
             std::sort(ids.begin(), ids.end());
             ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
         } else ids = l.hits_ids;
+        return ids;
+    }
+    std::vector<std::pair<uint32_t, float>> resolve_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b) {
+        PhaseTimer pt(1);
+        const std::vector<uint32_t> ids = boost_1n_text_ids(part, l);
         std::vector<uint32_t> value_ids;  // join_to_parent_ids search.rs:281-315
         const KVStore& to_parent = kv_store(l.path + VALUE_ID_TO_PARENT);
         for (uint32_t id : ids) {
@@ -753,6 +758,60 @@ struct Compiler {
         // (leaf request, boost path) and batch: by whichever request gets there first, for all compilation passes and all requests that share
         // the leaf (Boost1nCache).  What remains per request is copying the layers' arrays into its blob.
         const std::string cache_key = (l.key.empty() ? part.key() : l.key) + "|" + b.path;
+        auto emit_layer = [&](const HList& h) {
+            const uint32_t li = add_list(h);
+            cq.algorithmic_bytes += 8ull * h.len;
+            DColBoost cb{};
+            fill_boost_params(cb, b);
+            cb.nskip = 0;  // apply_boost_values_anchor has no skip_when_score
+            cq.leaf_cols.push_back(cb);
+            DOp op{};
+            op.kind = OP_BOOST1N;
+            op.nchild = 1;
+            op.list_begin = uint16_t(li);
+            op.list_count = 1;
+            op.child_slot[0] = uint8_t(cq.leaf_cols.size() - 1);  // rebased behind the request-level boosts when the query is finished
+            push_op(ops, op, sp);
+        };
+        // K10 (VQ_BOOST1N_DEVICE=1): the list is resolved on the device (gather of the value ids, sort, boost value and anchor of each) — the compiler
+        // only learns its length and whether an anchor carries several values; then the look-ahead rule needs the pairs themselves: host path below.
+        // Off by default: measured on the reference's bench_jmdict request it moves 4 ms of host work per 256 requests into a 2.4 ms pre-pass
+        // (segmented sort 1.2 ms, one wave per list 1.1 ms) plus a third compilation pass, and the longest lists — prefix matches, which are
+        // the ones with several values per anchor — end on the host path anyway: 14.3 k instead of 17.3 k requests/s.
+        static const bool device_on = std::getenv("VQ_BOOST1N_DEVICE") != nullptr;
+        if (boost_cache && device_on) {
+            const std::string to_parent = l.path + VALUE_ID_TO_PARENT, to_anchor = b.path + VALUE_ID_TO_ANCHOR, col = b.path + BOOST_VALID_TO_VALUE;
+            auto kp = idx.kv.find(to_parent), ka = idx.kv.find(to_anchor);
+            const bool staged = kp != idx.kv.end() && ka != idx.kv.end() && kp->second.value_csr && ka->second.value_csr && idx.boost.count(col);
+            if (staged && !boost_cache->device) {  // first pass: ask for the list
+                Boost1nJob job;
+                job.key = cache_key;
+                job.to_parent_path = to_parent;
+                job.to_anchor_path = to_anchor;
+                job.boost_path = col;
+                job.text_ids = boost_1n_text_ids(part, l);
+                cq.boost1n_requests.push_back(std::move(job));
+                return;  // (this compilation is thrown away)
+            }
+            if (staged) {
+                auto it = boost_cache->device->find(cache_key);
+                if (it != boost_cache->device->end() && it->second.done) {
+                    const Boost1nJob& job = it->second;
+                    if (!job.ascending) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
+                    if (!job.several) {
+                        HList h;
+                        h.d_docs = job.d_docs;
+                        h.d_scores = reinterpret_cast<const uint16_t*>(job.d_vals);
+                        h.len = job.len;
+                        h.global_len = job.total;
+                        h.flags = LIST_HAS_SCORES | LIST_F32;
+                        h.term_score = 1.0f;
+                        emit_layer(h);
+                        return;
+                    }
+                }
+            }
+        }
         std::shared_ptr<Boost1nEntry> entry;
         Boost1nCache local;
         Boost1nCache& cache = boost_cache ? *boost_cache : local;
@@ -863,19 +922,7 @@ struct Compiler {
             h.inline_val_idx = int(cq.inline_vals.size());
             cq.inline_lists.push_back(layer.docs);
             cq.inline_vals.push_back(layer.vals);
-            const uint32_t li = add_list(h);
-            cq.algorithmic_bytes += 8ull * h.len;
-            DColBoost cb{};
-            fill_boost_params(cb, b);
-            cb.nskip = 0;  // apply_boost_values_anchor has no skip_when_score
-            cq.leaf_cols.push_back(cb);
-            DOp op{};
-            op.kind = OP_BOOST1N;
-            op.nchild = 1;
-            op.list_begin = uint16_t(li);
-            op.list_count = 1;
-            op.child_slot[0] = uint8_t(cq.leaf_cols.size() - 1);  // rebased behind the request-level boosts when the query is finished
-            push_op(ops, op, sp);
+            emit_layer(h);
         }
     }
 
@@ -2253,7 +2300,7 @@ CompiledQuery compile_query(const Index& idx, const vqreq::Request& req_in, cons
         if (!c.cq.range_requests.empty()) {
             c.cq.status = kStatusNeedsRanges;
             c.cq.error = "internal: range jobs pending";
-        } else if (!c.cq.union_requests.empty() || !c.cq.locality_requests.empty()) {
+        } else if (!c.cq.union_requests.empty() || !c.cq.locality_requests.empty() || !c.cq.boost1n_requests.empty()) {
             c.cq.status = kStatusNeedsUnion;
             c.cq.error = "internal: union jobs pending";
         } else if (c.cq.n_counts) {

@@ -207,6 +207,7 @@ struct Boost1nEntry {
 struct Boost1nCache {
     std::mutex mu;
     std::unordered_map<std::string, std::shared_ptr<Boost1nEntry>> map;
+    const std::map<std::string, struct Boost1nJob>* device = nullptr;  // lists the K10 pre-pass has resolved on the device (second compilation pass on)
 };
 // Text locality of a field whose text ids are not anchors (boost.rs:34-87), resolved before the final compilation by the K7 pre-pass: the
 // token -> text rows of the query's terms are gathered and sorted, texts occurring c > 1 times are expanded to their anchors with the boost
@@ -221,6 +222,22 @@ struct LocalityJob {
     uint32_t len = 0;
 };
 using LocalityTable = std::map<std::string, LocalityJob>;
+// A 1:n boost list (boost.rs:432-468) resolved by the K10 pre-pass: the leaf's text ids -> value ids of the 1:n object (gathered and sorted on
+// the device) -> the (anchor, boost value) pair of every boosted value id, in value-id order, as a (doc, f32) list the scans read.
+struct Boost1nJob {
+    std::string key;
+    std::string to_parent_path, to_anchor_path, boost_path;  // "<leaf>.textindex.value_id_to_parent", "<boost>.value_id_to_anchor", "<boost>.boost_valid_to_value"
+    std::vector<uint32_t> text_ids;
+    // result (lives in the batch workspace)
+    const uint32_t* d_docs = nullptr;
+    const float* d_vals = nullptr;
+    uint32_t len = 0;          // pairs inside this shard
+    uint32_t total = 0;        // pairs of the unsharded list
+    bool ascending = true;     // anchors non-decreasing in value-id order (else the reference's merge is not reproducible: declined)
+    bool several = false;      // some anchor has more than one boosted value: the look-ahead rule applies (host path)
+    bool done = false;
+};
+using Boost1nTable = std::map<std::string, Boost1nJob>;
 constexpr int kStatusNeedsUnion = -1;  // internal: compile again once the requested union / locality jobs have run
 constexpr int kStatusNeedsCounts = -2; // internal: the compiled query IS a count pre-pass; compile again with its results
 constexpr int kStatusNeedsRanges = -3; // internal: compile again once the requested range jobs have run
@@ -265,6 +282,10 @@ struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device ima
     // on every shard like the dictionary), read by the text-locality pre-pass (K7)
     bool text_csr = false;
     DevBuf d_text_vals;  // u32, host_values as handed over (row r = [host_off[r], host_off[r + 1]))
+    // 1:n boost use (K10): value_id_to_parent (text id -> value ids) and value_id_to_anchor (value id -> anchor) as whole CSRs in HBM: keys
+    // are not anchors, so the tables are replicated on every shard like the dictionary; d_text_vals holds the values, d_csr_off the offsets
+    bool value_csr = false;
+    DevBuf d_csr_off;    // u64 [num_keys + 1]
     // facet use: keys are anchors -> CSR restricted to the shard's anchors
     bool facet_csr = false;
     uint32_t csr_key_base = 0, csr_num_keys = 0;
@@ -347,6 +368,7 @@ struct Workspace {  // scratch of one in-flight batch
     DevBuf d_down;      // results
     DevBuf d_union_docs[2], d_union_vals[2], d_union_max, d_union_meta;  // materialised leaves (k_union), level 1 / level 2
     DevBuf d_loc_a, d_loc_b, d_loc_pairs_a, d_loc_pairs_b, d_loc_meta, d_loc_tmp, d_loc_docs, d_loc_vals;  // text locality pre-pass (K7)
+    DevBuf d_b1n_a, d_b1n_b, d_b1n_meta, d_b1n_tmp, d_b1n_docs, d_b1n_vals;                              // 1:n boost lists (K10)
     DevBuf d_probe_desc, d_probe_counts, d_probe_ids;                    // dictionary scans (k_dict_scan): kept, so that no hipFree synchronises the device mid-pipeline
 };
 
@@ -484,6 +506,7 @@ struct CompiledQuery {
     std::vector<RangeJob> range_requests;  // status == kStatusNeedsRanges
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
     std::vector<LocalityJob> locality_requests;  // likewise (K7)
+    std::vector<Boost1nJob> boost1n_requests;    // likewise (K10)
     std::vector<uint32_t> count_nodes;     // status == kStatusNeedsCounts: node ids; counters 2i / 2i+1 = hits / hits inside the filter, then the filter
     uint32_t n_counts = 0;
     std::vector<HList> lists;
@@ -525,6 +548,7 @@ CompiledQuery compile_query(const Index& idx, const vqreq::Request& req, const F
                             const QueryCounts* counts = nullptr, const RangeTable* ranges = nullptr, Boost1nCache* boost_cache = nullptr,
                             const LocalityTable* localities = nullptr);
 void run_locality_jobs(const Index& idx, Workspace& ws, LocalityTable& table, hipStream_t st);
+void run_boost1n_jobs(const Index& idx, Workspace& ws, Boost1nTable& table, hipStream_t st);
 void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st);
 void run_union_jobs(const Index& idx, Workspace& ws, UnionTable& table, hipStream_t st);
 struct Result;

@@ -31,6 +31,12 @@ void PinnedBuf::ensure(size_t n) {
     bytes = want;
 }
 
+extern std::atomic<uint64_t> g_compile_ns[6];
+static bool timing_enabled() {
+    static const bool on = std::getenv("VQ_TIMING") != nullptr;
+    return on;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 const char* const kKernelNames[K_COUNT_] = {"k_dict_scan", "k_union<count>", "k_union<write>", "k_range_hits", "k_tile_scan<count pre-pass>", "k_scan_leaf_f32",
@@ -638,6 +644,125 @@ void run_locality_jobs(const Index& idx, Workspace& ws, LocalityTable& table, hi
     }
 }
 
+// K10: the 1:n boost lists of a batch (boost.rs:432-468).  Host: one gather descriptor per text id (its value_id_to_parent row).  Device: gather
+// the value ids, sort them per job (value-id order is the order the reference applies the boosts in), k_b1n_map.
+void run_boost1n_jobs(const Index& idx, Workspace& ws, Boost1nTable& table, hipStream_t st) {
+    const double t_begin = now_ms();
+    std::vector<Boost1nJob*> jobs;
+    for (auto& kv : table) jobs.push_back(&kv.second);
+    if (jobs.empty()) return;
+    std::stable_sort(jobs.begin(), jobs.end(), [](const Boost1nJob* a, const Boost1nJob* b) { return a->to_parent_path < b->to_parent_path; });
+    const size_t nj = jobs.size();
+    std::vector<B1nJob> dj(nj);
+    std::vector<LocRow> rows;
+    std::vector<std::pair<size_t, size_t>> table_rows;  // per run of jobs over one value_id_to_parent table: [first row, end row)
+    uint64_t cursor = 0, out_cursor = 0;
+    for (size_t j = 0; j < nj; ++j) {
+        const KVStore& to_parent = idx.kv.at(jobs[j]->to_parent_path);
+        const KVStore& to_anchor = idx.kv.at(jobs[j]->to_anchor_path);
+        const BoostColumn& col = idx.boost.at(jobs[j]->boost_path);
+        if (j == 0 || jobs[j]->to_parent_path != jobs[j - 1]->to_parent_path) table_rows.push_back({rows.size(), rows.size()});
+        B1nJob& J = dj[j];
+        std::memset(&J, 0, sizeof J);
+        J.boost_present = col.has_present ? col.present.as<uint32_t>() : nullptr;
+        J.boost_values = col.values.as<float>();
+        J.boost_key_base = col.key_base;
+        J.boost_num_keys = col.num_keys;
+        J.to_anchor_off = to_anchor.d_csr_off.as<uint64_t>();
+        J.to_anchor_vals = to_anchor.d_text_vals.as<uint32_t>();
+        J.to_anchor_key_base = to_anchor.key_base;
+        J.to_anchor_num_keys = to_anchor.num_keys;
+        J.doc_lo = idx.doc_lo;
+        J.doc_hi = idx.doc_hi;
+        J.seg_begin = uint32_t(cursor);
+        for (uint32_t id : jobs[j]->text_ids) {
+            if (id < to_parent.key_base || id - to_parent.key_base >= to_parent.num_keys) continue;
+            const uint32_t r = id - to_parent.key_base;
+            uint64_t src = to_parent.host_off[r], left = to_parent.host_off[r + 1] - to_parent.host_off[r];
+            while (left) {
+                const uint32_t piece = uint32_t(std::min<uint64_t>(left, 65536));
+                rows.push_back(LocRow{src, cursor, piece, 0u});
+                src += piece;
+                cursor += piece;
+                left -= piece;
+            }
+        }
+        if (cursor > 0xFFFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "1:n field boost: more than 2^32 value ids in one batch");
+        J.seg_end = uint32_t(cursor);
+        J.out_off = uint32_t(out_cursor);
+        out_cursor += (uint64_t(J.seg_end - J.seg_begin) + 8 + 3) / 4 * 4;  // 8 sentinel entries behind every list, starts stay 16-byte aligned
+        if (out_cursor > 0xFFFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "1:n field boost: more than 2^32 value ids in one batch");
+        table_rows.back().second = rows.size();
+    }
+    const uint32_t E = uint32_t(cursor);
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_jobs = 0, o_rows = al(nj * sizeof(B1nJob)), o_sb = o_rows + al(rows.size() * sizeof(LocRow)), o_se = o_sb + al(nj * 4), o_res = o_se + al(nj * 4),
+                 meta_bytes = o_res + al(nj * sizeof(B1nResult));
+    ws.d_b1n_meta.ensure(meta_bytes);
+    ws.d_b1n_a.ensure(size_t(E) * 4 + 16);
+    ws.d_b1n_b.ensure(size_t(E) * 4 + 16);
+    ws.d_b1n_docs.ensure(out_cursor * 4 + 64);
+    ws.d_b1n_vals.ensure(out_cursor * 4 + 64);
+    uint8_t* m = ws.d_b1n_meta.as<uint8_t>();
+    std::vector<uint32_t> sb(nj), se(nj);
+    for (size_t j = 0; j < nj; ++j) {
+        sb[j] = dj[j].seg_begin;
+        se[j] = dj[j].seg_end;
+    }
+    const double t_rows = now_ms();
+    LaunchTimer timer(idx.profile.enabled, ws, st, K_BOOST1N, size_t(E) * 24, size_t(E) * 12, nj);
+    VQ_HIP(hipMemcpyAsync(m + o_jobs, dj.data(), nj * sizeof(B1nJob), hipMemcpyHostToDevice, st));
+    if (!rows.empty()) VQ_HIP(hipMemcpyAsync(m + o_rows, rows.data(), rows.size() * sizeof(LocRow), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_sb, sb.data(), nj * 4, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(m + o_se, se.data(), nj * 4, hipMemcpyHostToDevice, st));
+    if (E) {
+        size_t tr = 0;
+        for (size_t j = 0; j < nj; ++j)
+            if (j == 0 || jobs[j]->to_parent_path != jobs[j - 1]->to_parent_path) {
+                const KVStore& to_parent = idx.kv.at(jobs[j]->to_parent_path);
+                const auto [r0, r1] = table_rows[tr++];
+                launch_loc_gather(st, reinterpret_cast<const LocRow*>(m + o_rows) + r0, uint32_t(r1 - r0), to_parent.d_text_vals.as<uint32_t>(), ws.d_b1n_a.as<uint32_t>());
+            }
+        VQ_HIP(hipGetLastError());
+        const size_t need = seg_sort_u32(nullptr, 0, ws.d_b1n_a.as<uint32_t>(), ws.d_b1n_b.as<uint32_t>(), E, uint32_t(nj), reinterpret_cast<const uint32_t*>(m + o_sb),
+                                         reinterpret_cast<const uint32_t*>(m + o_se), st);
+        if (need == size_t(-1)) throw VelociError(ERR_DEVICE, "segmented radix sort failed (size query)");
+        ws.d_b1n_tmp.ensure(need + 256);
+        if (seg_sort_u32(ws.d_b1n_tmp.p, need, ws.d_b1n_a.as<uint32_t>(), ws.d_b1n_b.as<uint32_t>(), E, uint32_t(nj), reinterpret_cast<const uint32_t*>(m + o_sb),
+                         reinterpret_cast<const uint32_t*>(m + o_se), st) == size_t(-1))
+            throw VelociError(ERR_DEVICE, "segmented radix sort failed");
+    }
+    double t_sorted = 0;
+    if (timing_enabled()) {
+        VQ_HIP(hipStreamSynchronize(st));
+        t_sorted = now_ms();
+    }
+    launch_b1n_map(st, reinterpret_cast<const B1nJob*>(m + o_jobs), uint32_t(nj), ws.d_b1n_b.as<uint32_t>(), ws.d_b1n_docs.as<uint32_t>(), ws.d_b1n_vals.as<float>(),
+                   reinterpret_cast<B1nResult*>(m + o_res));
+    VQ_HIP(hipGetLastError());
+    std::vector<B1nResult> res(nj);
+    VQ_HIP(hipMemcpyAsync(res.data(), m + o_res, nj * sizeof(B1nResult), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    for (size_t j = 0; j < nj; ++j) {
+        jobs[j]->d_docs = ws.d_b1n_docs.as<uint32_t>() + dj[j].out_off;
+        jobs[j]->d_vals = ws.d_b1n_vals.as<float>() + dj[j].out_off;
+        jobs[j]->len = res[j].len;
+        jobs[j]->total = res[j].total;
+        jobs[j]->ascending = !(res[j].flags & 1u);
+        jobs[j]->several = (res[j].flags & 2u) != 0;
+        jobs[j]->done = true;
+    }
+    if (timing_enabled()) {
+        uint32_t longest = 0, n_several = 0;
+        for (size_t j = 0; j < nj; ++j) {
+            longest = std::max(longest, dj[j].seg_end - dj[j].seg_begin);
+            n_several += jobs[j]->several ? 1u : 0u;
+        }
+        std::fprintf(stderr, "[vq timing] 1:n boost lists (K10): %zu jobs, %u value ids (longest list %u, %u with several values per anchor), %zu gather rows; host rows %.3f ms, gather + sort %.3f ms, map %.3f ms\n",
+                     nj, E, longest, n_several, rows.size(), t_rows - t_begin, t_sorted - t_rows, now_ms() - t_sorted);
+    }
+}
+
 // Count pre-pass: launches k_tile_scan in count mode for queries whose AND operands' result sizes the compiler needs
 // (set_op.rs:388-393,439) and returns them per query.  Presence only: no scores are read.
 static void run_count_queries(const Index& idx, Workspace& ws, const std::vector<CompiledQuery*>& cqs, std::vector<QueryCounts>& out, hipStream_t st) {
@@ -698,12 +823,6 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
     }
 }
 
-extern std::atomic<uint64_t> g_compile_ns[6];
-static bool timing_enabled() {
-    static const bool on = std::getenv("VQ_TIMING") != nullptr;
-    return on;
-}
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot, int64_t arena_offset) {
     const double t_start = now_ms();
@@ -751,15 +870,14 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     UnionTable unions;
     RangeTable ranges;
     LocalityTable localities;
+    Boost1nTable boost1n;
     std::vector<size_t> again;
-    bool any_ranges = false;
     for (size_t i = 0; i < n; ++i)
         if (pb->queries[i].status == kStatusNeedsUnion || pb->queries[i].status == kStatusNeedsRanges) {
             again.push_back(i);
             for (auto& j : pb->queries[i].union_requests) unions.emplace(j.key, j);
             for (auto& j : pb->queries[i].locality_requests) localities.emplace(j.key, j);
-            for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
-            any_ranges = any_ranges || pb->queries[i].status == kStatusNeedsRanges;
+            for (auto& j : pb->queries[i].boost1n_requests) boost1n.emplace(j.key, j);
         }
     double t_unions = t_pass1, t_ranges = t_pass1;
     if (!again.empty()) {
@@ -773,32 +891,49 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             for (auto& kv : unions) kv.second.global_len = lens[k++];
         }
         if (!localities.empty()) run_locality_jobs(idx, ws, localities, pst);
+        if (!boost1n.empty()) {
+            run_boost1n_jobs(idx, ws, boost1n, pst);
+            boost_cache.device = &boost1n;
+        }
         t_unions = t_ranges = now_ms();
-        // ---- 1:n boosts with several values per anchor: which of them apply follows the leaf's hits around each anchor (k_range_hits,
-        //      on the merged list of a materialised leaf)
-        const bool ranges_ok = !any_ranges || !idx.sharded() || idx.can_sum_over_shards();
-        if (any_ranges && ranges_ok) run_range_jobs(idx, ws, ranges, unions, pst);
-        t_ranges = now_ms();
-        auto recompile = [&](size_t b, size_t e) {
-            for (size_t k = b; k < e; ++k) {
-                CompiledQuery& q = pb->queries[again[k]];
-                if (q.status == kStatusNeedsRanges && !ranges_ok) {
-                    q.status = ERR_UNSUPPORTED;
-                    q.error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
-                    continue;
+        // Compile again with the jobs' results.  A 1:n boost list only shows once it is resolved (K10) whether an anchor carries several values:
+        // those leaves then ask for a range pre-pass — which of the values apply follows the leaf's hits around each anchor (k_range_hits, on the
+        // merged list of a materialised leaf) — and are compiled a third time.
+        for (int round = 0; round < 2 && !again.empty(); ++round) {
+            bool any_ranges = false;
+            for (size_t i : again)
+                if (pb->queries[i].status == kStatusNeedsRanges) {
+                    any_ranges = true;
+                    for (auto& j : pb->queries[i].range_requests) ranges.emplace(j.key, j);
                 }
-                q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, nullptr, ranges.empty() ? nullptr : &ranges, &boost_cache,
-                                  localities.empty() ? nullptr : &localities);
-                if (q.status == kStatusNeedsUnion || q.status == kStatusNeedsRanges) {
-                    q.status = ERR_UNSUPPORTED;
-                    q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
+            const bool ranges_ok = !any_ranges || !idx.sharded() || idx.can_sum_over_shards();
+            if (any_ranges && ranges_ok) run_range_jobs(idx, ws, ranges, unions, pst);
+            t_ranges = now_ms();
+            auto recompile = [&](size_t b, size_t e) {
+                for (size_t k = b; k < e; ++k) {
+                    CompiledQuery& q = pb->queries[again[k]];
+                    if (q.status == kStatusNeedsRanges && !ranges_ok) {
+                        q.status = ERR_UNSUPPORTED;
+                        q.error = "unsupported on the MI355X query path: 1:n field boost with several boosted values on one anchor, on a sharded index without vq_index_set_allreduce";
+                        continue;
+                    }
+                    q = compile_query(idx, *reqs[again[k]], fuzzy.empty() ? nullptr : &fuzzy, unions.empty() ? nullptr : &unions, nullptr, ranges.empty() ? nullptr : &ranges, &boost_cache,
+                                      localities.empty() ? nullptr : &localities);
+                    if (q.status == kStatusNeedsUnion || (q.status == kStatusNeedsRanges && round == 1)) {
+                        q.status = ERR_UNSUPPORTED;
+                        q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
+                    }
                 }
-            }
-        };
-        if (again.size() >= 8 && host_threads() > 1) {
-            const size_t parts = again.size() / 2;
-            host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
-        } else recompile(0, again.size());
+            };
+            if (again.size() >= 8 && host_threads() > 1) {
+                const size_t parts = again.size() / 2;
+                host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
+            } else recompile(0, again.size());
+            std::vector<size_t> still;
+            for (size_t i : again)
+                if (pb->queries[i].status == kStatusNeedsRanges) still.push_back(i);
+            again.swap(still);
+        }
     }
     const RangeTable* rangesp = ranges.empty() ? nullptr : &ranges;
     // ---- ANDs whose summation order / label follow run-time operand sizes: count pre-pass, then the final compilation

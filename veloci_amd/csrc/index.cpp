@@ -290,6 +290,14 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
             s.d_text_vals.upload(k.values.data(), k.values.size() * 4);
             idx->device_bytes += s.d_text_vals.bytes;
         }
+        if (ends_with(path, VALUE_ID_TO_PARENT) || ends_with(path, VALUE_ID_TO_ANCHOR)) {  // the 1:n boost pre-pass (K10) walks these on the device
+            s.value_csr = true;
+            s.d_text_vals.alloc(k.values.size() * 4 + 16);
+            s.d_text_vals.upload(k.values.data(), k.values.size() * 4);
+            s.d_csr_off.alloc(k.offsets.size() * 8 + 16);
+            s.d_csr_off.upload(k.offsets.data(), k.offsets.size() * 8);
+            idx->device_bytes += s.d_text_vals.bytes + s.d_csr_off.bytes;
+        }
         // facet sources: anchor-keyed value lists (facet.rs:38-44)
         s.facet_csr = ends_with(path, ANCHOR_TO_TEXT_ID) || (ends_with(path, PARENT_TO_VALUE_ID) && path.find("[]") == std::string::npos);
         if (s.facet_csr) {

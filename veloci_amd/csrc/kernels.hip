@@ -3070,6 +3070,79 @@ void launch_loc_expand(hipStream_t st, bool write, const LocJob* jobs, uint32_t 
 }
 
 // one wave per job: an ordered compaction of its sorted pairs
+// K10 — one wave per 1:n boost list: its sorted value ids, 4 x 64 at a time (all lookups of a round in flight together), keep the boosted
+// ones (boost_valid_to_value has an entry), look the anchor up (value_id_to_anchor, first value of the row: boost.rs:455-463), and compact
+// the (anchor, value) pairs of the shard's docs into the job's padded (doc, f32) list in value-id order.  Along the way: are the anchors
+// non-decreasing, does one repeat (the compiler needs both, see Boost1nJob).
+__global__ __launch_bounds__(64) void k_b1n_map(const B1nJob* __restrict__ jobs, const uint32_t* __restrict__ vids, uint32_t* __restrict__ out_docs,
+                                                float* __restrict__ out_vals, B1nResult* __restrict__ results) {
+    const B1nJob J = jobs[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    uint32_t written = 0, total = 0, flags = 0;
+    uint32_t prev = 0;       // anchor of the last pair seen so far (any shard)
+    bool have_prev = false;  // uniform
+    for (uint32_t base = J.seg_begin; base < J.seg_end; base += 256u) {  // uniform
+        uint32_t anchor[4];
+        float value[4];
+        bool keep[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = base + u * 64u + lane;
+            keep[u] = false;
+            anchor[u] = 0u;
+            value[u] = 0.0f;
+            if (i < J.seg_end) {
+                const uint32_t v = vids[i];
+                if (v >= J.boost_key_base && v - J.boost_key_base < J.boost_num_keys && v >= J.to_anchor_key_base && v - J.to_anchor_key_base < J.to_anchor_num_keys) {
+                    const uint32_t rb = v - J.boost_key_base, ra = v - J.to_anchor_key_base;
+                    const bool present = !J.boost_present || ((J.boost_present[rb >> 5] >> (rb & 31u)) & 1u);
+                    const unsigned long long a0 = J.to_anchor_off[ra], a1 = J.to_anchor_off[ra + 1];
+                    if (present && a1 > a0) {
+                        keep[u] = true;
+                        anchor[u] = J.to_anchor_vals[a0];
+                        value[u] = J.boost_values[rb];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const unsigned long long m = __ballot(keep[u]);
+            if (!m) continue;  // uniform
+            // order checks against the pair in front (previous kept lane, or the last pair of the rounds before)
+            const unsigned long long below = m & ((1ull << lane) - 1ull);
+            const uint32_t got = (uint32_t)__shfl((int)anchor[u], below ? 63 - (int)__clzll((long long)below) : (int)lane);  // (executed by every lane)
+            const uint32_t before = below ? got : prev;
+            const bool has_before = below ? true : have_prev;
+            if (keep[u] && has_before) {
+                if (anchor[u] < before) flags |= 1u;
+                if (anchor[u] == before) flags |= 2u;
+            }
+            const bool in_shard = keep[u] && anchor[u] >= J.doc_lo && anchor[u] < J.doc_hi;
+            const unsigned long long ms = __ballot(in_shard);
+            if (in_shard) {
+                const uint32_t pos = J.out_off + written + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+                out_docs[pos] = anchor[u];
+                out_vals[pos] = value[u];
+            }
+            written += (uint32_t)__popcll(ms);
+            total += (uint32_t)__popcll(m);
+            prev = (uint32_t)__shfl((int)anchor[u], 63 - (int)__clzll((long long)m));
+            have_prev = true;
+        }
+    }
+    flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(flags & 1u) ? 1u : 0u)) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(flags & 2u) ? 2u : 0u));
+    if (lane < 8u) {  // sentinels behind the list: the scans read whole 16-byte vectors
+        out_docs[J.out_off + written + lane] = 0xFFFFFFFFu;
+        out_vals[J.out_off + written + lane] = 0.0f;
+    }
+    if (lane == 0) results[blockIdx.x] = B1nResult{written, total, flags, 0u};
+}
+void launch_b1n_map(hipStream_t st, const B1nJob* jobs, uint32_t n_jobs, const uint32_t* sorted_value_ids, uint32_t* out_docs, float* out_vals, B1nResult* results) {
+    if (!n_jobs) return;
+    hipLaunchKernelGGL(k_b1n_map, dim3(n_jobs), dim3(64), 0, st, jobs, sorted_value_ids, out_docs, out_vals, results);
+}
+
 __global__ __launch_bounds__(64) void k_loc_compact(const LocJob* __restrict__ jobs, const unsigned long long* __restrict__ sorted, uint32_t* __restrict__ out_docs,
                                                     float* __restrict__ out_vals, uint32_t* __restrict__ out_len) {
     const LocJob J = jobs[blockIdx.x];

@@ -92,6 +92,20 @@ size_t seg_sort_u32(void* tmp, size_t tmp_bytes, const uint32_t* in, uint32_t* o
 size_t seg_sort_u64(void* tmp, size_t tmp_bytes, const unsigned long long* in, unsigned long long* out, uint32_t n, uint32_t nseg, const uint32_t* seg_begin,
                     const uint32_t* seg_end, hipStream_t st);
 
+// ---- 1:n boost lists (K10, boost.rs:432-468)
+struct B1nJob {  // sorted value ids [seg_begin, seg_end) -> the (anchor, boost value) pair of every boosted one, in value-id order
+    const uint32_t* boost_present;  // bitmap over [boost_key_base, + boost_num_keys), or null = all present
+    const float* boost_values;
+    const uint64_t* to_anchor_off;  // value_id_to_anchor as a CSR
+    const uint32_t* to_anchor_vals;
+    uint32_t boost_key_base, boost_num_keys, to_anchor_key_base, to_anchor_num_keys;
+    uint32_t seg_begin, seg_end, out_off, doc_lo, doc_hi, pad;
+};
+struct B1nResult {
+    uint32_t len, total, flags, pad;  // pairs inside [doc_lo, doc_hi) / in all; flags: 1 anchors not ascending, 2 an anchor with several values
+};
+void launch_b1n_map(hipStream_t st, const B1nJob* jobs, uint32_t n_jobs, const uint32_t* sorted_value_ids, uint32_t* out_docs, float* out_vals, B1nResult* results);
+
 // ---- explain: the returned hits' scores recomputed step by step, every intermediate value written to a trace
 struct ExList {  // one posting list of one matched term (search_field.rs:419-444)
     const uint32_t* docs;
