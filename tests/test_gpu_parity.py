@@ -407,8 +407,9 @@ def test_reference_integration_case(case):
 
 
 # ------------------------------------------------------------------ randomized differential test on the reference's own fixture corpus
-def _random_request(rng, info, depth=0):
-    """Random Request over the `test_all` corpus: trees of exact / fuzzy / prefix leaves, filters, boosts, phrase pairs, locality, facets."""
+def _random_request(rng, info, depth=0, extras=False):
+    """Random Request over the `test_all` corpus: trees of exact / fuzzy / prefix leaves, filters, boosts, phrase pairs, locality, facets;
+    extras: also one term expanded over several fields (the query generator's shape: fused leaves), regex leaves, why_found, explain."""
     text_fields = ["meanings.ger[]", "meanings.eng[]", "tags[]", "title", "ent_seq", "kanji[].text", "field1[].text", "address[].line[]"]
 
     def leaf():
@@ -429,14 +430,26 @@ def _random_request(rng, info, depth=0):
             part["boost"] = float(rng.choice([0.5, 2.0, 3.5]))
         if rng.random() < 0.1:
             part["top"] = int(rng.integers(1, 4))
+        if extras and rng.random() < 0.06 and len(t) >= 3 and t.isalnum():
+            part = {"path": path, "terms": [".*" + t[1:3] + ".*"], "is_regex": True}
         return {"search": part}
+
+    def expansion():
+        """one term over 2-6 fields, as query_parser_to_veloci_request.rs:84-109 writes it"""
+        base = leaf()["search"]
+        fields = [text_fields[int(i)] for i in rng.choice(len(text_fields), size=int(rng.integers(2, 7)), replace=False)]
+        return [{"search": dict(base, path=f)} for f in fields]
 
     def tree(d):
         if d >= 2 or rng.random() < 0.4:
             return leaf()
         kind = "and" if rng.random() < 0.4 else "or"
         wide = d >= 1 and rng.random() < 0.1  # (one leaf per term and field, as the query generator writes them)
-        return {kind: {"queries": [tree(d + 1) for _ in range(int(rng.integers(5, 8) if wide else rng.integers(2, 4)))]}}
+        queries = [tree(d + 1) for _ in range(int(rng.integers(5, 8) if wide else rng.integers(2, 4)))]
+        if extras and kind == "or" and rng.random() < 0.35:
+            for _ in range(int(rng.integers(1, 3))):
+                queries[int(rng.integers(0, len(queries) + 1)):0] = expansion()
+        return {kind: {"queries": queries}}
 
     req = {"search_req": tree(0), "top": int(rng.choice([1, 3, 10, 50]))}
     if rng.random() < 0.2:
@@ -469,6 +482,10 @@ def _random_request(rng, info, depth=0):
         req["text_locality"] = True
     if rng.random() < 0.3:
         req["facets"] = [{"field": str(rng.choice(["tags[]", "commonness", "meanings.eng[]"]))}]
+    if extras and rng.random() < 0.15:
+        req["why_found"] = True
+    if extras and rng.random() < 0.2 and "phrase_boosts" not in req and not any("[]" in b["path"] for b in req.get("boost", [])):
+        req["explain"] = True  # (with phrase boosts or a 1:n boost: declined)
     return req
 
 
@@ -483,7 +500,7 @@ def test_random_requests_on_reference_corpus_match_the_oracle():
     rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "20241003")))
     ran = declined = 0
     for i in range(600):
-        req = _random_request(rng, info)
+        req = _random_request(rng, info, extras=i % 2 == 1)
         js = json.dumps(req)
         try:
             want = ora.search_json(js)
@@ -502,8 +519,11 @@ def test_random_requests_on_reference_corpus_match_the_oracle():
             continue
         exact = not any(b.get("boost_fun") in ("Log10", "Log2") for b in req.get("boost", []))
         assert_same(req, got, want, exact_scores=exact)
+        assert {k: sorted(v) for k, v in got.why_found_terms.items()} == {k: sorted(v) for k, v in want.why_found_terms.items()}, js
+        if exact:
+            assert got.explain_json == (want.explain_json if req.get("explain") else "null"), js
         ran += 1
-    assert declined <= 6 and ran >= 590, (ran, declined)
+    assert declined <= 6 and ran >= 585, (ran, declined)
 
 
 def test_1n_boost_with_several_values_per_anchor_follows_the_reference_walk():
