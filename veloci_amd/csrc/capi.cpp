@@ -5,6 +5,9 @@
 #include <cstring>
 
 #include "../../include/veloci_amd.h"
+#include <functional>
+#include <future>
+
 #include "engine.hpp"
 #include "text.hpp"
 
@@ -674,6 +677,40 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             copy_flat(results, st, errs, bounds(c).first, stride, num_hits, counts, ids, scores, status);
             inflight[c].reset();
         };
+        // Requests with pre-passes (dictionary scans of fuzzy / prefix leaves, then unions) make the HOST side of a chunk long: it waits for
+        // each pre-pass.  Two host threads, two chunks each, keep the GPU fed (config #4: 4.3 ms of kernels per chunk against 5 ms of
+        // host-visible time; one thread: 50 k requests/s).  Plain batches stay on the calling thread: their host side is short.
+        static const bool one_thread = std::getenv("VQ_FLAT_ONE_THREAD") != nullptr;
+        bool prepasses = false;
+        if (nchunks == 4 && kWorkspaces >= 4 && !one_thread) {
+            std::function<bool(const vqreq::SearchRequest&)> scans = [&](const vqreq::SearchRequest& r) {
+                if (r.kind == vqreq::SearchRequest::Search) return vq::needs_dictionary_scan(r.part);
+                for (auto& q : r.tree.queries)
+                    if (scans(q)) return true;
+                return false;
+            };
+            for (size_t i = 0; i < n && !prepasses; i += 16)  // (a sample: the decision is about the batch's character)
+                prepasses = reqs[i] && reqs[i]->search_req && scans(*reqs[i]->search_req);
+        }
+        if (prepasses) {
+            auto half = [&](size_t t) {
+                for (size_t c : {t, t + 2}) {
+                    auto [b, e] = bounds(c);
+                    inflight[c] = run_partial(*index->idx, reqs.data() + b, e - b, int(c));
+                }
+                finish(t);
+                finish(t + 2);
+            };
+            auto other = std::async(std::launch::async, half, size_t(1));
+            try {
+                half(0);
+            } catch (...) {
+                other.wait();
+                throw;
+            }
+            other.get();
+            return;
+        }
         for (size_t c = 0; c < nchunks; ++c) {
             if (c >= size_t(kWorkspaces)) finish(c - kWorkspaces);
             auto [b, e] = bounds(c);

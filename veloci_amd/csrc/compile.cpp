@@ -1427,13 +1427,19 @@ struct Compiler {
         for (size_t o = 0; o < cq.ops.size(); ++o) {
             const DOp& op = cq.ops[o];
             if (op.kind == OP_LEAF) {
-                if (op.list_count != 1) return;
-                const HList& l = cq.lists[op.list_begin];
-                if (!(l.flags & LIST_HAS_SCORES) || l.inline_idx >= 0 || l.inline_val_idx >= 0) return;
-                if (leaves.size() >= 4) return;
-                if (l.flags & LIST_F32) S.f32_mask |= uint8_t(1u << leaves.size());
-                st.push_back(Node{true, uint32_t(leaves.size()), op, {}});
-                leaves.push_back(op.list_begin);
+                if (op.list_count == 0 || op.list_count > 4) return;
+                Node g{false, 0, op, {}};  // a leaf over 2-4 posting lists (a fuzzy term that matched a few dictionary terms): a group that takes the maximum
+                g.op.kind = OP_LEAFMAX;
+                for (uint32_t j = 0; j < op.list_count; ++j) {
+                    const HList& l = cq.lists[op.list_begin + j];
+                    if (!(l.flags & LIST_HAS_SCORES) || l.inline_idx >= 0 || l.inline_val_idx >= 0) return;
+                    if (leaves.size() >= 4) return;
+                    if (l.flags & LIST_F32) S.f32_mask |= uint8_t(1u << leaves.size());
+                    g.kids.push_back(uint32_t(leaves.size()));
+                    leaves.push_back(uint16_t(op.list_begin + j));
+                }
+                if (op.list_count == 1) st.push_back(Node{true, g.kids[0], op, {}});
+                else st.push_back(g);
             } else if (op.kind == OP_AND || op.kind == OP_OR) {
                 if (op.nchild > st.size() || op.nchild > 4) return;
                 std::vector<Node> kids(st.end() - op.nchild, st.end());
@@ -1473,12 +1479,15 @@ struct Compiler {
             } else return;  // OP_BOOST1N ...
         }
         if (!have_root) {
-            if (st.size() != 1 || !st[0].is_leaf) return;  // a single leaf
+            if (st.size() != 1 || !(st[0].is_leaf || st[0].op.kind == OP_LEAFMAX)) return;  // a single leaf
             S.ngroups = 1;
             S.root_kind = OP_LEAF;
             S.root_nslots = 1;
-            S.g_kind[0] = OP_LEAF;
-            S.g_mask[0] = 1;
+            S.g_kind[0] = st[0].is_leaf ? OP_LEAF : OP_LEAFMAX;
+            S.g_mask[0] = 0;
+            if (st[0].is_leaf) S.g_mask[0] = 1;
+            else
+                for (uint32_t leaf : st[0].kids) S.g_mask[0] |= uint8_t(1u << leaf);
         }
         const uint32_t n = uint32_t(leaves.size());
         for (uint32_t k = 0; k < n; ++k) S.leaf_list[k] = leaves[k];

@@ -44,7 +44,7 @@ struct DList {  // 48 B
     const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + 2048 * k
 };
 
-enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2, OP_BOOST1N = 3 };  // OP_BOOST1N: unary, 1:n field boost of the leaf below (list_begin = anchors + f32 values, child_slot[0] = index into cols)
+enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2, OP_BOOST1N = 3, OP_LEAFMAX = 4 };  // OP_LEAFMAX: only as a DSimple2 group kind — one leaf over several posting lists, its value the largest of the present ones (search_field.rs:455-461);  // OP_BOOST1N: unary, 1:n field boost of the leaf below (list_begin = anchors + f32 values, child_slot[0] = index into cols)
 
 struct DOp {  // 40 B
     uint8_t kind;

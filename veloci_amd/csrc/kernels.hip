@@ -1638,6 +1638,17 @@ __device__ void rich_flush(uint32_t count, uint32_t n, const SimpleLeaf (&lf)[4]
                 }
                 gv[g] = sum * nd * nd;
                 if (pm & gm) gp |= 1u << g;
+            } else if (gk == OP_LEAFMAX) {  // one leaf over several lists: dedup keeps the max (search_field.rs:455-461)
+                float m = 0.0f;
+                bool any = false;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (((gm >> k) & 1u) && ((pm >> k) & 1u)) {
+                        m = (!any || val[k] > m) ? val[k] : m;
+                        any = true;
+                    }
+                gv[g] = m;
+                if (any) gp |= 1u << g;
             } else {  // a leaf
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k)
