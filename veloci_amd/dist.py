@@ -225,8 +225,12 @@ class ShardedSearcher:
         from .search import PartialBatch, RequestBatch
         batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
         if chunks is None:
+            # chunks per step, from the GLOBAL doc count and the world size (identical on every rank).  Pipelining pays while a chunk's scan is long
+            # next to the fixed cost of a chunk (compile hand-over, launch gaps; 256-query launches also run at a lower rate than 1024-query ones
+            # on small shards).  Measured through the collective path (tools/shard_sweep.sh, ms per 1024-query step with 1 / 2 / 4 chunks):
+            # 12.5 M docs per shard 1.91 / 2.09 / 2.4, 25 M 3.09 / 3.15 / 3.55, 50 M 5.30 / 5.19 / 5.45, 100 M: 4 chunks.
             per_shard = self.index.num_anchors // max(self.world, 1)
-            chunks = 1 if (batch.n < 512 or (self.collective and per_shard < 20_000_000)) else 4
+            chunks = 1 if (batch.n < 512 or (self.collective and per_shard < 40_000_000)) else 2 if (self.collective and per_shard < 80_000_000) else 4
             if os.environ.get("VQ_SHARD_CHUNKS"):
                 chunks = int(os.environ["VQ_SHARD_CHUNKS"])
         subs = batch.split(chunks)
