@@ -1376,3 +1376,35 @@ def test_explain_records_match_the_reference_and_the_oracle():
         with pytest.raises(veloci_amd.VelociError) as e:
             veloci_amd.search(req, idx)
         assert e.value.kind == "Unsupported" and "explain" in str(e.value), req
+
+
+def test_repeated_leaves_inside_one_or_are_fused_like_the_reference_merges_them():
+    """The same leaf twice under one OR (and the same term over several fields): the product fuses them into one leaf, the reference runs them as
+    separate operands of one term slot — same hits, scores, explain records, why_found terms, facets."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    data, docs, info = refcases.build("test_all")
+    idx = veloci_amd.Index(data, device=0)
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    leaf = lambda **kw: {"search": kw}
+    eng, ger = "meanings.eng[]", "meanings.ger[]"
+    reqs = []
+    for extra in ({}, {"explain": True}, {"why_found": True}, {"text_locality": True}, {"facets": [{"field": "tags[]"}]}):
+        reqs += [
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["will"], path=eng), leaf(terms=["urge"], path=eng)]}}}, **extra),
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["will"], path=eng)]}}}, **extra),
+            dict({"search_req": {"or": {"queries": [leaf(terms=["will"], path=eng, levenshtein_distance=1), leaf(terms=["will"], path=eng, levenshtein_distance=1),
+                                                    leaf(terms=["will"], path=ger, levenshtein_distance=1)]}}}, **extra),
+            dict({"search_req": {"and": {"queries": [{"or": {"queries": [leaf(terms=["will"], path=eng), leaf(terms=["will"], path=ger), leaf(terms=["will"], path=eng)]}},
+                                                     leaf(terms=["will"], path=eng)]}}}, **extra),
+        ]
+    for r in reqs:
+        js = json.dumps(r)
+        got, want = veloci_amd.search(r, idx), ora.search_json(js)
+        assert_same(r, got, want)
+        assert got.explain_json == (want.explain_json if r.get("explain") else "null"), js
+        assert {k: sorted(v) for k, v in got.why_found_terms.items()} == {k: sorted(v) for k, v in want.why_found_terms.items()}, js
+    for r, g in zip(reqs, veloci_amd.search_batch(reqs, idx)):
+        assert_same(r, g, ora.search_json(json.dumps(r)))
