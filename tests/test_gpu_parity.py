@@ -242,6 +242,52 @@ def test_two_shards_merge_equals_unsharded(corpus):
         assert_same(r, got, ora.search_json(json.dumps(r)))
 
 
+def test_two_shards_chunked_step_with_one_exchange_equals_unsharded(corpus):
+    """The N > 1 form of ShardedSearcher._one_collective, with both shards in this process: every shard scans its chunks into its partial arena
+    (vq_search_batch_partial_at), the arenas' used prefixes are concatenated shard-major — what ONE all-gather produces — and every chunk
+    merges out of that buffer with the prefix size as the shard stride (vq_merge_partials_flat_strided)."""
+    import torch
+    import veloci_amd
+    from veloci_amd import synth
+    from veloci_amd.dist import device_view
+    from veloci_amd.search import RequestBatch
+    data, meta, idx, ora = corpus
+    N = data.num_anchors
+    cut = N // 3
+    shards = [veloci_amd.Index(data, device=0, doc_lo=0, doc_hi=cut), veloci_amd.Index(data, device=0, doc_lo=cut, doc_hi=N)]
+    t = [list(x) for x in meta.triples]
+    reqs = []
+    for i in range(300):
+        a = t[i % len(t)]
+        reqs.append([synth.req_and(a), synth.req_or(a, top=25), synth.req_single(a[i % 3], top=3)][i % 3])
+    batch = RequestBatch(reqs)
+    subs = batch.split(3)
+    pbs, prefix = [[], []], 0
+    for s, shard in enumerate(shards):
+        off = 0
+        for c, sb in enumerate(subs):
+            pb = veloci_amd.PartialBatch(shard, sb, slot=c, arena_offset=off)
+            assert pb.hist_nbytes == 0
+            pbs[s].append(pb)
+            off += (pb.total_nbytes + 255) // 256 * 256
+        assert s == 0 or off == prefix
+        prefix = off
+    torch.cuda.synchronize()
+    gathered = torch.cat([device_view(shard.partial_arena_ptr, prefix).clone() for shard in shards])
+    torch.cuda.synchronize()
+    want = veloci_amd.search_batch_flat(reqs, idx, stride=25)
+    n = len(reqs)
+    out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 25), np.uint32), np.zeros((n, 25), np.float32), np.zeros(n, np.int32))
+    offset = 0
+    for pb, sb in zip(pbs[0], subs):
+        pb.merge_flat(gathered.data_ptr() + pb.arena_offset, 2, 25, out, offset, shard_stride=prefix)
+        offset += sb.n
+    for pb in pbs[1]:
+        pb.merge_flat(None, 1, 25)  # releases the shard's workspaces
+    for a, b in zip(out, want):
+        assert np.array_equal(a, b)
+
+
 def test_generic_kernel_also_matches_for_simple_queries():
     """Pure simple queries normally run on k_scan_simple; force them through the generic k_tile_scan in a
     child process (the switch is read once per process) and re-run the parity tests that cover them."""
