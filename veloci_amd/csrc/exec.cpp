@@ -71,6 +71,21 @@ static size_t host_threads() {
     }();
     return n;
 }
+// [begin, end) parts of n items for `threads` workers, shrinking: each part is 1 / (2 x threads) of what is left, at least one item
+static std::vector<std::pair<size_t, size_t>> guided_ranges(size_t n, size_t threads) {
+    std::vector<std::pair<size_t, size_t>> out;
+    if (threads <= 1) {
+        if (n) out.push_back({0, n});
+        return out;
+    }
+    static const size_t fixed = std::getenv("VQ_COMPILE_PART") ? size_t(std::atoi(std::getenv("VQ_COMPILE_PART"))) : 0;  // (experiments: parts of a fixed size)
+    for (size_t b = 0; b < n;) {
+        const size_t len = fixed ? std::min(fixed, n - b) : std::max<size_t>((n - b) / (2 * threads), 1);
+        out.push_back({b, b + len});
+        b += len;
+    }
+    return out;
+}
 static HostPool& host_pool(const Index& idx) {
     std::lock_guard<std::mutex> g(idx.pool_mu);
     if (!idx.pool) idx.pool = std::make_unique<HostPool>(host_threads() - 1);
@@ -860,10 +875,12 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
-        // parts are claimed dynamically, two requests at a time: a worker that wakes late — an idle core takes ~0.1 ms, a third of the whole job —
-        // still finds work, and requests of very different cost (a prefix leaf with a 1:n boost list takes 1000x a plain AND) balance out
-        const size_t parts = host_threads() > 1 ? n / 2 : 1;
-        host_pool(idx).run(parts, [&](size_t p) { compile_range(n * p / parts, n * (p + 1) / parts); });
+        // Parts are claimed dynamically and shrink as the work runs out (guided scheduling: a part is 1/(2 x threads) of what is left, down to
+        // one request): few claims while everybody is busy, single requests at the end — a worker that wakes late (an idle core takes ~0.1 ms,
+        // a third of the whole job) still finds work, and requests of very different cost (a prefix leaf with a 1:n boost list takes 1000x a
+        // plain AND) balance out.
+        const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(n, host_threads());
+        host_pool(idx).run(ranges.size(), [&](size_t p) { compile_range(ranges[p].first, ranges[p].second); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
     // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch
@@ -926,8 +943,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 }
             };
             if (again.size() >= 8 && host_threads() > 1) {
-                const size_t parts = again.size() / 2;
-                host_pool(idx).run(parts, [&](size_t p) { recompile(again.size() * p / parts, again.size() * (p + 1) / parts); });
+                const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(again.size(), host_threads());
+                host_pool(idx).run(ranges.size(), [&](size_t p) { recompile(ranges[p].first, ranges[p].second); });
             } else recompile(0, again.size());
             std::vector<size_t> still;
             for (size_t i : again)
