@@ -1244,8 +1244,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         if (pb->queries[i].status == 0 && !pb->queries[i].simple_flags && !pb->queries[i].facets.empty()) facets_generic = !no_facet_cache;
     if (facets_generic) desc_cap += 2 * 1024 * 4;
     static const uint32_t cand_min = [] {
-        const char* e = std::getenv("VQ_CAND_CAP");  // (a small buffer is pruned — and its threshold raised — sooner: 64 beats 256 by 2-7 %)
-        return uint32_t(e ? std::max(32, std::atoi(e)) : 64);
+        const char* e = std::getenv("VQ_CAND_CAP");  // (a small buffer is pruned — and its threshold raised — sooner: 64 beats 256 by 2-7 %, 32 beats 64 by 1-2 %)
+        return uint32_t(e ? std::max(32, std::atoi(e)) : 32);
     }();
     uint32_t cand_cap = cand_min;  // power of two >= 2 * top_k: candidate keys a workgroup keeps in LDS
     while (cand_cap < 2 * max_top_k) cand_cap <<= 1;
