@@ -38,9 +38,11 @@ def parse(text, no_attributes=False):
         pos += 1
         if pos == len(tokens):
             return cur
-        if tokens[pos] == "AND":
+        # AND / OR are operators only between two operands: first or last they are literals (query_parser/src/lexer.rs:265-275: "OR OR" is
+        # two literals, "OR OR OR" is Literal Or Literal)
+        if tokens[pos] == "AND" and pos + 1 < len(tokens):
             return ("bin", cur, "and", expr(pos + 1))
-        if tokens[pos] == "OR":
+        if tokens[pos] == "OR" and pos + 1 < len(tokens):
             return ("bin", cur, "or", expr(pos + 1))
         return ("bin", cur, "or", expr(pos))  # two literals next to each other: OR (parser.rs:113-115)
 

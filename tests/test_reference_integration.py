@@ -154,6 +154,11 @@ def test_query_generator_restatement_regenerates_the_committed_requests():
     assert qgen.get_default_levenshtein("a" * 2, 1, False) == 0 and qgen.get_default_levenshtein("a" * 3, 1, False) == 1  # query_generator.rs:84-99
     assert qgen.get_default_levenshtein("a" * 3, 1, True) == 0 and qgen.get_default_levenshtein("a" * 6, 2, False) == 2
     assert qgen.regex_escape("a.b*c") == "a\\.b\\*c"
+    # operators only between operands (query_parser/src/lexer.rs:265-275)
+    assert qgen.parse("OR OR", True) == ("bin", ("leaf", "OR"), "or", ("leaf", "OR"))
+    assert qgen.parse("OR OR OR", True) == ("bin", ("leaf", "OR"), "or", ("leaf", "OR"))
+    assert qgen.parse("AND AND AND", True) == ("bin", ("leaf", "AND"), "and", ("leaf", "AND"))
+    assert qgen.parse("ANDand AND", True) == ("bin", ("leaf", "ANDand"), "or", ("leaf", "AND"))
     flat = qgen.simplify({"or": {"queries": [{"or": {"queries": [{"search": 1}, {"search": 2}]}}, {"search": 3}]}})
     assert flat == {"or": {"queries": [{"search": 3}, {"search": 1}, {"search": 2}]}}
 
