@@ -129,6 +129,7 @@ void parse_expression(const std::string& expression, DColBoost& cb) {
 struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:16-44, plan_steps.rs:137-148)
     const RequestSearchPart* part = nullptr;  // the request's own part (it outlives the compilation)
     std::string key;                          // part->key(), built once
+    const PostingStore* store = nullptr;      // "<path>.to_anchor_id_score", looked up once
     std::string path;  // with ".textindex"
     bool get_scores = false, get_ids = false, store_term_id_hits = false;
     bool return_term = false, return_term_lowercase = false, store_term_texts = false;  // execution_plan.rs:16-44
@@ -210,7 +211,7 @@ struct Compiler {
         n.kind = XP_LEAF;
         n.list_begin = uint32_t(xplan->lists.size());
         if (l) {
-            const PostingStore& ps = posting_store(l->path);
+            const PostingStore& ps = posting_store(*l);
             for (auto& [tid, score] : l->hits_scores) {  // resolve_token_to_anchor walks the dictionary hits in this order (search_field.rs:419)
                 ExList x{};
                 if (tid < ps.num_tokens) {
@@ -484,6 +485,10 @@ struct Compiler {
         cq.inline_lists.push_back(std::move(d));
         return add_list(h);
     }
+    const PostingStore& posting_store(const Leaf& l) {  // (memoised in the leaf: the lookup builds a path string)
+        if (!l.store) const_cast<Leaf&>(l).store = &posting_store(l.path);
+        return *l.store;
+    }
     const PostingStore& posting_store(const std::string& textindex_path) {
         auto it = idx.postings.find(textindex_path + TO_ANCHOR_ID_SCORE);
         if (it == idx.postings.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + textindex_path + TO_ANCHOR_ID_SCORE);
@@ -571,7 +576,7 @@ struct Compiler {
     // key of the union job that materialises this leaf, or "" when the leaf's lists are scanned as they are (same rule and key as
     // in compile_leaf_lists)
     std::string leaf_union_key(const Leaf& l) {
-        const PostingStore& ps = posting_store(l.path);
+        const PostingStore& ps = posting_store(l);
         size_t nonempty = 0;
         for (auto& [tid, score] : l.hits_scores)
             if (tid < ps.num_tokens && ps.global_len[tid]) ++nonempty;
@@ -604,8 +609,10 @@ struct Compiler {
             float score;
         };
         std::vector<Entry> entries;
+        entries.reserve(4);
+        info.cover.reserve(4);
         for (Leaf* l : members) {
-            const PostingStore& ps = posting_store(l->path);
+            const PostingStore& ps = posting_store(*l);
             for (auto& [tid, score] : l->hits_scores)
                 if (tid < ps.num_tokens) entries.push_back({&ps, tid, score});
         }
@@ -1039,6 +1046,7 @@ struct Compiler {
             }
         }
         std::vector<NodeInfo> ch;
+        ch.reserve(queries.size());
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const SearchRequest& q = queries[qi];
             if (skip[qi]) continue;
@@ -1125,6 +1133,7 @@ struct Compiler {
             }
             // swap_remove(shortest): the last operand takes its slot; the shortest is added last (:393,:415-416)
             std::vector<uint8_t> order;
+            order.reserve(n);
             for (size_t i = 0; i < n; ++i) order.push_back(uint8_t(i));
             order[shortest] = order[n - 1];
             order.pop_back();
@@ -1686,6 +1695,11 @@ struct Compiler {
 
     // ------------------------------------------------------------ the whole request (search.rs:143-228)
     void run() {
+        cq.lists.reserve(8);  // (the vectors of a typical request: one allocation each instead of a growth chain)
+        cq.ops.reserve(8);
+        cq.pres.reserve(8);
+        cq.pres_in.reserve(16);
+        by_address.reserve(8);
         if (req.has_select) unsupported("select");
         if (req.why_found && req.has_select) unsupported("why_found with select (why_found_info: highlighting of the returned documents)");
         if (req.has_suggest) unsupported("suggest");
