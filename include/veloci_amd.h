@@ -153,6 +153,9 @@ const char* vq_request_to_json(const vq_request*);
 /* str::to_lowercase as the dictionary side applies it (src/search/search_field.rs:284,312).  Returns the byte length written to `out`, or
  * (size_t)-1 when `cap` is too small.  Diagnostic: swept over every code point by tests/test_request_parse.py. */
 size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap);
+/* util::normalize_text (src/util.rs:11-29) as vq_highlight_json applies it to a part's terms; same conventions.  Diagnostic: compared with an
+ * independent regex engine by tests/test_request_parse.py. */
+size_t vq_debug_normalize_text(const char* utf8, size_t len, char* out, size_t cap);
 /* Compile a request against an index without launching anything (host-only): 0 = ready to scan, negative = a pre-pass would run first (-1 union /
  * locality jobs, -2 count pre-pass, -3 range jobs), otherwise the error code the search would return.  Diagnostic: the CPU sanitizer build (`make asan`) runs it over the
  * request fixtures; tools/compile_bench.py times it. */
@@ -203,6 +206,16 @@ const char* vq_suggest_text(const vq_suggest_result*, size_t i);
 float vq_suggest_score(const vq_suggest_result*, size_t i);
 uint32_t vq_suggest_term_id(const vq_suggest_result*, size_t i);
 void vq_suggest_free(vq_suggest_result*);
+
+/* ---------------------------------------------------------------- highlight
+ * == search_field::highlight(persistence, &mut part) (src/search/search_field.rs:233-245): `json` is a bare RequestSearchPart with
+ * "snippet": true (+ optional "snippet_info", src/search/request/snippet_info.rs).  The terms are normalised (util::normalize_text), matched
+ * against the field's dictionary (prefix / fuzzy scans run on the device), resolved to the texts that contain a matched token
+ * (resolve_token_hits_to_text_id, :550-639) and every such text is returned as a snippet (highlight_document, src/highlight_field.rs:187-272)
+ * with the best score among its matched tokens, ranked by score, cut by the part's top / skip.  Entry i: vq_suggest_text = the snippet,
+ * vq_suggest_score, vq_suggest_term_id = the text id.  Where the reference panics (a hit without a snippet: an untokenised field, "snippet" not
+ * set) the call returns VQ_ERR_INVALID_REQUEST.  Needs the field's tokens_to_text_id and text_id_to_token_ids stores. */
+int vq_highlight_json(const vq_index*, const char* json, size_t len, vq_suggest_result** out);
 
 /* ----------------------------------------------------------------- search */
 

@@ -57,6 +57,7 @@ def lib():
         L.vo_result_explain_json.restype = C.c_char_p
         L.vo_result_explain_json.argtypes = [C.c_void_p]
         L.vo_suggest_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.vo_highlight_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.vo_suggest_len.restype = C.c_size_t
         L.vo_suggest_len.argtypes = [C.c_void_p]
         L.vo_suggest_text.restype = C.c_char_p
@@ -159,6 +160,20 @@ class OracleIndex:
             js = js.encode()
         out = C.c_void_p()
         rc = self.L.vo_suggest_json(self.h, js, len(js), C.byref(out))
+        if rc != 0:
+            raise OracleError(rc, self.L.vo_last_error().decode())
+        try:
+            return [(self.L.vo_suggest_text(out, i).decode(), float(self.L.vo_suggest_score(out, i)), int(self.L.vo_suggest_term_id(out, i)))
+                    for i in range(self.L.vo_suggest_len(out))]
+        finally:
+            self.L.vo_suggest_free(out)
+
+    def highlight_json(self, js):
+        """search_field::highlight (search_field.rs:233-245) of a bare RequestSearchPart: -> [(snippet, score, text_id)]"""
+        if not isinstance(js, (bytes, bytearray)):
+            js = js.encode()
+        out = C.c_void_p()
+        rc = self.L.vo_highlight_json(self.h, js, len(js), C.byref(out))
         if rc != 0:
             raise OracleError(rc, self.L.vo_last_error().decode())
         try:

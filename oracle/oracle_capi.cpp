@@ -163,6 +163,26 @@ int vo_suggest_json(const void* index, const char* json, size_t len, void** out)
         return fail(VelociError(ERR_JSON, std::string("JsonError: ") + e.what()));
     }
 }
+// highlight (search_field.rs:233-245): `json` is a bare RequestSearchPart; the result is read with the vo_suggest_* accessors (text = snippet)
+int vo_highlight_json(const void* index, const char* json, size_t len, void** out) {
+    try {
+        *out = nullptr;
+        RequestSearchPart part = search_part_from_json(vqjson::parse(json, len));
+        auto* box = new SuggestBox();
+        try {
+            box->e = highlight(*static_cast<const Index*>(index), std::move(part));
+        } catch (...) {
+            delete box;
+            throw;
+        }
+        *out = box;
+        return 0;
+    } catch (const VelociError& e) {
+        return fail(e);
+    } catch (const vqjson::ParseError& e) {
+        return fail(VelociError(ERR_JSON, std::string("JsonError: ") + e.what()));
+    }
+}
 size_t vo_suggest_len(const void* s) { return static_cast<const SuggestBox*>(s)->e.size(); }
 const char* vo_suggest_text(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].text.c_str(); }
 float vo_suggest_score(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].score; }

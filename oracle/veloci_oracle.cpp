@@ -1396,4 +1396,133 @@ std::vector<SuggestEntry> suggest_multi(const Index& index, Request req) {
     return merged;
 }
 
+// ------------------------------------------------------------------ highlight
+namespace {
+const SnippetInfo kDefaultSnippetInfo;  // search/request/snippet_info.rs:31-39
+
+// highlight_field.rs:19-37
+std::vector<std::vector<int64_t>> group_hit_positions_for_snippet(const std::vector<size_t>& hit_pos_of_tokens_in_doc, const SnippetInfo& opt) {
+    const int64_t token_around_snippets = opt.num_words_around_snippet * 2;  // token separator token separator
+    std::vector<std::vector<int64_t>> grouped;
+    int64_t previous_token_pos = -token_around_snippets;
+    for (size_t token_pos : hit_pos_of_tokens_in_doc) {
+        if (int64_t(token_pos) - previous_token_pos >= token_around_snippets) grouped.emplace_back();
+        previous_token_pos = int64_t(token_pos);
+        grouped.back().push_back(int64_t(token_pos));
+    }
+    return grouped;
+}
+// highlight_field.rs:39-43
+std::pair<size_t, size_t> grouped_to_positions_for_snippet(const std::vector<int64_t>& vec, size_t token_len, int64_t token_around_snippets) {
+    const size_t start_index = size_t(std::max<int64_t>(vec.front() - token_around_snippets, 0));
+    const size_t end_index = std::min(size_t(vec.back() + token_around_snippets + 1), token_len);
+    return {start_index, end_index};
+}
+
+// highlight_field.rs:187-272: the snippet of text `value_id` around the tokens `token_ids`
+std::optional<std::string> highlight_document(const Index& index, const std::string& path, uint64_t value_id, const std::vector<uint32_t>& token_ids, const SnippetInfo& opt) {
+    const KeyValueStore& text_id_to_token_ids = index.get_valueid_to_parent(path + ".text_id_to_token_ids");
+    const uint32_t *b, *e;
+    if (!text_id_to_token_ids.get_values(value_id, &b, &e)) {  // :196-207
+        if (std::find(token_ids.begin(), token_ids.end(), uint32_t(value_id)) != token_ids.end())
+            return opt.snippet_start_tag + get_text_for_id(index, path, uint32_t(value_id)) + opt.snippet_end_tag;  // the whole text
+        return std::nullopt;
+    }
+    const std::vector<uint32_t> documents_token_ids(b, e);
+    const std::set<uint32_t> wanted(token_ids.begin(), token_ids.end());
+    std::vector<size_t> hit_pos_of_tokens_in_doc;
+    for (uint32_t token_id : wanted)  // :219-231
+        for (size_t pos = 0; pos < documents_token_ids.size(); ++pos)
+            if (documents_token_ids[pos] == token_id) hit_pos_of_tokens_in_doc.push_back(pos);
+    if (hit_pos_of_tokens_in_doc.empty()) return std::nullopt;
+    std::sort(hit_pos_of_tokens_in_doc.begin(), hit_pos_of_tokens_in_doc.end());
+
+    const int64_t token_around_snippets = opt.num_words_around_snippet * 2;
+    const auto grouped = group_hit_positions_for_snippet(hit_pos_of_tokens_in_doc, opt);
+    // build_snippet (:45-71): the windows' texts, hits wrapped in the tags, at most max_snippets of them joined by the connector
+    std::string snippet;
+    size_t taken = 0;
+    for (auto& g : grouped) {
+        if (taken == opt.max_snippets) break;
+        if (taken++) snippet += opt.snippet_connector;
+        const auto window = grouped_to_positions_for_snippet(g, documents_token_ids.size(), token_around_snippets);
+        for (size_t i = window.first; i < window.second; ++i) {
+            const std::string text = get_text_for_id(index, path, documents_token_ids[i]);
+            if (wanted.count(documents_token_ids[i])) snippet += opt.snippet_start_tag + text + opt.snippet_end_tag;
+            else snippet += text;
+        }
+    }
+    // ellipsis_snippet (:73-90)
+    const int64_t first_index = int64_t(hit_pos_of_tokens_in_doc.front()), last_index = int64_t(hit_pos_of_tokens_in_doc.back());
+    if (first_index > token_around_snippets) snippet.insert(0, opt.snippet_connector);
+    if (last_index < int64_t(documents_token_ids.size()) - token_around_snippets) snippet += opt.snippet_connector;
+    return snippet;
+}
+}  // namespace
+
+// search_field::highlight (search_field.rs:233-245) = get_term_ids_in_field + resolve_token_hits_to_text_id (:550-639) with snippets +
+// get_text_score_id_from_result(false, ..) (:160-192)
+std::vector<SuggestEntry> highlight(const Index& index, RequestSearchPart part) {
+    for (auto& t : part.terms) t = vqtext::normalize_text(t);  // :234
+    const SnippetInfo& opt = part.has_snippet_info ? part.snippet_info : kDefaultSnippetInfo;
+    if (opt.num_words_around_snippet < 0 || opt.num_words_around_snippet > 0x3FFFFFFF)  // the reference's window arithmetic overflows / panics there
+        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"snippet_info.num_words_around_snippet out of range\" ");
+    PlanRequestSearchPart options;
+    options.request = part;
+    options.get_scores = true;
+    SearchFieldResult result = get_term_ids_in_field(index, options);
+    std::map<uint32_t, std::string> highlight_of;  // SearchFieldResult::highlight
+
+    // resolve_token_hits_to_text_id
+    std::string path = options.request.path;
+    if (!ends_with(path, TEXTINDEX)) path += TEXTINDEX;
+    auto cit = index.columns.find(extract_field_name(path));
+    const bool is_tokenized = cit != index.columns.end() && cit->second.tokenize;
+    if (is_tokenized) {
+        const bool add_snippets = options.request.snippet.value_or(false);
+        const KeyValueStore& token_kvdata = index.get_valueid_to_parent(path + TOKENS_TO_TEXT_ID);
+        struct TokenHit {
+            uint32_t parent;
+            float score;
+            uint32_t token;
+        };
+        std::vector<TokenHit> token_hits;
+        for (const Hit& hit : result.hits_scores) {
+            const uint32_t *b, *e;
+            if (token_kvdata.get_values(hit.id, &b, &e))
+                for (const uint32_t* v = b; v != e; ++v) token_hits.push_back({*v, hit.score, hit.id});
+        }
+        std::stable_sort(token_hits.begin(), token_hits.end(), [](const TokenHit& a, const TokenHit& b) { return a.parent < b.parent; });  // :602 (unstable there)
+        if (!token_hits.empty()) {
+            if (add_snippets) result.hits_scores.clear();  // :608-610 only text hits for highlighting
+            for (size_t i = 0; i < token_hits.size();) {
+                size_t j = i;
+                float max_score = token_hits[i].score;
+                std::vector<uint32_t> tokens;
+                for (; j < token_hits.size() && token_hits[j].parent == token_hits[i].parent; ++j) {
+                    if (std::fabs(token_hits[j].score) >= std::fabs(max_score)) max_score = token_hits[j].score;  // max_by_key keeps the last maximum
+                    tokens.push_back(token_hits[j].token);
+                }
+                result.hits_scores.push_back(Hit{token_hits[i].parent, max_score});
+                if (add_snippets) {
+                    auto doc = highlight_document(index, path, token_hits[i].parent, tokens, opt);
+                    if (doc) highlight_of[token_hits[i].parent] = *doc;
+                }
+                i = j;
+            }
+        }
+    }
+    // get_text_score_id_from_result(false, ..): `&res.highlight[&id]` panics for a hit without a snippet
+    std::vector<SuggestEntry> out;
+    for (const Hit& h : result.hits_scores) {
+        auto it = highlight_of.find(h.id);
+        if (it == highlight_of.end())
+            throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"highlight: hit " + std::to_string(h.id) + " has no snippet (the reference panics)\" ");
+        out.push_back(SuggestEntry{it->second, h.score, h.id});
+    }
+    std::stable_sort(out.begin(), out.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.score > b.score; });  // :189 (unstable there)
+    apply_top_skip(out, options.request.skip, options.request.top);
+    return out;
+}
+
 }  // namespace vo

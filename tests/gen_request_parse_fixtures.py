@@ -23,7 +23,18 @@ EDGE = [
     '{"suggest":[{"terms":["wi"],"path":"p","starts_with":true,"top":10,"skip":0}],"top":5}',
     '  {\n"search_req" : { "search" : { "terms" : [ "a" ] , "path" : "f" , "boost" : 2.5E+0 } } , "top" : 10 }  ',
     '{}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"num_words_around_snippet":-2,"snippet_start_tag":"<em>","snippet_end_tag":"</em>","snippet_connector":" .. ","max_snippets":4294967295,"other":1}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":null}}}',
     # --- errors
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"num_words_around_snippet":null}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"num_words_around_snippet":2.0}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"max_snippets":4294967296}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"max_snippets":-1}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"snippet_start_tag":1}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":{"snippet_connector":null}}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":[]}}}',
+    '{"search_req":{"search":{"terms":["a"],"path":"f","snippet_info":"x"}}}',
     '{"search_req":{"search":{"terms":["a"]}}}',
     '{"search_req":{"search":{"path":"f"}}}',
     '{"search_req":{"search":{"terms":"a","path":"f"}}}',

@@ -65,6 +65,32 @@ for name, reqs in by_corpus.items():
         stats["device_errors"] += e.kind == "Device"
     del idx
 
+# highlight (search_field.rs:233-245) with exact terms is host work from end to end: snippets under the sanitizers, compared with the oracle's
+import test_reference_integration as T  # noqa: E402
+from oracle import binding as O  # noqa: E402
+data, docs, info = refcases.build("test_all")
+idx = veloci_amd.Index(data, device=0)
+ora = O.OracleIndex(data.num_anchors)
+data.load_into(ora)
+stats["highlighted"] = stats["highlight_errors"] = 0
+for part in T.highlight_parts():
+    if part.get("starts_with") or part.get("levenshtein_distance"):
+        continue
+    js = json.dumps(part)
+    try:
+        want = ora.highlight_json(js)
+    except O.OracleError as e:
+        try:
+            veloci_amd.highlight(part, idx)
+            raise AssertionError("no error for " + js)
+        except veloci_amd.VelociError as g:
+            assert str(g) == str(e), (js, str(g), str(e))
+        stats["highlight_errors"] += 1
+        continue
+    assert veloci_amd.highlight(part, idx) == want, js
+    stats["highlighted"] += 1
+del idx
+
 with open(os.path.join(TESTS, "golden", "reference_query_generator.json"), encoding="utf-8") as f:
     qg = json.load(f)
 for name, c in qg["corpora"].items():

@@ -111,13 +111,29 @@ def options(v):
             "boost": _opt(d, "boost", lambda s: _seq(s, boost_part))}
 
 
+def snippet_info(v):
+    """src/search/request/snippet_info.rs:1-13: every field has a serde default, so a missing key is fine and a null is not.  The canonical dump only
+    records that the object was there."""
+    d = _obj(v)
+    if "num_words_around_snippet" in d:
+        n = d["num_words_around_snippet"]
+        if isinstance(n, bool) or not isinstance(n, _Int) or not -(1 << 63) <= n < (1 << 63):
+            raise ParseError("expected an i64")
+    for key in ("snippet_start_tag", "snippet_end_tag", "snippet_connector"):
+        if key in d:
+            _str(d[key])
+    if "max_snippets" in d:
+        _uint(d["max_snippets"], 32)
+    return True
+
+
 def search_part(v):
     d = _obj(v)
     return {"path": _req(d, "path", _str), "terms": _req(d, "terms", lambda s: _seq(s, _str)),
             "levenshtein_distance": _opt(d, "levenshtein_distance", lambda x: _uint(x, 32)),
             "starts_with": _default_false(d, "starts_with"), "is_regex": _default_false(d, "is_regex"),
             "token_value": _opt(d, "token_value", boost_part), "boost": _opt(d, "boost", _f32), "ignore_case": _opt(d, "ignore_case", _bool),
-            "snippet": _opt(d, "snippet", _bool), "snippet_info": d.get("snippet_info") is not None,
+            "snippet": _opt(d, "snippet", _bool), "snippet_info": bool(_opt(d, "snippet_info", snippet_info)),
             "top": _opt(d, "top", _uint), "skip": _opt(d, "skip", _uint), "options": _opt(d, "options", options)}
 
 

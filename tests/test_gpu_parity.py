@@ -741,6 +741,37 @@ def test_text_locality_on_multi_valued_text_fields_device_prepass():
         assert_same(r, g, w)
 
 
+def test_highlight_matches_the_reference_and_the_oracle():
+    """SURVEY.md §8f-5: search_field::highlight (search_field.rs:233-245, highlight_field.rs:187-272) through the C ABI — the reference's own three
+    assertions (tests/all/tests.rs:1009-1085), then product == oracle (snippets, score bits, text ids, error texts) on the wider request set,
+    whose prefix / fuzzy parts take their match sets from k_dict_scan."""
+    import veloci_amd
+    from oracle import binding as O
+    import test_reference_integration as T
+    fx = T._load_suggest_regex()
+    data, docs, info = T.build_fixture_corpus(fx, "test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    idx = veloci_amd.Index(data, device=0)
+    for case in fx["highlight"]:
+        assert [t for t, _, _ in veloci_amd.highlight(case["request"], idx)] == case["expect_texts"], case["name"]
+    answered = errors = 0
+    for part in T.highlight_parts():
+        js = json.dumps(part)
+        try:
+            want = ora.highlight_json(js)
+        except O.OracleError as e:
+            with pytest.raises(veloci_amd.VelociError) as g:
+                veloci_amd.highlight(part, idx)
+            assert str(g.value) == str(e), js
+            errors += 1
+            continue
+        got = veloci_amd.highlight(part, idx)
+        assert [(t, np.float32(s).view(np.uint32), i) for t, s, i in got] == [(t, np.float32(s).view(np.uint32), i) for t, s, i in want], js
+        answered += 1
+    assert answered > 150 and errors > 10, (answered, errors)
+
+
 def test_suggest_regex_and_why_found_terms_match_the_reference_and_the_oracle():
     """SURVEY.md §8f-5 / f-4 (dictionary side): suggest (search_field.rs:194-231), regex leaves (:72-83) and `why_found_terms` (search.rs:186)
     through the C ABI — the reference's own assertions (tests/golden/reference_suggest_regex.json), then product == oracle on a wider set."""

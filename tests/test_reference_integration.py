@@ -92,6 +92,11 @@ def test_oracle_reproduces_reference_suggest_and_regex_assertions():
         ora = O.OracleIndex(data.num_anchors)
         data.load_into(ora)
         check_suggest_case(case, ora.suggest_json(json.dumps(case["request"])))
+    for case in fx["highlight"]:  # search_field::highlight, tests/all/tests.rs:1009-1085
+        data, docs, info = build_fixture_corpus(fx, case["corpus"])
+        ora = O.OracleIndex(data.num_anchors)
+        data.load_into(ora)
+        assert [t for t, _, _ in ora.highlight_json(json.dumps(case["request"]))] == case["expect_texts"], case["name"]
     for case in fx["term_lookup"]:
         data, docs, info = build_fixture_corpus(fx, case["corpus"])
         ora = O.OracleIndex(data.num_anchors)
@@ -217,6 +222,72 @@ def explain_requests():
             dict({"search_req": leaf(terms=[".*e.*"], path=ger, is_regex=True), "explain": True, "why_found": True}, **top),
         ]
     return reqs
+
+
+def highlight_parts():
+    """RequestSearchParts for search_field::highlight on the `test_all` corpus: every branch of resolve_token_hits_to_text_id (:550-639) and
+    highlight_document (highlight_field.rs:187-272) — several windows, windows that touch, ellipses on either side, hits at the text's edges,
+    snippet options, terms that util::normalize_text rewrites, and the requests on which the reference panics.  Shared by the oracle's own
+    checks, the sanitizer driver (the exact-term ones) and the GPU parity test."""
+    long_paths = ("mylongtext", "tags[]", "sub_level[].text")
+    parts = []
+    for path in long_paths:
+        for term in ("story", "Story,", "(the)", "a", "the", "prolog", "end", "world", "guy", "rule", "nope"):
+            for kw in ({}, {"starts_with": True}, {"levenshtein_distance": 1}):
+                parts.append(dict({"terms": [term], "path": path, "snippet": True}, **kw))
+        for si in ({"num_words_around_snippet": 0}, {"num_words_around_snippet": 1}, {"num_words_around_snippet": 2, "snippet_connector": " [..] "},
+                   {"num_words_around_snippet": 3, "max_snippets": 1}, {"max_snippets": 0}, {"snippet_start_tag": "<em>", "snippet_end_tag": "</em>"},
+                   {"num_words_around_snippet": 40}, {"num_words_around_snippet": -1}):
+            for term, kw in (("the", {}), ("a", {}), ("t", {"starts_with": True}), ("wen", {"levenshtein_distance": 1})):
+                parts.append(dict({"terms": [term], "path": path, "snippet": True, "snippet_info": si}, **kw))
+    for path in ("meanings.ger[]", "meanings.eng[]"):
+        for term, kw in (("majestät", {}), ("Majestät (f)", {}), ("anblick", {"levenshtein_distance": 1}), ("will", {"starts_with": True}), ("will", {"starts_with": True, "top": 2, "skip": 1}),
+                         ("test", {"boost": -2.0}), ("der", {"top": 1}), ("ist", {"ignore_case": False}), ("treffer", {"levenshtein_distance": 2, "top": 3})):
+            parts.append(dict({"terms": [term], "path": path, "snippet": True}, **kw))
+    parts += [
+        {"terms": ["story"], "path": "mylongtext"},                                  # no "snippet": the token hits keep no snippet -> the reference panics
+        {"terms": ["story"], "path": "mylongtext", "snippet": False},
+        {"terms": ["nope"], "path": "mylongtext"},                                   # nothing matched: an empty result
+        {"terms": ["Prolog:\nthis is a story of a guy who went out to rule the world, but then died. the end"], "path": "mylongtext", "snippet": True},
+        {"terms": ["nice"], "path": "tags[]", "snippet": True},                      # an untokenised-looking text: a text that is its own only token has no token rows
+        {"terms": ["1587690"], "path": "ent_seq", "snippet": True},
+        {"terms": ["story"], "path": "nosuchfield", "snippet": True},
+        {"terms": [], "path": "mylongtext", "snippet": True},
+        {"terms": ["(f)"], "path": "meanings.ger[]", "snippet": True},               # normalises to the empty term
+    ]
+    return parts
+
+
+def test_oracle_highlight_invariants():
+    """The oracle's highlight on the wider request set: every returned snippet, with its tags and connectors removed, is made of pieces of the
+    stored text; every tagged token is one of the matched terms; scores come out ranked."""
+    from oracle import binding as O
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    answered = errors = 0
+    for part in highlight_parts():
+        try:
+            got = ora.highlight_json(json.dumps(part))
+        except O.OracleError:
+            errors += 1
+            continue
+        answered += 1
+        scores = [s for _, s, _ in got]
+        assert scores == sorted(scores, reverse=True), part
+        si = part.get("snippet_info", {})
+        st, en, conn = si.get("snippet_start_tag", "<b>"), si.get("snippet_end_tag", "</b>"), si.get("snippet_connector", " ... ")
+        key = part["path"] + ".textindex"
+        kb, off, vals = data.key_value_stores[key + ".text_id_to_token_ids"]
+        terms = info[part["path"]]["terms"]
+        for snippet, _, text_id in got:
+            row = vals[int(off[text_id - kb]):int(off[text_id - kb + 1])]
+            full = "".join(terms[t] for t in row)
+            for piece in snippet.split(conn):  # (windows of hits 10-20 tokens apart overlap in the reference: a piece may start before the last one ended)
+                assert piece.replace(st, "").replace(en, "") in full, (part, snippet)
+            if si.get("max_snippets", 1) != 0:
+                assert st in snippet and en in snippet, (part, snippet)
+    assert answered > 150 and errors > 10, (answered, errors)
 
 
 def test_oracle_reproduces_reference_explain_assertions_and_its_own_invariants():

@@ -78,3 +78,39 @@ def test_lowercasing_agrees_with_an_independent_implementation_on_every_code_poi
     assert all(unicodedata.category(chr(cp)) in ("Cn", "Lu", "Lt", "Ll", "Lo") for cp in differ) and len(differ) <= 64, [hex(c) for c in differ[:80]]
     assert low("AbÇ ΔΣ İ") in ("abç δσ i̇", "abç δς i̇")  # final sigma: Rust lowercases a word-final Σ to ς; text.hpp always gives σ
     assert low("STRASSE ẞ Ǆ") == "strasse ß ǆ"
+
+
+def test_normalize_text_agrees_with_the_reference_regexes_run_by_an_independent_engine():
+    """util::normalize_text (src/util.rs:11-29) as text.hpp restates it (passes over code points) vs the reference's five regular expressions
+    run by Python's `re` in the same order.  Rust's `\\s` and str::trim use White_Space; Python's `\\s` adds U+001C-001F, so the white-space class
+    is spelled out here."""
+    import random
+    import re
+    from veloci_amd import _lib
+    L = _lib.lib()
+    buf = C.create_string_buffer(4096)
+    ws = "\\t\\n\\x0b\\x0c\\r \\x85\\xa0\\u1680\\u2000-\\u200a\\u2028\\u2029\\u202f\\u205f\\u3000"
+    steps = [(re.compile(r"\([fmn\d]\)"), " "), (re.compile(r"[\(\)]"), " "), (re.compile("[{}'\"“]"), ""), (re.compile("[%s][%s]+" % (ws, ws)), " "),
+             (re.compile("[,.…;・’-]"), "")]
+    strip = re.compile("^[%s]+|[%s]+$" % (ws, ws))
+
+    def want(s):
+        for rx, rep in steps:
+            s = rx.sub(rep, s)
+        return strip.sub("", s.lower())
+
+    def got(s):
+        raw = s.encode("utf-8")
+        n = L.vq_debug_normalize_text(raw, len(raw), buf, 4096)
+        assert n != C.c_size_t(-1).value
+        return buf.raw[:n].decode("utf-8")
+
+    fixed = ["majestätischer Anblick (m)", "Majestät (f)", "(1) eins", "((f))", "(f", "a  b\t\tc \n d", "it's {so} \"quoted\" “x", "e.g., this; that…・’-", " padded ", "",
+             "(٣)", "(５)", "a　　b", " x ", "(f)(m)(n)(9)", "A-B", "Straße (n) ", "(x)", "( f )"]
+    for s in fixed:
+        assert got(s) == want(s), repr(s)
+    rng = random.Random(5)
+    alphabet = list("()fmn019 {}'\"“\t\n ,.…;・’-abcXYZäÖ 　٣")
+    for _ in range(3000):
+        s = "".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 14)))
+        assert got(s) == want(s), repr(s)

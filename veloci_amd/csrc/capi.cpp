@@ -437,6 +437,14 @@ size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap
     std::memcpy(out, low.data(), low.size());
     return low.size();
 }
+// util::normalize_text (src/util.rs:11-29) as vq_highlight_json applies it to the terms: checked against an independent regex engine by
+// tests/test_request_parse.py.  Returns the length, or (size_t)-1 when `cap` is too small.
+size_t vq_debug_normalize_text(const char* utf8, size_t len, char* out, size_t cap) {
+    const std::string norm = vqtext::normalize_text(std::string(utf8 ? utf8 : "", utf8 ? len : 0));
+    if (norm.size() > cap) return size_t(-1);
+    std::memcpy(out, norm.data(), norm.size());
+    return norm.size();
+}
 // Compile `request` against `index` without launching anything: 0 when the query is ready to scan, negative when a pre-pass would run first
 // (-1 union / locality jobs, -2 count pre-pass, -3 range jobs), or the error code the search would return (message in vq_last_error).  Host-only work —
 // what the CPU sanitizer build exercises, and what tools/compile_bench.py times.
@@ -537,6 +545,26 @@ int vq_suggest_json(const vq_index* index, const char* json, size_t len, vq_sugg
         auto* r = new vq_suggest_result();
         try {
             r->e = run_suggest(*index->idx, req);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+    });
+}
+int vq_highlight_json(const vq_index* index, const char* json, size_t len, vq_suggest_result** out) {
+    return guard([&]() {
+        if (!index || !json || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_highlight_json: null argument");
+        *out = nullptr;
+        vqreq::RequestSearchPart part;
+        try {
+            part = vqreq::search_part_from_json(vqjson::parse(json, len));
+        } catch (const vqjson::ParseError& e) {
+            throw VelociError(VQ_ERR_JSON, std::string("JsonError: ") + e.what());
+        }
+        auto* r = new vq_suggest_result();
+        try {
+            r->e = run_highlight(*index->idx, std::move(part));
         } catch (...) {
             delete r;
             throw;

@@ -2190,6 +2190,140 @@ std::vector<SuggestEntry> suggest_part(const Index& idx, const RequestSearchPart
 }
 
 
+// highlight (search_field.rs:233-245): the texts that contain a matched token, each with its snippet (highlight_field.rs:187-272) and the
+// best score among its matched tokens (resolve_token_hits_to_text_id with snippets, search_field.rs:550-639).  `part.terms` are already
+// normalised; the dictionary scan of a fuzzy / prefix part has run on the device (`fuzzy`).  Host work over the host copies of
+// tokens_to_text_id / text_id_to_token_ids: one text at a time, a few dozen tokens each.
+namespace {
+std::string snippet_of_text(const Dictionary& dict, const uint32_t* toks, size_t n, const std::vector<uint32_t>& wanted_sorted, const vqreq::SnippetInfo& opt, bool* any) {
+    const int64_t around = opt.num_words_around_snippet * 2;  // token separator token separator
+    auto is_hit = [&](size_t i) { return std::binary_search(wanted_sorted.begin(), wanted_sorted.end(), toks[i]); };
+    auto text_of = [&](size_t i) -> const std::string& {
+        static const std::string empty;
+        return toks[i] < dict.terms.size() ? dict.terms[toks[i]] : empty;
+    };
+    // one walk: hits closer than `around` tokens share a window (group_hit_positions_for_snippet :19-37); a window reaches `around` tokens
+    // to both sides of its hits (grouped_to_positions_for_snippet :39-43)
+    std::string out;
+    int64_t first_hit = -1, last_hit = -1, group_first = -1, group_last = -1;
+    uint64_t windows = 0;
+    auto close_group = [&]() {
+        if (group_first < 0) return;
+        if (windows < opt.max_snippets) {
+            if (windows) out += opt.snippet_connector;
+            const size_t lo = size_t(std::max<int64_t>(group_first - around, 0)), hi = size_t(std::min<int64_t>(group_last + around + 1, int64_t(n)));
+            for (size_t i = lo; i < hi; ++i) {
+                if (is_hit(i)) {
+                    out += opt.snippet_start_tag;
+                    out += text_of(i);
+                    out += opt.snippet_end_tag;
+                } else out += text_of(i);
+            }
+        }
+        ++windows;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        if (!is_hit(i)) continue;
+        if (first_hit < 0) first_hit = int64_t(i);
+        if (group_first < 0 || int64_t(i) - group_last >= around) {
+            close_group();
+            group_first = int64_t(i);
+        }
+        group_last = last_hit = int64_t(i);
+    }
+    close_group();
+    *any = first_hit >= 0;
+    if (!*any) return out;
+    if (first_hit > around) out.insert(0, opt.snippet_connector);             // ellipsis_snippet :73-90
+    if (last_hit < int64_t(n) - around) out += opt.snippet_connector;
+    return out;
+}
+}  // namespace
+
+std::vector<SuggestEntry> highlight_part(const Index& idx, const RequestSearchPart& part, const FuzzyTable* fuzzy) {
+    static const vqreq::SnippetInfo kDefault;
+    const vqreq::SnippetInfo& opt = part.has_snippet_info ? part.snippet_info : kDefault;
+    if (opt.num_words_around_snippet < 0 || opt.num_words_around_snippet > 0x3FFFFFFF)  // the reference's window arithmetic overflows / panics there
+        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"snippet_info.num_words_around_snippet out of range\" ");
+    RequestSearchPart lookup = part;  // get_term_ids_in_field does not look at the snippet fields
+    lookup.snippet.reset();
+    lookup.has_snippet_info = false;
+    Request dummy;
+    Compiler c(idx, dummy, fuzzy);
+    Leaf l;
+    l.part = &lookup;
+    l.get_scores = true;
+    c.lookup_terms(idx, l, true, false);
+    if (lookup.token_value) c.apply_token_value(*lookup.token_value, l);
+
+    struct TextHit {
+        uint32_t text;
+        float score;
+        uint32_t token, order;
+    };
+    std::vector<TextHit> hits;
+    std::vector<std::pair<uint32_t, float>> ranked;  // (text id, best score): SearchFieldResult::hits_scores after the resolve step
+    const std::string& path = l.path;
+    auto cit = idx.columns.find(path.substr(0, path.size() - std::strlen(TEXTINDEX)));
+    const bool tokenized = cit != idx.columns.end() && cit->second.tokenize;
+    const bool add_snippets = part.snippet.value_or(false);
+    std::map<uint32_t, std::string> snippets;
+    for (auto& h : l.hits_scores) ranked.push_back(h);
+    if (tokenized) {
+        auto kit = idx.kv.find(path + TOKENS_TO_TEXT_ID);
+        if (kit == idx.kv.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + path + TOKENS_TO_TEXT_ID);
+        uint32_t order = 0;
+        for (auto& h : l.hits_scores) {
+            const uint32_t *b, *e;
+            if (!kit->second.host_row(h.first, &b, &e)) continue;
+            for (const uint32_t* v = b; v != e; ++v) hits.push_back({*v, h.second, h.first, order++});
+        }
+        std::sort(hits.begin(), hits.end(), [](const TextHit& a, const TextHit& b) { return a.text != b.text ? a.text < b.text : a.order < b.order; });
+        if (!hits.empty()) {
+            if (add_snippets) ranked.clear();  // :608-610
+            const KVStore* t2t = nullptr;
+            const Dictionary& dict = idx.dict.at(path);
+            std::vector<uint32_t> wanted;
+            for (size_t i = 0; i < hits.size();) {
+                size_t j = i;
+                float best = hits[i].score;
+                wanted.clear();
+                for (; j < hits.size() && hits[j].text == hits[i].text; ++j) {
+                    if (std::fabs(hits[j].score) >= std::fabs(best)) best = hits[j].score;  // Iterator::max_by_key keeps the last maximum
+                    wanted.push_back(hits[j].token);
+                }
+                const uint32_t text = hits[i].text;
+                ranked.push_back({text, best});
+                if (add_snippets) {
+                    if (!t2t) {
+                        auto tit = idx.kv.find(path + ".text_id_to_token_ids");
+                        if (tit == idx.kv.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + path + ".text_id_to_token_ids");
+                        t2t = &tit->second;
+                    }
+                    std::sort(wanted.begin(), wanted.end());
+                    const uint32_t *b, *e;
+                    if (t2t->host_row(text, &b, &e)) {
+                        bool any = false;
+                        std::string sn = snippet_of_text(dict, b, size_t(e - b), wanted, opt, &any);
+                        if (any) snippets[text] = std::move(sn);
+                    } else if (std::binary_search(wanted.begin(), wanted.end(), text))  // the text is its own only token: all of it (highlight_field.rs:198-203)
+                        snippets[text] = opt.snippet_start_tag + (text < dict.terms.size() ? dict.terms[text] : std::string()) + opt.snippet_end_tag;
+                }
+                i = j;
+            }
+        }
+    }
+    std::vector<SuggestEntry> out;
+    for (auto& r : ranked) {  // get_text_score_id_from_result(false, ..) search_field.rs:160-192: indexing `highlight` panics for a hit without a snippet
+        auto it = snippets.find(r.first);
+        if (it == snippets.end())
+            throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"highlight: hit " + std::to_string(r.first) + " has no snippet (the reference panics)\" ");
+        out.push_back(SuggestEntry{it->second, r.second, r.first});
+    }
+    return out;
+}
+
+
 // ---- dictionary scans requested by a batch (collected before compilation, answered by k_dict_scan)
 std::string fuzzy_key(const RequestSearchPart& p) {
     std::string path = p.path;

@@ -156,6 +156,8 @@ struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, 
 };
 std::vector<SuggestEntry> suggest_part(const Index& idx, const vqreq::RequestSearchPart& part, const FuzzyTable* fuzzy);
 void collect_suggest_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
+std::vector<SuggestEntry> highlight_part(const Index& idx, const vqreq::RequestSearchPart& part, const FuzzyTable* fuzzy);
+std::vector<SuggestEntry> run_highlight(const Index& idx, vqreq::RequestSearchPart part);  // search_field::highlight, search_field.rs:233-245
 std::vector<SuggestEntry> run_suggest(const Index& idx, const vqreq::Request& req);  // suggest_multi, search_field.rs:194-219
 
 // A leaf whose expansion matched many terms is materialised before the scan (k_union, K2): union of the

@@ -1348,6 +1348,30 @@ std::vector<SuggestEntry> run_suggest(const Index& idx, const vqreq::Request& re
     return merged;
 }
 
+// search_field::highlight (search_field.rs:233-245): the part's terms normalised (util.rs:11-29), its dictionary scan on the device, the snippets on
+// the host, ranked by score with the part's own top / skip
+std::vector<SuggestEntry> run_highlight(const Index& idx, vqreq::RequestSearchPart part) {
+    for (auto& t : part.terms) t = vqtext::normalize_text(t);
+    VQ_HIP(hipSetDevice(idx.device));
+    vqreq::Request probe_req;
+    probe_req.suggest = std::vector<vqreq::RequestSearchPart>{part};
+    FuzzyTable fuzzy;
+    collect_suggest_probes(idx, probe_req, fuzzy);
+    if (!fuzzy.empty()) {
+        Workspace& ws = idx.ws[idx.next_ws.fetch_add(1) % kWorkspaces];
+        std::unique_lock<std::mutex> lock(ws.mu);
+        ws.timed.clear();
+        ws.ev_used = 0;
+        run_fuzzy_probes(idx, ws, fuzzy, idx.pre_stream ? idx.pre_stream : idx.stream);
+    }
+    std::vector<SuggestEntry> out = highlight_part(idx, part, fuzzy.empty() ? nullptr : &fuzzy);
+    std::stable_sort(out.begin(), out.end(), [](const SuggestEntry& a, const SuggestEntry& b) { return a.score > b.score; });  // :189
+    const size_t skip = std::min(part.skip.value_or(0), out.size());  // apply_top_skip, search.rs:230-239
+    out.erase(out.begin(), out.begin() + skip);
+    if (part.top && out.size() > *part.top) out.resize(*part.top);
+    return out;
+}
+
 void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
                             std::vector<int>& status, std::vector<std::string>& errors) {
     constexpr uint64_t kMaxDeep = 65536;  // ranked hits one request may reach (64 scans)

@@ -39,6 +39,12 @@ struct SearchRequestOptions {  // src/search/request/search_request.rs:103-119
     inline std::string key() const;
 };
 
+struct SnippetInfo {  // src/search/request/snippet_info.rs:1-39 (the defaults are DEFAULT_SNIPPETINFO)
+    int64_t num_words_around_snippet = 5;
+    std::string snippet_start_tag = "<b>", snippet_end_tag = "</b>", snippet_connector = " ... ";
+    uint32_t max_snippets = 0xFFFFFFFFu;
+};
+
 struct RequestSearchPart {  // src/search/request/search_request.rs:127-179
     std::string path;
     std::vector<std::string> terms;
@@ -50,6 +56,7 @@ struct RequestSearchPart {  // src/search/request/search_request.rs:127-179
     std::optional<bool> ignore_case;
     std::optional<bool> snippet;
     bool has_snippet_info = false;
+    SnippetInfo snippet_info;  // meaningful when has_snippet_info
     std::optional<size_t> top, skip;
     std::optional<SearchRequestOptions> options;
     inline std::string key() const;  // stands in for derive(PartialEq, Hash): equal keys <=> equal requests
@@ -157,6 +164,12 @@ inline std::string RequestSearchPart::key() const {
     s += ignore_case ? (*ignore_case ? '1' : '0') : '-';
     s += snippet ? (*snippet ? '1' : '0') : '-';
     s += has_snippet_info ? 'I' : 'i';
+    if (has_snippet_info) {
+        s += std::to_string(snippet_info.num_words_around_snippet) + "," + std::to_string(snippet_info.max_snippets);
+        key_s(s, snippet_info.snippet_start_tag);
+        key_s(s, snippet_info.snippet_end_tag);
+        key_s(s, snippet_info.snippet_connector);
+    }
     s += top ? std::to_string(*top) : "-";
     s += ',';
     s += skip ? std::to_string(*skip) : "-";
@@ -256,7 +269,24 @@ inline RequestSearchPart search_part_from_json(const vqjson::Value& v) {
     p.boost = j_opt<float>(v, "boost", j_f32);
     p.ignore_case = j_opt<bool>(v, "ignore_case", j_bool);
     p.snippet = j_opt<bool>(v, "snippet", j_bool);
-    if (const vqjson::Value* s = v.get("snippet_info"); s && !s->is_null()) p.has_snippet_info = true;
+    if (const vqjson::Value* s = v.get("snippet_info"); s && !s->is_null()) {
+        if (!s->is_object()) json_fail("SnippetInfo: expected an object");
+        p.has_snippet_info = true;
+        SnippetInfo& si = p.snippet_info;
+        if (const vqjson::Value* n = s->get("num_words_around_snippet")) {
+            if (!n->is_number() || !n->is_integer || n->num < -9223372036854775808.0 || n->num >= 9223372036854775808.0)
+                json_fail("invalid type for num_words_around_snippet, expected i64");
+            si.num_words_around_snippet = int64_t(n->num);
+        }
+        if (const vqjson::Value* t = s->get("snippet_start_tag")) si.snippet_start_tag = j_string(*t, "snippet_start_tag");
+        if (const vqjson::Value* t = s->get("snippet_end_tag")) si.snippet_end_tag = j_string(*t, "snippet_end_tag");
+        if (const vqjson::Value* t = s->get("snippet_connector")) si.snippet_connector = j_string(*t, "snippet_connector");
+        if (const vqjson::Value* m = s->get("max_snippets")) {
+            const size_t d = j_usize(*m, "max_snippets");
+            if (d > 0xFFFFFFFFull) json_fail("invalid value for max_snippets, expected u32");
+            si.max_snippets = uint32_t(d);
+        }
+    }
     p.top = j_opt<size_t>(v, "top", j_usize);
     p.skip = j_opt<size_t>(v, "skip", j_usize);
     if (const vqjson::Value* o = v.get("options"); o && !o->is_null()) p.options = options_from_json(*o);

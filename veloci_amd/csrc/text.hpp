@@ -136,4 +136,56 @@ inline bool is_ascii(const char* s, size_t n) {
     return true;
 }
 
+// ---- util::normalize_text (src/util.rs:11-29): five regex replacements in sequence, then to_lowercase + trim — restated as passes over code
+// points.  `\d` is Unicode Nd and `\s` / trim are White_Space, as in Rust's regex and str::trim (tables: Unicode 13).
+inline bool is_decimal_digit(uint32_t cp) {
+    static const uint32_t kStart[] = {0x30,    0x660,   0x6f0,   0x7c0,   0x966,   0x9e6,   0xa66,   0xae6,   0xb66,   0xbe6,   0xc66,   0xce6,   0xd66,
+                                      0xde6,   0xe50,   0xed0,   0xf20,   0x1040,  0x1090,  0x17e0,  0x1810,  0x1946,  0x19d0,  0x1a80,  0x1a90,  0x1b50,
+                                      0x1bb0,  0x1c40,  0x1c50,  0xa620,  0xa8d0,  0xa900,  0xa9d0,  0xa9f0,  0xaa50,  0xabf0,  0xff10,  0x104a0, 0x10d30,
+                                      0x11066, 0x110f0, 0x11136, 0x111d0, 0x112f0, 0x11450, 0x114d0, 0x11650, 0x116c0, 0x11730, 0x118e0, 0x11950, 0x11c50,
+                                      0x11d50, 0x11da0, 0x16a60, 0x16b50, 0x1e140, 0x1e2f0, 0x1e950, 0x1fbf0};
+    if (cp >= 0x1d7ce && cp <= 0x1d7ff) return true;  // mathematical digits: five decades in a row
+    for (uint32_t s : kStart)
+        if (cp >= s && cp < s + 10) return true;
+    return false;
+}
+inline bool is_white_space(uint32_t cp) {
+    return (cp >= 0x9 && cp <= 0xD) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) || cp == 0x2028 || cp == 0x2029 ||
+           cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+inline std::string normalize_text(const std::string& text) {
+    std::vector<uint32_t> a = decode_utf8(text), b;
+    for (size_t i = 0; i < a.size();) {  // \([fmn\d]\) -> " "
+        if (a[i] == '(' && i + 2 < a.size() && a[i + 2] == ')' && (a[i + 1] == 'f' || a[i + 1] == 'm' || a[i + 1] == 'n' || is_decimal_digit(a[i + 1]))) {
+            b.push_back(' ');
+            i += 3;
+        } else b.push_back(a[i++]);
+    }
+    a.clear();
+    for (uint32_t c : b) {  // [\(\)] -> " ", then [{}'"“] -> ""
+        if (c == '(' || c == ')') c = ' ';
+        if (c == '{' || c == '}' || c == '\'' || c == '"' || c == 0x201C) continue;
+        a.push_back(c);
+    }
+    b.clear();
+    for (size_t i = 0; i < a.size();) {  // \s\s+ -> " " (a lone white-space character stays what it is)
+        size_t j = i;
+        while (j < a.size() && is_white_space(a[j])) ++j;
+        if (j - i >= 2) {
+            b.push_back(' ');
+            i = j;
+        } else b.push_back(a[i++]);
+    }
+    a.clear();
+    for (uint32_t c : b)  // [,.…;・’-] -> ""
+        if (!(c == ',' || c == '.' || c == 0x2026 || c == ';' || c == 0x30FB || c == 0x2019 || c == '-')) a.push_back(c);
+    a = to_lower_cps(a);
+    size_t lo = 0, hi = a.size();
+    while (lo < hi && is_white_space(a[lo])) ++lo;
+    while (hi > lo && is_white_space(a[hi - 1])) --hi;
+    std::string out;
+    for (size_t i = lo; i < hi; ++i) append_utf8(out, a[i]);
+    return out;
+}
+
 }  // namespace vqtext

@@ -258,6 +258,7 @@ def build_index(docs, indices="", token_values=None):
             raw[path] = {
                 "fc": fc,
                 "tokens_to_text_id": [] if on("TokensToTextID") else None,
+                "text_id_to_token_ids": {} if on("TextIDToTokenIds") else None,  # text id -> its tokens, stored once (create.rs:228, 267-270)
                 "text_id_to_parent": [] if on("TextIDToParent") else None,
                 "text_id_to_anchor": [] if on("TextIDToAnchor") else None,
                 "phrase": [] if on("PhrasePairToAnchor") else None,
@@ -302,8 +303,14 @@ def build_index(docs, indices="", token_values=None):
                 seen = []
                 prev = None
                 pos = 0
+                t2t = d["text_id_to_token_ids"]
+                store_tokens = t2t is not None and text_id not in t2t
+                if store_tokens:
+                    t2t[text_id] = []
                 for tok, is_sep in toks:
                     tid = term_id[path][tok]
+                    if store_tokens:
+                        t2t[text_id].append(tid)
                     add(d["tokens_to_text_id"], (tid, text_id))
                     if d["postings"] is not None:
                         seen.append((tid, pos, t[tok]))
@@ -344,6 +351,11 @@ def build_index(docs, indices="", token_values=None):
         tp = path + TEXTINDEX
         if d["tokens_to_text_id"] is not None:
             data.add_key_value_store(tp + ".tokens_to_text_id", *csr_from_lists(_multi_store(d["tokens_to_text_id"], True)))
+        if d["text_id_to_token_ids"]:  # create.rs:633-635: insertion order kept, separators included, nothing deduplicated
+            rows = [[] for _ in range(max(d["text_id_to_token_ids"]) + 1)]
+            for k, v in d["text_id_to_token_ids"].items():
+                rows[k] = v
+            data.add_key_value_store(tp + ".text_id_to_token_ids", *csr_from_lists(rows))
         if d["postings"] is not None:  # stream_iter_to_anchor_score create.rs:389-411
             by_token = {}
             for tid, anchor, score in d["postings"]:

@@ -112,6 +112,22 @@ def suggest(request, index):
         L.vq_suggest_free(out)
 
 
+def highlight(part, index):
+    """== search_field::highlight (src/search/search_field.rs:233-245): `part` is a RequestSearchPart (dict or JSON) with "snippet": true.
+    -> [(snippet, score, text_id)]"""
+    L = _lib.lib()
+    if isinstance(part, dict):
+        part = json.dumps(part)
+    if isinstance(part, str):
+        part = part.encode()
+    out = C.c_void_p()
+    _lib.check(L.vq_highlight_json(index.h, part, len(part), C.byref(out)))
+    try:
+        return [(L.vq_suggest_text(out, i).decode(), float(L.vq_suggest_score(out, i)), int(L.vq_suggest_term_id(out, i))) for i in range(L.vq_suggest_len(out))]
+    finally:
+        L.vq_suggest_free(out)
+
+
 def search_batch(requests, index, raise_on_error=True):
     """n independent searches executed as one device batch (`vq_search_batch`)."""
     L = _lib.lib()
