@@ -90,12 +90,37 @@ void launch_finalize(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, con
     no_device("k_finalize");
 }
 void launch_facet_select(hipStream_t, uint32_t, const FacetJob*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*) { no_device("k_facet_select"); }
-void launch_range_hits(hipStream_t, uint32_t, const UList*, const RangeTask*, unsigned long long*) { no_device("k_range_hits"); }
+void launch_range_hits(hipStream_t, uint32_t, uint32_t, const UList*, const RangeJobD*, const uint32_t*, unsigned long long*) { no_device("k_range_hits"); }
 void launch_union(hipStream_t, bool, uint32_t, const UList*, const UTask*, const uint32_t*, uint32_t*, const uint64_t*, uint32_t*, float*, uint32_t*) { no_device("k_union"); }
 void launch_scan_union(hipStream_t, bool, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*) {
     no_device("k_scan_union");
 }
-void launch_dict_scan(hipStream_t, const DictProbe*, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t, uint32_t*, uint32_t, DictMatch*) { no_device("k_dict_scan"); }
+// VQ_STUB_DICT_SCAN=1 (tools/host_profile.py only): exact / prefix probes answered by a plain loop, so that the host compiler can be timed on this
+// machine on requests with prefix leaves.  The sanitizer test leaves it off: there every launcher throws.
+void launch_dict_scan(hipStream_t, const DictProbe* probes, uint32_t probe_base, uint32_t n_probes, const uint32_t* off, const uint16_t* chars, const uint16_t* low_chars,
+                      uint32_t num_terms, uint32_t* out_count, uint32_t out_cap, DictMatch* out) {
+    if (!std::getenv("VQ_STUB_DICT_SCAN")) no_device("k_dict_scan");
+    for (uint32_t p = 0; p < n_probes; ++p) {
+        const DictProbe& P = probes[p];
+        if (P.max_d != 0) no_device("k_dict_scan (the stub's loop answers distance 0 only)");
+        for (uint32_t t = 0; t < num_terms; ++t) {
+            const uint32_t n = off[t + 1] - off[t];
+            if ((P.flags & 2u) ? n < P.m : n != P.m) continue;
+            bool eq = true;
+            for (uint32_t i = 0; i < P.m && eq; ++i) eq = chars[off[t] + i] == P.query[i];
+            if (!eq) continue;
+            uint32_t info = 0;
+            if (P.lm != 0xFFFFFFFFu) {  // lower-cased hit against the lower-cased term: a prefix match is n - lm insertions away
+                bool starts = n >= P.lm;
+                for (uint32_t i = 0; i < P.lm && starts; ++i) starts = low_chars[off[t] + i] == P.lquery[i];
+                const uint32_t d = starts ? std::min<uint32_t>(n - P.lm, 255u) : 255u;
+                info = d | (d << 8) | (uint32_t(starts) << 16);
+            }
+            const uint32_t pos = (*out_count)++;
+            if (pos < out_cap) out[pos] = DictMatch{probe_base + p, t, info};
+        }
+    }
+}
 void launch_loc_gather(hipStream_t, const LocRow*, uint32_t, const uint32_t*, uint32_t*) { no_device("k_loc_gather"); }
 void launch_loc_expand(hipStream_t, bool, const LocJob*, uint32_t, const uint32_t*, uint32_t, uint32_t*, unsigned long long*) { no_device("k_loc_expand"); }
 void launch_loc_compact(hipStream_t, const LocJob*, uint32_t, const unsigned long long*, uint32_t*, float*, uint32_t*) { no_device("k_loc_compact"); }

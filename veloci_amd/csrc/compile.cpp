@@ -16,7 +16,8 @@
 #include "text.hpp"
 
 namespace vq {
-std::atomic<uint64_t> g_compile_ns[6];  // 0 lookup_terms, 1 resolve_boost_1n, 2 emit_boost_1n rest, 3 leaf lists, 4 the longest single compile_query, 5 total
+std::atomic<uint64_t> g_compile_ns[16];  // 0 lookup_terms, 1 resolve_boost_1n, 2 emit_boost_1n rest, 3 leaf lists, 4 the longest single compile_query, 5 total;
+                                         // inside 1: 6 value-id gather, 7 sort, 8 (anchor, value) pairs; 9 order check + layers of a resolved list
 
 using namespace vqreq;
 
@@ -139,6 +140,51 @@ struct Leaf {  // PlanStepFieldSearchToTokenIds + its result (execution_plan.rs:
     std::vector<uint32_t> hits_ids;                        // term ids
     std::map<uint32_t, ExplainRecs> explain;               // options.explain: the dictionary result's records per term id (search_field.rs:334-343)
 };
+// Ascending, duplicate-free — for id lists that can reach 10^5 entries per leaf (the value ids behind a prefix leaf's 1:n boost): a bitmap over
+// the ids' span when it is dense enough (one pass to mark, one to read back), LSD radix passes otherwise; short lists take std::sort.
+void sort_unique_u32(std::vector<uint32_t>& v) {
+    const size_t n = v.size();
+    if (n < 2048) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        return;
+    }
+    uint32_t lo = v[0], hi = v[0];
+    for (uint32_t x : v) {
+        lo = std::min(lo, x);
+        hi = std::max(hi, x);
+    }
+    const uint64_t span = uint64_t(hi) - lo + 1, words = (span + 63) / 64;
+    if (words <= 8 * n) {
+        thread_local std::vector<uint64_t> bits;
+        bits.assign(words, 0);
+        for (uint32_t x : v) bits[(x - lo) >> 6] |= 1ull << ((x - lo) & 63);
+        size_t k = 0;
+        for (uint64_t w = 0; w < words; ++w) {
+            uint64_t b = bits[w];
+            while (b) {
+                v[k++] = lo + uint32_t(w * 64) + uint32_t(__builtin_ctzll(b));
+                b &= b - 1;
+            }
+        }
+        v.resize(k);
+        return;
+    }
+    thread_local std::vector<uint32_t> tmp;
+    tmp.resize(n);
+    uint32_t* a = v.data();
+    uint32_t* b = tmp.data();
+    for (uint32_t shift = 0; shift < 32 && (span - 1) >> shift; shift += 11) {
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; ++i) ++count[(((a[i] - lo) >> shift) & 2047u) + 1];
+        for (int i = 0; i < 2048; ++i) count[i + 1] += count[i];
+        for (size_t i = 0; i < n; ++i) b[count[((a[i] - lo) >> shift) & 2047u]++] = a[i];
+        std::swap(a, b);
+    }
+    if (a != v.data()) std::memcpy(v.data(), a, n * sizeof(uint32_t));
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
 // VQ_TIMING: where request compilation spends its time (summed over threads, printed per batch by exec.cpp)
 struct PhaseTimer {
     static bool on() {
@@ -728,26 +774,32 @@ struct Compiler {
                 if (t2t.host_row(h.first, &rb, &re)) ids.insert(ids.end(), rb, re);
                 else ids.push_back(h.first);  // is a text id
             }
-            std::sort(ids.begin(), ids.end());
-            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            sort_unique_u32(ids);
         } else ids = l.hits_ids;
         return ids;
     }
     std::vector<std::pair<uint32_t, float>> resolve_boost_1n(const RequestSearchPart& part, Leaf& l, const RequestBoostPart& b) {
         PhaseTimer pt(1);
-        const std::vector<uint32_t> ids = boost_1n_text_ids(part, l);
         std::vector<uint32_t> value_ids;  // join_to_parent_ids search.rs:281-315
-        const KVStore& to_parent = kv_store(l.path + VALUE_ID_TO_PARENT);
-        for (uint32_t id : ids) {
-            const uint32_t *rb, *re;
-            if (to_parent.host_row(id, &rb, &re)) value_ids.insert(value_ids.end(), rb, re);
+        {
+            PhaseTimer gather(6);
+            const std::vector<uint32_t> ids = boost_1n_text_ids(part, l);
+            const KVStore& to_parent = kv_store(l.path + VALUE_ID_TO_PARENT);
+            for (uint32_t id : ids) {
+                const uint32_t *rb, *re;
+                if (to_parent.host_row(id, &rb, &re)) value_ids.insert(value_ids.end(), rb, re);
+            }
         }
-        std::sort(value_ids.begin(), value_ids.end());
-        value_ids.erase(std::unique(value_ids.begin(), value_ids.end()), value_ids.end());
+        {
+            PhaseTimer sort(7);
+            sort_unique_u32(value_ids);
+        }
+        PhaseTimer pairs_timer(8);
         auto bit = idx.boost.find(b.path + BOOST_VALID_TO_VALUE);
         if (bit == idx.boost.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + b.path + BOOST_VALID_TO_VALUE);
         const KVStore& to_anchor = kv_store(b.path + VALUE_ID_TO_ANCHOR);
         std::vector<std::pair<uint32_t, float>> pairs;  // (anchor, boost value) in value-id order
+        pairs.reserve(value_ids.size());
         for (uint32_t vid : value_ids) {
             float v;
             if (!bit->second.host_value(vid, &v)) continue;
@@ -819,15 +871,7 @@ struct Compiler {
                 }
             }
         }
-        std::shared_ptr<Boost1nEntry> entry;
-        Boost1nCache local;
-        Boost1nCache& cache = boost_cache ? *boost_cache : local;
-        {
-            std::lock_guard<std::mutex> g(cache.mu);
-            auto& slot = cache.map[cache_key];
-            if (!slot) slot = std::make_shared<Boost1nEntry>();
-            entry = slot;
-        }
+        std::shared_ptr<Boost1nEntry> entry = boost_cache ? boost_cache->entry(cache_key) : std::make_shared<Boost1nEntry>();
         auto make_layers = [&](const std::vector<std::vector<std::pair<uint32_t, float>>>& layers) {
             auto out = std::make_shared<std::vector<Boost1nEntry::Layer>>();
             for (auto& layer : layers) {
@@ -846,6 +890,7 @@ struct Compiler {
         };
         std::call_once(entry->resolved, [&] {
             entry->pairs = resolve_boost_1n(part, l, b);  // (anchor, boost value) in value-id order
+            PhaseTimer order_check(9);
             const auto& pairs = entry->pairs;
             for (size_t i = 1; i < pairs.size(); ++i) {
                 if (pairs[i].first < pairs[i - 1].first) entry->ascending = false;
@@ -853,9 +898,11 @@ struct Compiler {
             }
             if (!entry->ascending) return;
             if (!entry->several) entry->layers = make_layers({pairs});
-            else
+            else {
+                entry->anchors.reserve(pairs.size());
                 for (auto& pr : pairs)
                     if (entry->anchors.empty() || entry->anchors.back() != pr.first) entry->anchors.push_back(pr.first);
+            }
         });
         if (!entry->ascending) unsupported("1:n field boost whose value ids are not in anchor order (" + b.path + ")");
         std::shared_ptr<const std::vector<Boost1nEntry::Layer>> layers = entry->layers;
@@ -880,14 +927,7 @@ struct Compiler {
                 job.union_key = leaf_union_key(l);
                 job.tokens.reserve(l.hits_scores.size());
                 for (auto& h : l.hits_scores) job.tokens.push_back(h.first);
-                job.lo.reserve(2 * anchors.size());
-                job.hi.reserve(2 * anchors.size());
-                for (size_t j = 0; j < anchors.size(); ++j) {
-                    job.lo.push_back(anchors[j]);
-                    job.hi.push_back(anchors[j] + 1u);
-                    job.lo.push_back(j ? anchors[j - 1] + 1u : 0u);
-                    job.hi.push_back(j ? anchors[j] : 0u);
-                }
+                job.anchors = std::shared_ptr<const std::vector<uint32_t>>(entry, &entry->anchors);
                 cq.range_requests.push_back(std::move(job));
                 // (placeholder: this compilation is thrown away)
                 static const auto empty = std::make_shared<const std::vector<Boost1nEntry::Layer>>(1);

@@ -186,8 +186,8 @@ struct RangeJob {
     std::string store_path;          // "<field>.textindex.to_anchor_id_score"
     std::vector<uint32_t> tokens;    // the leaf's posting lists
     std::string union_key;           // key of the leaf's union job when it asks to be materialised (the merged list is scanned instead)
-    std::vector<uint32_t> lo, hi;    // doc ranges [lo, hi)
-    std::vector<uint64_t> counts;    // result: leaf postings inside each range, summed over the shards
+    std::shared_ptr<const std::vector<uint32_t>> anchors;  // the boost list's entry anchors a_0 < a_1 < ... (owned by the batch's Boost1nEntry)
+    std::vector<uint64_t> counts;    // result, summed over the shards: [2j] leaf postings at a_j, [2j + 1] strictly between a_(j-1) and a_j (0 for j = 0)
 };
 using RangeTable = std::map<std::string, RangeJob>;
 // (anchor, boost value) lists of 1:n field boosts resolved on the host, shared by the requests and compilation passes of one batch
@@ -206,9 +206,20 @@ struct Boost1nEntry {
     std::vector<uint32_t> anchors;  // several: the distinct anchors, ascending
     std::shared_ptr<const std::vector<Layer>> layers;
 };
-struct Boost1nCache {
-    std::mutex mu;
-    std::unordered_map<std::string, std::shared_ptr<Boost1nEntry>> map;
+struct Boost1nCache {  // sharded: every compiling thread comes here once per boosted leaf, and a thread that has to sleep on a lock loses more time
+                       // than the lookup takes
+    static constexpr size_t kShards = 64;
+    struct Shard {
+        std::mutex mu;
+        std::unordered_map<std::string, std::shared_ptr<Boost1nEntry>> map;
+    } shard[kShards];
+    std::shared_ptr<Boost1nEntry> entry(const std::string& key) {
+        Shard& sh = shard[std::hash<std::string>{}(key) % kShards];
+        std::lock_guard<std::mutex> g(sh.mu);
+        auto& slot = sh.map[key];
+        if (!slot) slot = std::make_shared<Boost1nEntry>();
+        return slot;
+    }
     const std::map<std::string, struct Boost1nJob>* device = nullptr;  // lists the K10 pre-pass has resolved on the device (second compilation pass on)
 };
 // Text locality of a field whose text ids are not anchors (boost.rs:34-87), resolved before the final compilation by the K7 pre-pass: the

@@ -31,7 +31,7 @@ void PinnedBuf::ensure(size_t n) {
     bytes = want;
 }
 
-extern std::atomic<uint64_t> g_compile_ns[6];
+extern std::atomic<uint64_t> g_compile_ns[16];
 static bool timing_enabled() {
     static const bool on = std::getenv("VQ_TIMING") != nullptr;
     return on;
@@ -72,10 +72,17 @@ static size_t host_threads() {
     return n;
 }
 // [begin, end) parts of n items for `threads` workers, shrinking: each part is 1 / (2 x threads) of what is left, at least one item
-static std::vector<std::pair<size_t, size_t>> guided_ranges(size_t n, size_t threads) {
+// `singles`: that many leading items are parts of their own (items sorted heaviest first: the heavy ones must not queue up behind each other)
+static std::vector<std::pair<size_t, size_t>> guided_ranges(size_t n, size_t threads, size_t singles = 0) {
     std::vector<std::pair<size_t, size_t>> out;
     if (threads <= 1) {
         if (n) out.push_back({0, n});
+        return out;
+    }
+    singles = std::min(singles, n);
+    for (size_t b = 0; b < singles; ++b) out.push_back({b, b + 1});
+    if (singles) {
+        for (auto& r : guided_ranges(n - singles, threads)) out.push_back({r.first + singles, r.second + singles});
         return out;
     }
     static const size_t fixed = std::getenv("VQ_COMPILE_PART") ? size_t(std::atoi(std::getenv("VQ_COMPILE_PART"))) : 0;  // (experiments: parts of a fixed size)
@@ -414,10 +421,16 @@ void run_union_level(bool timed, Workspace& ws, std::vector<UnionTaskH>& tasks, 
 }
 }  // namespace
 
-// Range jobs (k_range_hits): how many postings of a leaf fall into each requested doc range; summed over the shards.
+// Range jobs (k_range_hits): the leaf's postings at and between the entry anchors of its 1:n boost list; summed over the shards.
 void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const UnionTable& unions, hipStream_t st) {
     std::vector<UList> ulists;
-    std::vector<RangeTask> tasks;
+    std::vector<RangeJobD> jobs;
+    size_t n_anchors = 0;
+    uint32_t n_blocks = 0;
+    for (auto& kv : table) n_anchors += kv.second.anchors ? kv.second.anchors->size() : 0;
+    if (n_anchors > 0x7FFFFFF0ull) throw VelociError(ERR_UNSUPPORTED, "1:n field boosts of one batch with more than 2^31 boosted anchors");
+    std::vector<uint32_t> anchors;
+    anchors.reserve(n_anchors);
     for (auto& kv : table) {
         RangeJob& job = kv.second;
         const PostingStore& ps = idx.postings.at(job.store_path);
@@ -438,30 +451,43 @@ void run_range_jobs(const Index& idx, Workspace& ws, RangeTable& table, const Un
             u.len = ps.len[tid];
             ulists.push_back(u);
         }
-        for (size_t r = 0; r < job.lo.size(); ++r) tasks.push_back(RangeTask{lb, uint32_t(ulists.size()) - lb, job.lo[r], job.hi[r]});
+        RangeJobD d{};
+        d.list_begin = lb;
+        d.n_lists = uint32_t(ulists.size()) - lb;
+        d.anchor_begin = uint32_t(anchors.size());
+        d.n_anchors = job.anchors ? uint32_t(job.anchors->size()) : 0u;
+        d.block_begin = n_blocks;
+        if (job.anchors) anchors.insert(anchors.end(), job.anchors->begin(), job.anchors->end());
+        if (d.n_lists == 0 || d.n_anchors == 0) continue;  // nothing to count: the job's counts stay 0
+        n_blocks += d.n_lists == 1 ? (d.n_anchors + 63u) / 64u : d.n_anchors;
+        jobs.push_back(d);
     }
-    std::vector<uint64_t> counts(tasks.size(), 0);
-    if (!tasks.empty() && !ulists.empty()) {
+    std::vector<uint64_t> counts(2 * n_anchors, 0);
+    if (!jobs.empty()) {
         auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-        const size_t o_tasks = al(ulists.size() * sizeof(UList)), o_cnt = o_tasks + al(tasks.size() * sizeof(RangeTask)), bytes = o_cnt + al(tasks.size() * 8);
+        const size_t o_jobs = al(ulists.size() * sizeof(UList)), o_anchors = o_jobs + al(jobs.size() * sizeof(RangeJobD)), o_cnt = o_anchors + al(anchors.size() * 4),
+                     bytes = o_cnt + al(counts.size() * 8);
         ws.d_union_meta.ensure(bytes);
         uint8_t* m = ws.d_union_meta.as<uint8_t>();
         VQ_HIP(hipMemcpyAsync(m, ulists.data(), ulists.size() * sizeof(UList), hipMemcpyHostToDevice, st));
-        VQ_HIP(hipMemcpyAsync(m + o_tasks, tasks.data(), tasks.size() * sizeof(RangeTask), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(m + o_jobs, jobs.data(), jobs.size() * sizeof(RangeJobD), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(m + o_anchors, anchors.data(), anchors.size() * 4, hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemsetAsync(m + o_cnt, 0, counts.size() * 8, st));
         {
-            LaunchTimer timer(idx.profile.enabled, ws, st, K_RANGE_HITS, 0, 0, tasks.size());
-            launch_range_hits(st, uint32_t(tasks.size()), reinterpret_cast<const UList*>(m), reinterpret_cast<const RangeTask*>(m + o_tasks),
-                              reinterpret_cast<unsigned long long*>(m + o_cnt));
+            LaunchTimer timer(idx.profile.enabled, ws, st, K_RANGE_HITS, 0, 0, jobs.size());
+            launch_range_hits(st, n_blocks, uint32_t(jobs.size()), reinterpret_cast<const UList*>(m), reinterpret_cast<const RangeJobD*>(m + o_jobs),
+                              reinterpret_cast<const uint32_t*>(m + o_anchors), reinterpret_cast<unsigned long long*>(m + o_cnt));
         }
         VQ_HIP(hipGetLastError());
-        VQ_HIP(hipMemcpyAsync(counts.data(), m + o_cnt, tasks.size() * 8, hipMemcpyDeviceToHost, st));
+        VQ_HIP(hipMemcpyAsync(counts.data(), m + o_cnt, counts.size() * 8, hipMemcpyDeviceToHost, st));
         VQ_HIP(hipStreamSynchronize(st));
     }
     if (idx.sharded()) idx.sum_over_shards(counts);
     size_t k = 0;
     for (auto& kv : table) {
-        kv.second.counts.assign(counts.begin() + k, counts.begin() + k + kv.second.lo.size());
-        k += kv.second.lo.size();
+        const size_t n = kv.second.anchors ? 2 * kv.second.anchors->size() : 0;
+        kv.second.counts.assign(counts.begin() + k, counts.begin() + k + n);
+        k += n;
     }
 }
 
@@ -866,8 +892,29 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     pb->slot.assign(n, UINT32_MAX);
     pb->queries.resize(n);
     Boost1nCache boost_cache;  // resolved 1:n boost lists, shared by the batch's requests and compilation passes
+    // Requests are compiled heaviest first: a request's cost follows the terms its prefix / fuzzy leaves matched (their posting lists, the 1:n boost
+    // lists behind them), which the dictionary scans have just counted; one such request can take as long as a hundred others, and claimed last
+    // it alone would be the end of the parallel pass.
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = uint32_t(i);
+    const bool heavy_first = n >= 64 && !fuzzy.empty() && host_threads() > 1;
+    if (heavy_first) {
+        std::vector<uint64_t> weight(n, 0);
+        std::function<void(const vqreq::SearchRequest&, uint64_t&)> walk = [&](const vqreq::SearchRequest& r, uint64_t& w) {
+            if (r.kind == vqreq::SearchRequest::Search) {
+                if (!needs_dictionary_scan(r.part)) return;
+                auto it = fuzzy.find(fuzzy_key(r.part));
+                if (it != fuzzy.end()) w += it->second.matches.size();
+            } else
+                for (auto& q : r.tree.queries) walk(q, w);
+        };
+        for (size_t i = 0; i < n; ++i)
+            if (reqs[i] && reqs[i]->search_req) walk(*reqs[i]->search_req, weight[i]);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+    }
     auto compile_range = [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
+        for (size_t k = b; k < e; ++k) {
+            const size_t i = order[k];
             if (!reqs[i]) {
                 pb->queries[i].status = ERR_INVALID_ARGUMENT;
                 pb->queries[i].error = "null request";
@@ -879,18 +926,23 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         // one request): few claims while everybody is busy, single requests at the end — a worker that wakes late (an idle core takes ~0.1 ms,
         // a third of the whole job) still finds work, and requests of very different cost (a prefix leaf with a 1:n boost list takes 1000x a
         // plain AND) balance out.
-        const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(n, host_threads());
+        const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(n, host_threads(), heavy_first ? 4 * host_threads() : 0);
         host_pool(idx).run(ranges.size(), [&](size_t p) { compile_range(ranges[p].first, ranges[p].second); });
     } else compile_range(0, n);
     const double t_pass1 = now_ms();
+    if (timing_enabled() && std::getenv("VQ_TIMING_SUB")) {  // (tools/host_profile.py stops at the first launch: the running totals, pass 1 only)
+        std::fprintf(stderr, "[vq timing] pass 1 of %zu: %.3f ms wall;", n, t_pass1 - t_probes);
+        for (int k = 0; k < 10; ++k) std::fprintf(stderr, " [%d] %.3f", k, g_compile_ns[k].load() * 1e-6);
+        std::fprintf(stderr, "\n");
+    }
     // ---- leaves that asked to be materialised first (K2): run the union jobs once per batch
     UnionTable unions;
     RangeTable ranges;
     LocalityTable localities;
     Boost1nTable boost1n;
     std::vector<size_t> again;
-    for (size_t i = 0; i < n; ++i)
-        if (pb->queries[i].status == kStatusNeedsUnion || pb->queries[i].status == kStatusNeedsRanges) {
+    for (size_t k = 0; k < n; ++k)
+        if (const size_t i = order[k]; pb->queries[i].status == kStatusNeedsUnion || pb->queries[i].status == kStatusNeedsRanges) {
             again.push_back(i);
             for (auto& j : pb->queries[i].union_requests) unions.emplace(j.key, j);
             for (auto& j : pb->queries[i].locality_requests) localities.emplace(j.key, j);
@@ -943,7 +995,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 }
             };
             if (again.size() >= 8 && host_threads() > 1) {
-                const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(again.size(), host_threads());
+                const std::vector<std::pair<size_t, size_t>> ranges = guided_ranges(again.size(), host_threads(), heavy_first ? 4 * host_threads() : 0);
                 host_pool(idx).run(ranges.size(), [&](size_t p) { recompile(ranges[p].first, ranges[p].second); });
             } else recompile(0, again.size());
             std::vector<size_t> still;
@@ -1308,8 +1360,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
                      t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense + spans_leaf, now_ms() - t_compiled);
     if (timing_enabled()) {  // thread-time inside compile_query since the last batch (all passes, all threads)
-        uint64_t v[6];
-        for (int k = 0; k < 6; ++k) v[k] = g_compile_ns[k].exchange(0);
+        uint64_t v[16];
+        for (int k = 0; k < 16; ++k) v[k] = g_compile_ns[k].exchange(0);
+        if (std::getenv("VQ_TIMING_SUB")) {
+            std::fprintf(stderr, "[vq timing] inside 1:n resolve (thread-ms; 6 value-id gather, 7 sort, 8 pairs, 9 order check + layers):");
+            for (int k = 6; k < 10; ++k) std::fprintf(stderr, " [%d] %.3f", k, v[k] * 1e-6);
+            std::fprintf(stderr, "\n");
+        }
         std::fprintf(stderr, "[vq timing] compile thread-ms: total %.3f = dictionary lookups %.3f + 1:n resolve %.3f + 1:n layers %.3f + leaf lists %.3f + rest %.3f; longest request %.3f\n", v[5] * 1e-6,
                      v[0] * 1e-6, v[1] * 1e-6, (v[2] - v[1]) * 1e-6, v[3] * 1e-6, (double(v[5]) - double(v[0]) - double(v[2]) - double(v[3])) * 1e-6, v[4] * 1e-6);
     }

@@ -3228,25 +3228,55 @@ __device__ __forceinline__ uint32_t lane_lower_bound(const VQ_GLOBAL uint32_t* a
     return lo;
 }
 
-// Leaf hits inside doc ranges: task t counts the postings with doc in [lo, hi) over its lists (one wave per task, lanes stride
-// over the lists).  A pre-pass of 1:n field boosts with several values per anchor (compile.cpp emit_boost_1n, boost.rs:255-281).
-__global__ __launch_bounds__(64) void k_range_hits(const UList* __restrict__ ulists, const RangeTask* __restrict__ tasks, uint32_t n_tasks,
-                                                    unsigned long long* __restrict__ counts) {
-    const uint32_t t = blockIdx.x;
-    if (t >= n_tasks) return;
-    const RangeTask task = tasks[t];
-    unsigned long long c = 0;
-    for (uint32_t i = threadIdx.x; i < task.n_lists; i += 64u) {
-        const UList L = ulists[task.list_begin + i];
-        const VQ_GLOBAL uint32_t* d = as_global(L.docs);
-        c += lane_lower_bound(d, L.len, task.hi) - lane_lower_bound(d, L.len, task.lo);
+// Leaf hits around the entry anchors of a 1:n boost list with several values per anchor (compile.cpp emit_boost_1n, boost.rs:255-281): for the
+// job's anchors a_0 < a_1 < ... the leaf's postings AT a_j (counts[2j]) and strictly between a_(j-1) and a_j (counts[2j + 1]; 0 for j = 0),
+// summed over the leaf's lists.  A materialised leaf is one list: a lane per anchor, 64 anchors per block; otherwise a block per anchor with
+// the lanes striding over the lists.  The host sends the anchors themselves (4 B each), not the ranges.
+__global__ __launch_bounds__(64) void k_range_hits(const UList* __restrict__ ulists, const RangeJobD* __restrict__ jobs, uint32_t n_jobs,
+                                                    const uint32_t* __restrict__ anchors, unsigned long long* __restrict__ counts) {
+    uint32_t jl = 0, jh = n_jobs;
+    while (jh - jl > 1u) {  // the job this block belongs to (uniform)
+        const uint32_t mid = (jl + jh) >> 1;
+        if (jobs[mid].block_begin <= blockIdx.x) jl = mid;
+        else jh = mid;
     }
-    for (uint32_t off = 32; off > 0; off >>= 1) c += shfl_u64(c, (threadIdx.x + off) & 63u);
-    if (threadIdx.x == 0) counts[t] = c;
+    const RangeJobD J = jobs[jl];
+    const uint32_t b = blockIdx.x - J.block_begin;
+    const VQ_GLOBAL uint32_t* an = as_global(anchors) + J.anchor_begin;
+    if (J.n_lists == 1u) {
+        const uint32_t j = b * 64u + threadIdx.x;
+        if (j >= J.n_anchors) return;
+        const UList L = ulists[J.list_begin];
+        const VQ_GLOBAL uint32_t* d = as_global(L.docs);
+        const uint32_t a = an[j];
+        const uint32_t p1 = lane_lower_bound(d, L.len, a), p2 = lane_lower_bound(d, L.len, a + 1u);
+        const uint32_t p0 = j ? lane_lower_bound(d, L.len, an[j - 1u] + 1u) : p1;
+        counts[2ull * (J.anchor_begin + j)] = p2 - p1;
+        counts[2ull * (J.anchor_begin + j) + 1ull] = p1 - p0;
+        return;
+    }
+    if (b >= J.n_anchors) return;
+    const uint32_t a = an[b], prev = b ? an[b - 1u] + 1u : a;
+    unsigned long long hit = 0, between = 0;
+    for (uint32_t i = threadIdx.x; i < J.n_lists; i += 64u) {
+        const UList L = ulists[J.list_begin + i];
+        const VQ_GLOBAL uint32_t* d = as_global(L.docs);
+        const uint32_t p1 = lane_lower_bound(d, L.len, a);
+        hit += lane_lower_bound(d, L.len, a + 1u) - p1;
+        between += p1 - lane_lower_bound(d, L.len, prev);
+    }
+    for (uint32_t off = 32; off > 0; off >>= 1) {
+        hit += shfl_u64(hit, (threadIdx.x + off) & 63u);
+        between += shfl_u64(between, (threadIdx.x + off) & 63u);
+    }
+    if (threadIdx.x == 0) {
+        counts[2ull * (J.anchor_begin + b)] = hit;
+        counts[2ull * (J.anchor_begin + b) + 1ull] = between;
+    }
 }
-void launch_range_hits(hipStream_t st, uint32_t n_tasks, const UList* ulists, const RangeTask* tasks, unsigned long long* counts) {
-    if (!n_tasks) return;
-    hipLaunchKernelGGL(k_range_hits, dim3(n_tasks), dim3(64), 0, st, ulists, tasks, n_tasks, counts);
+void launch_range_hits(hipStream_t st, uint32_t n_blocks, uint32_t n_jobs, const UList* ulists, const RangeJobD* jobs, const uint32_t* anchors, unsigned long long* counts) {
+    if (!n_blocks || !n_jobs) return;
+    hipLaunchKernelGGL(k_range_hits, dim3(n_blocks), dim3(64), 0, st, ulists, jobs, n_jobs, anchors, counts);
 }
 
 constexpr uint32_t kUnionWindow = 16;

@@ -26,8 +26,9 @@ struct UList {  // one input list of a union task (k_union)
     float term_score;
     uint32_t flags, pad;
 };
-struct RangeTask {  // k_range_hits: postings with doc in [lo, hi) over lists [list_begin, list_begin + n_lists)
-    uint32_t list_begin, n_lists, lo, hi;
+struct RangeJobD {  // k_range_hits: the leaf's lists [list_begin, + n_lists), its 1:n boost list's entry anchors [anchor_begin, + n_anchors) and the
+                    // job's first block (n_lists == 1: 64 anchors per block, else one)
+    uint32_t list_begin, n_lists, anchor_begin, n_anchors, block_begin, pad;
 };
 struct UTask {  // <= 64 lists merged by one wave per span
     uint32_t list_begin, n_lists;  // into the UList table
@@ -60,7 +61,7 @@ void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const ui
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n);
 
-void launch_range_hits(hipStream_t st, uint32_t n_tasks, const UList* ulists, const RangeTask* tasks, unsigned long long* counts);
+void launch_range_hits(hipStream_t st, uint32_t n_blocks, uint32_t n_jobs, const UList* ulists, const RangeJobD* jobs, const uint32_t* anchors, unsigned long long* counts);
 void launch_union(hipStream_t st, bool write, uint32_t total_spans, const UList* ulists, const UTask* tasks, const uint32_t* span_task, uint32_t* span_cnt,
                   const uint64_t* span_off, uint32_t* out_docs, float* out_vals, uint32_t* task_min);
 void launch_scan_union(hipStream_t st, bool with_or, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
