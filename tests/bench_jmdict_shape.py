@@ -88,8 +88,18 @@ def main():
     from veloci_amd import mini_indexer
     n = int(os.environ.get("DOCS", "166600")); lev = int(os.environ.get("LEV", "0")); batch = int(os.environ.get("BATCH", "256"))
     t0 = time.time()
-    docs, terms = corpus(n)
-    data, info = mini_indexer.build_index(docs, INDICES)
+    cache = os.environ.get("JM_CACHE")  # (parameter sweeps: build the corpus once per box)
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as f:
+            data, terms = pickle.load(f)
+    else:
+        docs, terms = corpus(n)
+        data, info = mini_indexer.build_index(docs, INDICES)
+        if cache:
+            import pickle
+            with open(cache, "wb") as f:
+                pickle.dump((data, terms), f, protocol=4)
     print(f"corpus of {n} entries generated and indexed in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     idx = veloci_amd.Index(data, device=0)
     reqs_json = [jmdict_request(terms[i % len(terms)], lev) for i in range(batch)]
@@ -102,6 +112,14 @@ def main():
     for _ in range(steps):
         veloci_amd.search_batch(reqs, idx)
     dt = time.perf_counter() - t0
+    if os.environ.get("KERNELS") == "1":  # per-kernel device time of one more pass (event brackets on)
+        idx.profile_enable(True)
+        idx.profile_json(reset=True)
+        for _ in range(steps):
+            veloci_amd.search_batch(reqs, idx)
+        prof = idx.profile_json(reset=True)
+        idx.profile_enable(False)
+        print(json.dumps({"per_step": steps, "kernels": prof}), file=sys.stderr, flush=True)
     lat = []
     for i in range(200):
         a = time.perf_counter()

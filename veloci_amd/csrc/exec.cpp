@@ -1076,6 +1076,22 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 if (cq.status == 0) cq.n_spans = uint32_t(std::max<uint64_t>(cq.n_spans, std::min<uint64_t>(uint64_t(cq.n_spans) * f, cq.max_spans)));
             }
         }
+        // Requests of very different weight in one launch (a prefix leaf over a third of the documents beside exact matches of a few): the launch
+        // ends with the longest span, so a request gets spans in proportion to its postings — as many as keep every span of the launch near
+        // total / target postings, but no span below 4096 (bench_jmdict shape, 256 requests: k_tile_scan 4.1 -> 0.8 ms)
+        static const bool weighted = std::getenv("VQ_NO_WEIGHTED_SPANS") == nullptr;
+        uint64_t total_postings = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (pb->queries[i].status == 0) total_postings += pb->queries[i].total_len;
+        if (weighted && n > 1 && total_postings) {
+            const uint64_t per_span = std::max<uint64_t>(total_postings / target, 4096);
+            for (size_t i = 0; i < n; ++i) {
+                CompiledQuery& cq = pb->queries[i];
+                if (cq.status != 0) continue;
+                const uint64_t want = std::min<uint64_t>((cq.total_len + per_span - 1) / per_span, cq.max_spans);
+                cq.n_spans = uint32_t(std::max<uint64_t>(cq.n_spans, want));
+            }
+        }
     }
     for (size_t i = 0; i < n; ++i) {
         CompiledQuery& cq = pb->queries[i];
