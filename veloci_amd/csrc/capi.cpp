@@ -614,9 +614,19 @@ static int run_batch(const vq_index* index, const vq_request* const* requests, s
             errs[i] = std::move(e2[i - b]);
         }
     };
-    // (cutting a batch with pre-passes in two and running the halves on two host threads — what the flat entry point does — was measured on
-    // the bench_jmdict request: 14.6 k instead of 16.2 k requests/s; its host side computes (1:n boost lists, shared per batch) rather than waits)
-    run_range(0, n);
+    // A batch with pre-passes waits for the device several times before its scan starts (dictionary scans, unions, range counts): cut in
+    // two and run on two host threads, one half computes while the other waits (VQ_BATCH_HALVES=0: one piece)
+    static const bool halves = !(std::getenv("VQ_BATCH_HALVES") && std::atoi(std::getenv("VQ_BATCH_HALVES")) == 0);
+    if (halves && n >= 128 && kWorkspaces >= 2 && batch_has_prepasses(reqs)) {
+        auto other = std::async(std::launch::async, run_range, n / 2, n);
+        try {
+            run_range(0, n / 2);
+        } catch (...) {
+            other.wait();
+            throw;
+        }
+        other.get();
+    } else run_range(0, n);
     for (size_t i = 0; i < n; ++i) {
         out[i] = nullptr;
         if (status) status[i] = st[i];
