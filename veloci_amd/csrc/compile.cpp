@@ -1999,7 +1999,6 @@ struct Compiler {
                 if (!kv.facet_csr) unsupported("facet source " + store_path + " is not staged as an anchor-keyed CSR");
                 auto dit = idx.dict.find(steps.back());
                 if (dit == idx.dict.end()) throw VelociError(ERR_FST_NOT_FOUND, "fst not found loaded in indices " + steps.back() + " ");
-                if (fr.top && *fr.top > size_t(kMaxTopK)) unsupported("facet top > " + std::to_string(kMaxTopK));
                 DFacet f{};
                 f.offsets = kv.csr_off.as<uint64_t>();
                 f.values = kv.csr_values.as<uint32_t>();
@@ -2009,13 +2008,15 @@ struct Compiler {
                 // value ids beyond the dictionary (texts longer than do_not_store_text_longer_than) are counted too and render as ""
                 f.num_values = std::max<uint32_t>(uint32_t(dit->second.terms.size()), kv.csr_num_keys ? kv.csr_max_value + 1 : 0);
                 // top: null reports every value that was counted (facet.rs:19-23 truncates only with Some(top))
-                if (!fr.top && f.num_values > uint32_t(kMaxTopK)) unsupported("facet with top: null over more than " + std::to_string(kMaxTopK) + " distinct values");
-                f.top = fr.top ? uint32_t(*fr.top) : f.num_values;
+                const uint64_t want = fr.top ? std::min<uint64_t>(*fr.top, f.num_values) : f.num_values;
+                // k_facet_select ranks up to kMaxTopK entries per facet; beyond that the histogram itself goes to the host (finish_batch)
+                f.top = want > uint64_t(kMaxTopK) ? 0u : uint32_t(want);
                 cq.facets.push_back(f);
                 FacetOut fo;
                 fo.field = fr.field;
                 fo.dict_path = steps.back();
                 fo.top = f.top;
+                fo.host_top = want > uint64_t(kMaxTopK) ? uint32_t(want) : 0u;
                 fo.num_values = f.num_values;
                 cq.facet_out.push_back(fo);
                 cq.algorithmic_bytes += 4ull * f.num_values;

@@ -482,6 +482,7 @@ struct FacetOut {
     std::string dict_path;  // fst used to turn value ids into strings
     uint32_t top = 10;
     uint32_t num_values = 0;
+    uint32_t host_top = 0;  // > 0: more entries than k_facet_select ranks (kMaxTopK) — the job's histogram is downloaded and ranked on the host; `top` is 0 then
 };
 
 // ---- explain (src/search/result/explain.rs:2-21)
@@ -601,6 +602,7 @@ struct PartialBatch {
     std::vector<CompiledQuery> queries;   // status != 0: failed at compile time
     std::vector<uint32_t> slot;           // slot[i]: position of request i among the device queries, or UINT32_MAX
     std::vector<uint8_t> qclass;          // profiling: KernelId of the scan that serves device query q
+    std::vector<FacetJob> facet_jobs;     // host copy of the facet jobs (histogram offsets of the ones ranked on the host)
     uint32_t nq_dev = 0;
     PartialLayout layout{};
     // device addresses inside the workspace

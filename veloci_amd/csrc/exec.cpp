@@ -1126,6 +1126,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     pb->total_spans = uint32_t(total_spans);
     pb->n_facet_jobs = uint32_t(jobs.size());
     pb->total_facet_out = fac_out_total;
+    pb->facet_jobs = jobs;
 
     PartialLayout& lay = pb->layout;
     lay.nq = nq;
@@ -1828,6 +1829,22 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
             for (uint32_t k = 0; k < fn && k < fo.top; ++k) {
                 std::string text = (dit != idx.dict.end() && fv[k] < dit->second.terms.size()) ? dit->second.terms[fv[k]] : std::string();
                 rf.entries.push_back({std::move(text), uint64_t(fc[k])});
+            }
+            if (fo.host_top) {  // more entries than the device ranks: the job's counts (summed over the shards in place), ranked here — count descending,
+                                // value id ascending like k_facet_select (the reference's sort is unstable, facet.rs:19-23)
+                const FacetJob& fj = pb.facet_jobs[job];
+                std::vector<uint32_t> counts(fj.num_values);
+                VQ_HIP(hipMemcpyAsync(counts.data(), pb.d_partial + lay.off_hist + size_t(fj.hist_off) * 4, size_t(fj.num_values) * 4, hipMemcpyDeviceToHost, st));
+                VQ_HIP(hipStreamSynchronize(st));
+                std::vector<uint32_t> order;
+                for (uint32_t v = 0; v < fj.num_values; ++v)
+                    if (counts[v]) order.push_back(v);
+                const size_t keep = std::min<size_t>(order.size(), fo.host_top);
+                std::partial_sort(order.begin(), order.begin() + keep, order.end(), [&](uint32_t x, uint32_t y) { return counts[x] != counts[y] ? counts[x] > counts[y] : x < y; });
+                for (size_t k = 0; k < keep; ++k) {
+                    std::string text = (dit != idx.dict.end() && order[k] < dit->second.terms.size()) ? dit->second.terms[order[k]] : std::string();
+                    rf.entries.push_back({std::move(text), uint64_t(counts[order[k]])});
+                }
             }
             r->facets.push_back(std::move(rf));
         }

@@ -1327,6 +1327,10 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
     __shared__ unsigned long long cand[kCandCap];
     __shared__ uint32_t misc[4];
     const FacetJob job = jobs[blockIdx.x];
+    if (job.top == 0u) {  // more entries wanted than the candidate buffer ranks: the host selects from the histogram itself (finish_batch)
+        if (threadIdx.x == 0) out_n[blockIdx.x] = 0u;
+        return;
+    }
     CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
     if (threadIdx.x == 0) {
         *cs.thr = 0ull;
