@@ -261,6 +261,13 @@ void* vq_partial_hist_device_ptr(vq_partial_batch*);
  * each `vq_partial_bytes` long) into final results; facet counts are read from `local`'s (already summed) histograms. */
 int vq_merge_partials(const vq_index*, vq_partial_batch* local, const void* gathered_device,
                       uint32_t num_shards, vq_result** out, int* status);
+/* One scan ranks the best 1024 hits of a request.  A request whose top + skip reaches further (the reference has no limit: src/search/sort.rs:5-22,
+ * src/search.rs:230-239) comes back from vq_merge_partials as its PAGE 0 — all 1024 ranked hits, top / skip not applied yet — with
+ * vq_result_is_page() == 1.  The caller (every rank alike: the merged page is the same on all of them) sends vq_request_page_after(request, score and
+ * id of the page's last hit) through partial -> all-gather -> merge again, appends the hits, and repeats while a page comes back full; then it
+ * applies skip / top (apply_top_skip).  vq_search / vq_search_batch do this themselves on an unsharded index; the flat merges decline such requests. */
+int vq_result_is_page(const vq_result*);
+int vq_request_page_after(const vq_request*, float score, uint32_t id, vq_request** out);
 /* Same merge with flat output (see vq_search_batch_flat). */
 int vq_merge_partials_flat(const vq_index*, vq_partial_batch* local, const void* gathered_device, uint32_t num_shards, size_t stride,
                            uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status);

@@ -1031,7 +1031,7 @@ def test_degenerate_inputs(corpus):
 def test_deep_paging_beyond_one_scan(big_corpus):
     """top + skip above what one scan ranks (1024): the request runs as a chain of pages, each scan ranking only what lies below
     the previous page's last key; window, num_hits and facets equal the oracle's.  Through vq_search, vq_search_batch and the
-    flat entry point; the sharded merge path declines."""
+    flat entry point, and over doc-range shards, where the merge's caller pages."""
     import veloci_amd
     from veloci_amd import synth
     from parity import assert_same
@@ -1063,8 +1063,19 @@ def test_deep_paging_beyond_one_scan(big_corpus):
     with pytest.raises(veloci_amd.VelociError) as e:
         veloci_amd.search(dict(synth.req_or(a), top=10, skip=70000), idx)
     assert e.value.kind == "Unsupported" and "ranked hits" in str(e.value)
-    got = _search_batch_over_shards(data, [dict(synth.req_and(a), top=1500), synth.req_and(a)], 2)
-    assert isinstance(got[0], veloci_amd.VelociError) and got[0].kind == "Unsupported" and not isinstance(got[1], Exception)
+    # over doc-range shards the caller of the merge pages (vq_result_is_page / vq_request_page_after): every page is one more exchange round
+    sharded = reqs[:12] + reqs[-3:] + [synth.req_and(a), dict(synth.req_or(a), top=10, skip=70000)]
+    got = _search_batch_over_shards(data, sharded, 2)
+    for r, g in zip(sharded[:-1], got[:-1]):
+        assert not isinstance(g, Exception), (str(g), json.dumps(r))
+        assert_same(r, g, ora.search_json(json.dumps(r)))
+    assert isinstance(got[-1], veloci_amd.VelociError) and got[-1].kind == "Unsupported" and "ranked hits" in str(got[-1])
+    from veloci_amd.dist import search_shards_local
+    N = data.num_anchors
+    parts = [veloci_amd.Index(data, device=0, doc_lo=0, doc_hi=N // 4), veloci_amd.Index(data, device=0, doc_lo=N // 4, doc_hi=N)]
+    plain = [r for r in reqs if "phrase_boosts" not in r and "text_locality" not in r][:8]
+    for r, g in zip(plain, search_shards_local(parts, plain)):
+        assert_same(r, g, ora.search_json(json.dumps(r)))
 
 
 def test_wide_nodes_up_to_16_operands(corpus):
@@ -1199,29 +1210,38 @@ def _search_batch_over_shards(data, reqs, shards):
             barrier.wait()
         return hook
 
-    pbs = [None] * shards
-    errs = []
-
-    def run(rank):
-        try:
-            parts[rank].set_allreduce(make_hook(rank))
-            pbs[rank] = veloci_amd.PartialBatch(parts[rank], reqs)
-        except Exception as ex:  # noqa: BLE001
-            errs.append(repr(ex))
-            barrier.abort()
-
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(shards)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    assert not errs, errs
-    assert len({pb.nbytes for pb in pbs}) == 1
     from veloci_amd.dist import exchange_local
-    g = exchange_local(pbs)
-    got = pbs[0].merge(g.data_ptr(), shards, raise_on_error=False)
-    for pb in pbs[1:]:
-        pb.merge(None, 1, raise_on_error=False)
+    from veloci_amd.search import complete_deep_pages, _as_request
+
+    def one_round(round_reqs):
+        pbs = [None] * shards
+        errs = []
+
+        def run(rank):
+            try:
+                parts[rank].set_allreduce(make_hook(rank))
+                pbs[rank] = veloci_amd.PartialBatch(parts[rank], round_reqs)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(shards)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        assert len({pb.nbytes for pb in pbs}) == 1
+        g = exchange_local(pbs)
+        res = pbs[0].merge(g.data_ptr(), shards, raise_on_error=False)
+        for pb in pbs[1:]:
+            pb.merge(None, 1, raise_on_error=False)
+        return res
+
+    parsed = [_as_request(r) for r in reqs]
+    got = one_round(parsed)
+    if any(getattr(g, "is_page", False) for g in got):  # requests reaching beyond one scan's ranking: further rounds over all shards
+        got = complete_deep_pages(parsed, got, one_round)
     return got
 
 
@@ -1276,8 +1296,6 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
     declined = 0
     for req, g in zip(reqs, got):
         if shards > 1 and isinstance(g, veloci_amd.VelociError) and g.kind == "Unsupported":
-            if req.get("top", 10) + req.get("skip", 0) > 1024:
-                continue  # deep paging is declined on the sharded merge path
             declined += 1
             continue
         assert not isinstance(g, Exception), (str(g), json.dumps(req))
@@ -1312,6 +1330,12 @@ def test_rccl_collective_path_with_one_rank(corpus):
             a = t[i % len(t)]
             reqs.append([synth.req_and(a), synth.req_or(a, top=25), synth.req_single(a[i % 3], top=3),
                          dict(synth.req_and(a[:2]), facets=[{"field": "cat", "top": 5}])][i % 4])
+        # paged over further collectives; > 1024 facet entries ranked on the host from the all-reduced histogram
+        deep = [dict(synth.req_or(t[0]), top=1500, skip=700), dict(synth.req_single(meta.extra_probes[1]), top=10, skip=2500, facets=[{"field": "tags[]", "top": None}])]
+        for g, w in zip(searcher.search_batch(reqs[:5] + deep)[5:], veloci_amd.search_batch(deep, idx)):
+            assert g.num_hits == w.num_hits and list(g.ids) == list(w.ids) and len(g.ids) > 0
+            assert np.array_equal(np.asarray(g.scores, np.float32).view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
+            assert sorted(map(repr, (g.facets or {}).items())) == sorted(map(repr, (w.facets or {}).items()))
         want = veloci_amd.search_batch(reqs, idx)
         for _ in range(3):  # several batches back to back on the side stream
             got = searcher.search_batch(reqs)

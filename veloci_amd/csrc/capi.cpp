@@ -459,9 +459,20 @@ int vq_debug_compile(const vq_index* index, const vq_request* request) {
     return rc != 0 ? rc : status;
 }
 void vq_request_free(vq_request* r) { delete r; }
+// The continuation of `request` behind the ranked hit (score, id): what a caller of the sharded partial / merge path sends for the next page of a
+// request whose top + skip reaches beyond one scan's ranking (vq_result_is_page).
+int vq_request_page_after(const vq_request* request, float score, uint32_t id, vq_request** out) {
+    return guard([&] {
+        if (!request || !out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_request_page_after: null argument");
+        auto* r = new vq_request();
+        r->req = vq::page_request_after(request->req, score, id);
+        *out = r;
+    });
+}
 
 // ------------------------------------------------------------------ results
 uint64_t vq_result_num_hits(const vq_result* r) { return r->r.num_hits; }
+int vq_result_is_page(const vq_result* r) { return r->r.deep ? 1 : 0; }
 uint64_t vq_result_execution_time_ns(const vq_result* r) { return r->r.execution_time_ns; }
 size_t vq_result_len(const vq_result* r) { return r->r.ids.size(); }
 const uint32_t* vq_result_ids(const vq_result* r) { return r->r.ids.data(); }
@@ -822,7 +833,7 @@ void* vq_partial_device_ptr(vq_partial_batch* p) { return p ? p->pb->d_partial :
 size_t vq_partial_hist_bytes(const vq_partial_batch* p) { return p ? size_t(p->pb->layout.total_hist) * 4 : 0; }
 void* vq_partial_hist_device_ptr(vq_partial_batch* p) { return p && p->pb->d_partial ? p->pb->d_partial + p->pb->layout.off_hist : nullptr; }
 
-// the sharded path ranks top + skip <= kMaxTopK per request: paging a deep request would need the merged result of every page on all ranks
+// the flat merges rank top + skip <= kMaxTopK per request (vq_merge_partials hands page 0 back instead: vq_result_is_page / vq_request_page_after)
 static void decline_deep(std::vector<std::unique_ptr<Result>>& results, std::vector<int>& st, std::vector<std::string>& errs) {
     for (size_t i = 0; i < results.size(); ++i)
         if (st[i] == 0 && results[i] && results[i]->deep) {
@@ -839,7 +850,7 @@ int vq_merge_partials(const vq_index* index, vq_partial_batch* local, const void
         std::vector<int> st;
         std::vector<std::string> errs;
         finish_batch(*index->idx, *local->pb, gathered_device, num_shards, results, st, errs);
-        decline_deep(results, st, errs);
+        // (a request that reaches beyond one scan's ranking comes back as its page 0, vq_result_is_page: the caller pages on, on all shards)
         decline_explain(results, st, errs, "the sharded partial / merge path");
         for (size_t i = 0; i < results.size(); ++i) {
             out[i] = nullptr;

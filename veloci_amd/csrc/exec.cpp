@@ -1447,6 +1447,18 @@ std::vector<SuggestEntry> run_highlight(const Index& idx, vqreq::RequestSearchPa
     return out;
 }
 
+// The continuation of a request behind the ranked hit (score, id): the next kMaxTopK hits below that key, no facets (page 0 counted them)
+vqreq::Request page_request_after(const vqreq::Request& R, float score, uint32_t id) {
+    vqreq::Request page = R;
+    page.top = size_t(kMaxTopK);
+    page.skip = 0;
+    page.facets.reset();
+    uint32_t bits;
+    std::memcpy(&bits, &score, 4);
+    page.key_upper = (uint64_t(order_f32(bits)) << 32) | id;
+    return page;
+}
+
 void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
                             std::vector<int>& status, std::vector<std::string>& errors) {
     constexpr uint64_t kMaxDeep = 65536;  // ranked hits one request may reach (64 scans)

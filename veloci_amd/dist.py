@@ -220,12 +220,27 @@ class ShardedSearcher:
         return True
 
     def search_batch(self, requests):
-        from .search import PartialBatch
+        """Result objects of a batch over all shards.  A request whose top + skip reaches beyond one scan's ranking (1024 hits) is paged:
+        its merged page 0 is the same on every rank, so every rank sends the same continuation requests through further rounds."""
+        from .search import complete_deep_pages, _as_request
+
+        def one_round(reqs):
+            pb = self._partial(reqs)
+            if not self.collective:
+                return pb.merge(None, 1, raise_on_error=False)
+            gathered = self._gather(pb)
+            return pb.merge(gathered.data_ptr(), self.world, raise_on_error=False)
+
+        requests = [_as_request(r) for r in requests]
         pb = self._partial(requests)
-        if not self.collective:
-            return pb.merge(None, 1)
-        gathered = self._gather(pb)
-        return pb.merge(gathered.data_ptr(), self.world)
+        results = pb.merge(None, 1) if not self.collective else pb.merge(self._gather(pb).data_ptr(), self.world)
+        if any(getattr(r, "is_page", False) for r in results):
+            results = complete_deep_pages(requests, results, one_round)
+            for r in results:
+                if isinstance(r, Exception):
+                    raise r
+        return results
+
 
     def search_batch_flat(self, requests, stride=10, chunks=None):
         """Flat-output variant (see veloci_amd.search_batch_flat): no per-result Python objects.  A large batch runs as
@@ -268,3 +283,26 @@ class ShardedSearcher:
         while inflight:
             finish(*inflight.pop(0))
         return out
+
+
+def search_shards_local(shards, requests):
+    """Every doc-range shard in THIS process (tests, single-GPU rehearsals): partial per shard -> exchange_local -> merge, deep requests paged
+    like ShardedSearcher.search_batch pages them."""
+    from .search import PartialBatch, complete_deep_pages, _as_request
+
+    def one_round(reqs, raise_on_error=False):
+        pbs = [PartialBatch(s, reqs) for s in shards]
+        g = exchange_local(pbs)
+        res = pbs[0].merge(g.data_ptr(), len(shards), raise_on_error=raise_on_error)
+        for pb in pbs[1:]:
+            pb.merge(None, 1, raise_on_error=False)  # releases the shard's workspace
+        return res
+
+    requests = [_as_request(r) for r in requests]
+    results = one_round(requests, raise_on_error=True)
+    if any(getattr(r, "is_page", False) for r in results):
+        results = complete_deep_pages(requests, results, one_round)
+        for r in results:
+            if isinstance(r, Exception):
+                raise r
+    return results

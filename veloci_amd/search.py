@@ -33,6 +33,7 @@ class SearchResult:
         self.scores = scores        # np.float32
         self.facets = facets        # None or {field: [(value, count)]}
         self.execution_time_ns = int(execution_time_ns)
+        self.is_page = False
 
     @property
     def data(self):
@@ -60,6 +61,65 @@ class Request:
             self.L.vq_request_free(self.h)
             self.h = None
 
+    def page_after(self, score, doc_id):
+        """The continuation of this request behind the ranked hit (score, doc_id) — `vq_request_page_after`."""
+        h = C.c_void_p()
+        _lib.check(self.L.vq_request_page_after(self.h, C.c_float(float(score)), int(doc_id), C.byref(h)))
+        page = Request.__new__(Request)
+        page.L, page.h = self.L, h
+        return page
+
+    def top_skip(self):
+        """(top, skip) as parsed (top: 10 when absent, search.rs:146)."""
+        d = json.loads(self.L.vq_request_to_json(self.h).decode())
+        return (10 if d.get("top") is None else int(d["top"])), int(d.get("skip") or 0)
+
+
+def complete_deep_pages(requests, results, run_page):
+    """Requests whose top + skip reaches beyond one scan's ranking come back from the sharded merge as their page 0 (`res.is_page`): page on
+    — `run_page(list of Request) -> list of SearchResult` is one more partial -> exchange -> merge round over all shards — and apply skip / top
+    (search.rs:230-239).  The host loop of `complete_deep_requests` (exec.cpp) for callers that own the exchange."""
+    max_deep, page_len = 65536, 1024
+    state = {}
+    for i, res in enumerate(results):
+        if isinstance(res, SearchResult) and res.is_page:
+            req = _as_request(requests[i])
+            top, skip = req.top_skip()
+            want = top + skip
+            res.is_page = False
+            ids, scores = res.ids, res.scores
+            if skip >= res.num_hits:
+                res.ids, res.scores = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+                continue
+            reach = min(want, res.num_hits)
+            if reach > max_deep:
+                results[i] = VelociError(4, f"unsupported on the MI355X query path: top + skip reaches more than {max_deep} ranked hits")
+                continue
+            state[i] = [req, [ids], [scores], len(ids), reach, want, skip]
+    pending = sorted(i for i, s in state.items() if s[3] < s[4] and s[3] % page_len == 0 and s[3] > 0)
+    while pending:
+        pages = [state[i][0].page_after(state[i][2][-1][-1], state[i][1][-1][-1]) for i in pending]
+        got = run_page(pages)
+        nxt = []
+        for i, g in zip(pending, got):
+            s = state[i]
+            if isinstance(g, VelociError):
+                results[i] = g
+                state.pop(i)
+                continue
+            if len(g.ids) == 0:
+                continue
+            s[1].append(g.ids)
+            s[2].append(g.scores)
+            s[3] += len(g.ids)
+            if s[3] < s[4] and s[3] % page_len == 0:
+                nxt.append(i)
+        pending = nxt
+    for i, s in state.items():
+        ids, scores = np.concatenate(s[1]), np.concatenate(s[2])
+        results[i].ids, results[i].scores = ids[s[6]:s[5]], scores[s[6]:s[5]]
+    return results
+
 
 def _take_result(L, h):
     try:
@@ -75,6 +135,7 @@ def _take_result(L, h):
                 facets[L.vq_result_facet_field(h, f).decode()] = [(L.vq_result_facet_value(h, f, i).decode(), int(L.vq_result_facet_count(h, f, i)))
                                                                    for i in range(fl)]
         res = SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
+        res.is_page = bool(L.vq_result_is_page(h))  # page 0 of a request that reaches beyond one scan's ranking (sharded merge only)
         res.why_found_terms = json.loads(L.vq_result_why_found_terms_json(h).decode())
         res.explain_json = L.vq_result_explain_json(h).decode()  # per hit: null or its Explain records (src/search.rs:86,96); "null" without `explain`
         res.explain = json.loads(res.explain_json)
