@@ -216,6 +216,16 @@ void vq_suggest_free(vq_suggest_result*);
  * vq_suggest_score, vq_suggest_term_id = the text id.  Where the reference panics (a hit without a snippet: an untokenised field, "snippet" not
  * set) the call returns VQ_ERR_INVALID_REQUEST.  Needs the field's tokens_to_text_id and text_id_to_token_ids stores. */
 int vq_highlight_json(const vq_index*, const char* json, size_t len, vq_suggest_result** out);
+/* == highlight_field::highlight_text(text, set, opt, tokenizer) (src/highlight_field.rs:92-146): `text` with the tokens that are in `terms` wrapped in
+ * the snippet tags, cut into windows like vq_highlight_json's snippets — what why_found highlighting (highlight_on_original_document, :148-185) applies to
+ * every text of a returned document with the field's terms from vq_result_why_found_terms_json.  `tokenized` = the field has a tokenizer (the default
+ * separators of src/tokenizer/mod.rs:21-23); `snippet_info_json` may be NULL (DEFAULT_SNIPPETINFO); term_lens may be NULL (C strings).  Returns the
+ * snippet's byte length — the bytes are in `out` when the length fits `cap`, otherwise call again with a larger buffer —, VQ_HIGHLIGHT_NONE when
+ * nothing is highlighted (the reference's None), VQ_HIGHLIGHT_ERROR on an error (vq_last_error).  Host work; needs no index. */
+#define VQ_HIGHLIGHT_NONE ((size_t)-1)
+#define VQ_HIGHLIGHT_ERROR ((size_t)-2)
+size_t vq_highlight_text(const char* text, size_t len, const char* const* terms, const size_t* term_lens, size_t n_terms, const char* snippet_info_json,
+                         size_t json_len, int tokenized, char* out, size_t cap);
 
 /* ----------------------------------------------------------------- search */
 

@@ -58,6 +58,9 @@ def lib():
         L.vo_result_explain_json.argtypes = [C.c_void_p]
         L.vo_suggest_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.vo_highlight_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.vo_highlight_text.restype = C.c_void_p
+        L.vo_highlight_text.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+        L.vo_string_free.argtypes = [C.c_void_p]
         L.vo_suggest_len.restype = C.c_size_t
         L.vo_suggest_len.argtypes = [C.c_void_p]
         L.vo_suggest_text.restype = C.c_char_p
@@ -92,6 +95,24 @@ class OracleResult:
         self.scores = scores
         self.facets = facets  # list of (field, [(value, count)])
         self.execution_time_ns = execution_time_ns
+
+
+def highlight_text(text, terms, snippet_info=None, tokenized=True):
+    """highlight_field::highlight_text (highlight_field.rs:92-146) -> the snippet or None"""
+    import json
+    L = lib()
+    raw, tj = text.encode(), json.dumps(list(terms)).encode()
+    si = json.dumps(snippet_info).encode() if snippet_info is not None else b""
+    none = C.c_int(0)
+    p = L.vo_highlight_text(raw, len(raw), tj, len(tj), si, len(si), int(tokenized), C.byref(none))
+    if not p:
+        if none.value:
+            return None
+        raise OracleError(1, L.vo_last_error().decode())
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.vo_string_free(p)
 
 
 class OracleIndex:

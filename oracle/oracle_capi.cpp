@@ -3,6 +3,8 @@
 // oracle and the HIP library from the same arrays.
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 
 #include "veloci_oracle.hpp"
@@ -183,6 +185,34 @@ int vo_highlight_json(const void* index, const char* json, size_t len, void** ou
         return fail(VelociError(ERR_JSON, std::string("JsonError: ") + e.what()));
     }
 }
+// highlight_text (highlight_field.rs:92-146): terms as a JSON array of strings, snippet_info as JSON or empty.  Returns a malloc'ed C string (vo_string_free),
+// NULL with *none = 1 when nothing is highlighted, NULL with *none = 0 on an error (vo_last_error)
+char* vo_highlight_text(const char* text, size_t len, const char* terms_json, size_t terms_len, const char* snippet_info_json, size_t si_len, int tokenized, int* none) {
+    *none = 0;
+    try {
+        std::set<std::string> set;
+        vqjson::Value tv = vqjson::parse(terms_json, terms_len);
+        for (auto& e : tv.arr) set.insert(e.str);
+        SnippetInfo opt;
+        if (si_len) opt = snippet_info_from_json(vqjson::parse(snippet_info_json, si_len));
+        auto r = highlight_text(std::string(text, len), set, opt, tokenized != 0);
+        if (!r) {
+            *none = 1;
+            return nullptr;
+        }
+        char* out = static_cast<char*>(std::malloc(r->size() + 1));
+        std::memcpy(out, r->data(), r->size());
+        out[r->size()] = 0;
+        return out;
+    } catch (const VelociError& e) {
+        fail(e);
+        return nullptr;
+    } catch (const vqjson::ParseError& e) {
+        fail(VelociError(ERR_JSON, std::string("JsonError: ") + e.what()));
+        return nullptr;
+    }
+}
+void vo_string_free(char* s) { std::free(s); }
 size_t vo_suggest_len(const void* s) { return static_cast<const SuggestBox*>(s)->e.size(); }
 const char* vo_suggest_text(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].text.c_str(); }
 float vo_suggest_score(const void* s, size_t i) { return static_cast<const SuggestBox*>(s)->e[i].score; }

@@ -1460,6 +1460,70 @@ std::optional<std::string> highlight_document(const Index& index, const std::str
 }
 }  // namespace
 
+// SimpleTokenizerGroupTokenIter (tokenizer/simple_tokenizer_group.rs:51-82) over DEFAULT_SEPERATORS (tokenizer/mod.rs:21-23): (token, is_separator)
+static std::vector<std::pair<std::string, bool>> tokenize_group(const std::string& original) {
+    static const uint32_t seps[] = {' ', '\t', '\n', '\r', ':', '(', ')', ',', '.', 0x2026, ';', 0x30FB, 0x2019, 0x2014, '-', '\\', '[', ']', '{', '}', '<', '>', '\'', '"', 0x201C, 0x2122};
+    std::vector<std::pair<std::string, bool>> out;
+    size_t last_returned_byte = 0;
+    bool last_was_token = false;  // (the reference's name: true while inside a separator run)
+    const std::vector<uint32_t> cps = vqtext::decode_utf8(original);
+    size_t char_byte_pos = 0;
+    for (uint32_t c : cps) {
+        const bool is_sep = std::find(std::begin(seps), std::end(seps), c) != std::end(seps);
+        if (is_sep) {
+            if (char_byte_pos == 0) last_was_token = true;
+            else if (!last_was_token) {
+                out.push_back({original.substr(last_returned_byte, char_byte_pos - last_returned_byte), false});
+                last_was_token = true;
+                last_returned_byte = char_byte_pos;
+            }
+        } else if (last_was_token) {
+            out.push_back({original.substr(last_returned_byte, char_byte_pos - last_returned_byte), true});
+            last_was_token = false;
+            last_returned_byte = char_byte_pos;
+        }
+        char_byte_pos += c < 0x80 ? 1 : c < 0x800 ? 2 : c < 0x10000 ? 3 : 4;
+    }
+    if (last_returned_byte != original.size()) out.push_back({original.substr(last_returned_byte), last_was_token});
+    return out;
+}
+
+// highlight_field.rs:92-146
+std::optional<std::string> highlight_text(const std::string& text, const std::set<std::string>& set, const SnippetInfo& opt, bool has_tokenizer) {
+    if (opt.num_words_around_snippet < 0 || opt.num_words_around_snippet > 0x3FFFFFFF)
+        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"snippet_info.num_words_around_snippet out of range\" ");
+    bool contains_any_token = false;
+    if (set.size() == 1 && set.count(text)) return opt.snippet_start_tag + text + opt.snippet_end_tag;  // :96-98
+    if (!has_tokenizer) return std::nullopt;                                                             // :99
+    std::vector<std::string> tokens;
+    std::vector<size_t> hit_pos_of_tokens_in_doc;
+    for (auto& t : tokenize_group(text)) {
+        if (set.count(t.first)) hit_pos_of_tokens_in_doc.push_back(tokens.size());
+        tokens.push_back(t.first);
+    }
+    const int64_t token_around_snippets = opt.num_words_around_snippet * 2;
+    const auto grouped = group_hit_positions_for_snippet(hit_pos_of_tokens_in_doc, opt);
+    std::string snippet;
+    size_t taken = 0;
+    for (auto& g : grouped) {  // build_snippet :45-71
+        if (taken == opt.max_snippets) break;
+        if (taken++) snippet += opt.snippet_connector;
+        const auto window = grouped_to_positions_for_snippet(g, tokens.size(), token_around_snippets);
+        for (size_t i = window.first; i < window.second; ++i) {
+            if (set.count(tokens[i])) {
+                contains_any_token = true;
+                snippet += opt.snippet_start_tag + tokens[i] + opt.snippet_end_tag;
+            } else snippet += tokens[i];
+        }
+    }
+    if (!hit_pos_of_tokens_in_doc.empty()) {  // ellipsis_snippet :73-90
+        if (int64_t(hit_pos_of_tokens_in_doc.front()) > token_around_snippets) snippet.insert(0, opt.snippet_connector);
+        if (int64_t(hit_pos_of_tokens_in_doc.back()) < int64_t(tokens.size()) - token_around_snippets) snippet += opt.snippet_connector;
+    }
+    if (contains_any_token) return snippet;
+    return std::nullopt;
+}
+
 // search_field::highlight (search_field.rs:233-245) = get_term_ids_in_field + resolve_token_hits_to_text_id (:550-639) with snippets +
 // get_text_score_id_from_result(false, ..) (:160-192)
 std::vector<SuggestEntry> highlight(const Index& index, RequestSearchPart part) {

@@ -162,6 +162,7 @@ struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, 
     float score;
     uint32_t term_id;
 };
+std::optional<std::string> highlight_text(const std::string& text, const std::set<std::string>& set, const SnippetInfo& opt, bool has_tokenizer);  // highlight_field.rs:92-146
 std::vector<SuggestEntry> highlight(const struct Index& index, RequestSearchPart part);  // search_field.rs:233-245, highlight_field.rs:187-272
 std::vector<SuggestEntry> suggest_multi(const struct Index& index, Request req);  // search_field.rs:194-219 (and :221-231 for a bare RequestSearchPart)
 

@@ -316,3 +316,69 @@ def test_oracle_reproduces_reference_explain_assertions_and_its_own_invariants()
     res = ora.search_json(json.dumps({"search_req": {"search": {"terms": ["will"], "path": "meanings.eng[]", "levenshtein_distance": 1}}, "explain": True}))
     for score, recs in zip(res.scores, res.explain):
         assert np.float32(max(r["TermToAnchor"]["final_score"] for r in recs if "TermToAnchor" in r)) == score
+
+
+# ---------------------------------------------------------------- highlight_text (why_found highlighting of a document's texts)
+def test_highlight_text_matches_the_reference_vectors_the_oracle_and_a_python_restatement():
+    """highlight_field::highlight_text (highlight_field.rs:92-146), host work with no index behind it: the reference's four assertions (:279-320)
+    on the oracle and on the product (`vq_highlight_text`), then product == oracle == a restatement over mini_indexer's tokenizer (itself pinned by the
+    reference's tokenizer vectors) on random texts, term sets and snippet options."""
+    import random
+    import veloci_amd
+    from oracle import binding as O
+    from veloci_amd.mini_indexer import tokenize, DEFAULT_SEPARATORS as D
+    fx = _load_suggest_regex()
+    for case in fx["highlight_text"]:
+        assert O.highlight_text(case["text"], case["terms"]) == case["expect"], case
+        assert veloci_amd.highlight_text(case["text"], case["terms"]) == case["expect"], case
+
+    def restated(text, terms, si, tokenized):
+        st, en, conn = si.get("snippet_start_tag", "<b>"), si.get("snippet_end_tag", "</b>"), si.get("snippet_connector", " ... ")
+        around, max_snippets = 2 * si.get("num_words_around_snippet", 5), si.get("max_snippets", 2**32 - 1)
+        terms = set(terms)
+        if len(terms) == 1 and text in terms:
+            return st + text + en
+        if not tokenized:
+            return None
+        toks = [t for t, _ in tokenize(text, D)]
+        hits = [i for i, t in enumerate(toks) if t in terms]
+        groups, prev = [], -around
+        for h in hits:
+            if h - prev >= around:
+                groups.append([])
+            prev = h
+            groups[-1].append(h)
+        parts = ["".join(st + toks[i] + en if toks[i] in terms else toks[i] for i in range(max(g[0] - around, 0), min(g[-1] + around + 1, len(toks)))) for g in groups[:max_snippets]]
+        out = conn.join(parts)
+        if hits and hits[0] > around:
+            out = conn + out
+        if hits and hits[-1] < len(toks) - around:
+            out += conn
+        return out if parts else None
+
+    rng = random.Random(11)
+    words = ["story", "guy", "the", "a", "Schön", "Hans", "treffer", "went", "rule", "world", "end", "died", "Prolog", "意欲", "ok"]
+    seps = [" ", ", ", ".", " - ", "\n", ": ", "(", ") ", "…", "—", "\t", "'", "™ "]
+    for _ in range(1500):
+        n = rng.randrange(0, 40)
+        text = "".join(rng.choice(words) + rng.choice(seps) for _ in range(n))
+        if rng.random() < 0.3:
+            text = rng.choice(seps) + text
+        if rng.random() < 0.3 and text:
+            text = text.rstrip(" ,.-\n:()…—\t'™")
+        terms = rng.sample(words, rng.randrange(0, 4)) + ([text] if rng.random() < 0.05 else []) + ([", "] if rng.random() < 0.05 else [])
+        si = {}
+        if rng.random() < 0.5:
+            si = {"num_words_around_snippet": rng.randrange(0, 5)}
+            if rng.random() < 0.5:
+                si["max_snippets"] = rng.randrange(0, 3)
+            if rng.random() < 0.3:
+                si.update(snippet_start_tag="[", snippet_end_tag="]", snippet_connector=" ~ ")
+        tokenized = rng.random() < 0.9
+        want = restated(text, terms, si, tokenized)
+        assert O.highlight_text(text, terms, si or None, tokenized) == want, (text, terms, si, tokenized)
+        assert veloci_amd.highlight_text(text, terms, si or None, tokenized) == want, (text, terms, si, tokenized)
+    with pytest.raises(veloci_amd.VelociError):
+        veloci_amd.highlight_text("a b", ["a"], {"num_words_around_snippet": -1})
+    with pytest.raises(veloci_amd.VelociError):
+        veloci_amd.highlight_text("a b", ["a"], {"max_snippets": "x"})

@@ -583,6 +583,33 @@ int vq_highlight_json(const vq_index* index, const char* json, size_t len, vq_su
         *out = r;
     });
 }
+// highlight_text (highlight_field.rs:92-146).  Returns the snippet's byte length (written to `out` when it fits `cap`), VQ_HIGHLIGHT_NONE when there is
+// nothing to highlight, VQ_HIGHLIGHT_ERROR on an error (vq_last_error); a length above `cap` means: call again with a larger buffer.
+size_t vq_highlight_text(const char* text, size_t len, const char* const* terms, const size_t* term_lens, size_t n_terms, const char* snippet_info_json, size_t json_len,
+                         int tokenized, char* out, size_t cap) {
+    size_t result = size_t(-2);
+    guard([&] {
+        if ((!text && len) || (!terms && n_terms) || (!out && cap)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_highlight_text: null argument");
+        vqreq::SnippetInfo opt;
+        if (snippet_info_json && json_len) {
+            try {
+                opt = vqreq::snippet_info_from_json(vqjson::parse(snippet_info_json, json_len));
+            } catch (const vqjson::ParseError& e) {
+                throw VelociError(VQ_ERR_JSON, std::string("JsonError: ") + e.what());
+            }
+        }
+        std::vector<std::string> set;
+        for (size_t i = 0; i < n_terms; ++i) set.emplace_back(terms[i] ? terms[i] : "", terms[i] ? (term_lens ? term_lens[i] : std::strlen(terms[i])) : 0);
+        const std::optional<std::string> sn = vq::highlight_text(std::string(text ? text : "", len), set, opt, tokenized != 0);
+        if (!sn) {
+            result = size_t(-1);
+            return;
+        }
+        if (sn->size() <= cap) std::memcpy(out, sn->data(), sn->size());
+        result = sn->size();
+    });
+    return result;
+}
 size_t vq_suggest_len(const vq_suggest_result* r) { return r->e.size(); }
 const char* vq_suggest_text(const vq_suggest_result* r, size_t i) { return r->e[i].text.c_str(); }
 float vq_suggest_score(const vq_suggest_result* r, size_t i) { return r->e[i].score; }

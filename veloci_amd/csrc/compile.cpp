@@ -2236,13 +2236,10 @@ std::vector<SuggestEntry> suggest_part(const Index& idx, const RequestSearchPart
 // normalised; the dictionary scan of a fuzzy / prefix part has run on the device (`fuzzy`).  Host work over the host copies of
 // tokens_to_text_id / text_id_to_token_ids: one text at a time, a few dozen tokens each.
 namespace {
-std::string snippet_of_text(const Dictionary& dict, const uint32_t* toks, size_t n, const std::vector<uint32_t>& wanted_sorted, const vqreq::SnippetInfo& opt, bool* any) {
+// the snippet of n tokens: is_hit(i) marks the tokens to tag, append(out, i) writes token i's text
+template <class IsHit, class Append>
+std::string snippet_of_tokens(size_t n, IsHit is_hit, Append append_text, const vqreq::SnippetInfo& opt, bool* any) {
     const int64_t around = opt.num_words_around_snippet * 2;  // token separator token separator
-    auto is_hit = [&](size_t i) { return std::binary_search(wanted_sorted.begin(), wanted_sorted.end(), toks[i]); };
-    auto text_of = [&](size_t i) -> const std::string& {
-        static const std::string empty;
-        return toks[i] < dict.terms.size() ? dict.terms[toks[i]] : empty;
-    };
     // one walk: hits closer than `around` tokens share a window (group_hit_positions_for_snippet :19-37); a window reaches `around` tokens
     // to both sides of its hits (grouped_to_positions_for_snippet :39-43)
     std::string out;
@@ -2256,9 +2253,9 @@ std::string snippet_of_text(const Dictionary& dict, const uint32_t* toks, size_t
             for (size_t i = lo; i < hi; ++i) {
                 if (is_hit(i)) {
                     out += opt.snippet_start_tag;
-                    out += text_of(i);
+                    append_text(out, i);
                     out += opt.snippet_end_tag;
-                } else out += text_of(i);
+                } else append_text(out, i);
             }
         }
         ++windows;
@@ -2279,13 +2276,44 @@ std::string snippet_of_text(const Dictionary& dict, const uint32_t* toks, size_t
     if (last_hit < int64_t(n) - around) out += opt.snippet_connector;
     return out;
 }
+std::string snippet_of_text(const Dictionary& dict, const uint32_t* toks, size_t n, const std::vector<uint32_t>& wanted_sorted, const vqreq::SnippetInfo& opt, bool* any) {
+    return snippet_of_tokens(
+        n, [&](size_t i) { return std::binary_search(wanted_sorted.begin(), wanted_sorted.end(), toks[i]); },
+        [&](std::string& out, size_t i) {
+            if (toks[i] < dict.terms.size()) out += dict.terms[toks[i]];
+        },
+        opt, any);
+}
+void check_snippet_window(const vqreq::SnippetInfo& opt) {
+    if (opt.num_words_around_snippet < 0 || opt.num_words_around_snippet > 0x3FFFFFFF)  // the reference's window arithmetic overflows / panics there
+        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"snippet_info.num_words_around_snippet out of range\" ");
+}
 }  // namespace
+
+// highlight_text (highlight_field.rs:92-146): `text` with the tokens that are in `terms` tagged — what why_found highlighting applies to every text
+// of a returned document (highlight_on_original_document, :148-185) with the field's why_found_terms.  nullopt: nothing to highlight.
+std::optional<std::string> highlight_text(const std::string& text, const std::vector<std::string>& terms, const vqreq::SnippetInfo& opt, bool tokenized) {
+    check_snippet_window(opt);
+    std::vector<std::string> set = terms;
+    std::sort(set.begin(), set.end());
+    set.erase(std::unique(set.begin(), set.end()), set.end());
+    if (set.size() == 1 && set[0] == text) return opt.snippet_start_tag + text + opt.snippet_end_tag;  // one hit that is the whole text
+    if (!tokenized) return std::nullopt;
+    const std::vector<vqtext::TokenSpan> tokens = vqtext::tokenize_grouped(text);
+    std::vector<char> hit(tokens.size(), 0);
+    for (size_t i = 0; i < tokens.size(); ++i) hit[i] = std::binary_search(set.begin(), set.end(), text.substr(tokens[i].begin, tokens[i].end - tokens[i].begin));
+    bool any = false;
+    std::string out = snippet_of_tokens(
+        tokens.size(), [&](size_t i) { return hit[i] != 0; }, [&](std::string& o, size_t i) { o.append(text, tokens[i].begin, tokens[i].end - tokens[i].begin); }, opt, &any);
+    // (contains_any_token is set while the windows are written: with max_snippets == 0 nothing is)
+    if (!any || opt.max_snippets == 0) return std::nullopt;
+    return out;
+}
 
 std::vector<SuggestEntry> highlight_part(const Index& idx, const RequestSearchPart& part, const FuzzyTable* fuzzy) {
     static const vqreq::SnippetInfo kDefault;
     const vqreq::SnippetInfo& opt = part.has_snippet_info ? part.snippet_info : kDefault;
-    if (opt.num_words_around_snippet < 0 || opt.num_words_around_snippet > 0x3FFFFFFF)  // the reference's window arithmetic overflows / panics there
-        throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"snippet_info.num_words_around_snippet out of range\" ");
+    check_snippet_window(opt);
     RequestSearchPart lookup = part;  // get_term_ids_in_field does not look at the snippet fields
     lookup.snippet.reset();
     lookup.has_snippet_info = false;

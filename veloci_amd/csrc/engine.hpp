@@ -156,6 +156,7 @@ struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, 
 };
 std::vector<SuggestEntry> suggest_part(const Index& idx, const vqreq::RequestSearchPart& part, const FuzzyTable* fuzzy);
 void collect_suggest_probes(const Index& idx, const vqreq::Request& req, FuzzyTable& table);
+std::optional<std::string> highlight_text(const std::string& text, const std::vector<std::string>& terms, const vqreq::SnippetInfo& opt, bool tokenized);  // highlight_field.rs:92-146
 vqreq::Request page_request_after(const vqreq::Request& request, float score, uint32_t id);
 std::vector<SuggestEntry> highlight_part(const Index& idx, const vqreq::RequestSearchPart& part, const FuzzyTable* fuzzy);
 std::vector<SuggestEntry> run_highlight(const Index& idx, vqreq::RequestSearchPart part);  // search_field::highlight, search_field.rs:233-245

@@ -248,6 +248,26 @@ inline SearchRequestOptions options_from_json(const vqjson::Value& v) {
     return o;
 }
 
+inline SnippetInfo snippet_info_from_json(const vqjson::Value& sv) {  // src/search/request/snippet_info.rs:1-13: every field has a serde default
+    if (!sv.is_object()) json_fail("SnippetInfo: expected an object");
+    const vqjson::Value* s = &sv;
+    SnippetInfo si;
+    if (const vqjson::Value* n = s->get("num_words_around_snippet")) {
+        if (!n->is_number() || !n->is_integer || n->num < -9223372036854775808.0 || n->num >= 9223372036854775808.0)
+            json_fail("invalid type for num_words_around_snippet, expected i64");
+        si.num_words_around_snippet = int64_t(n->num);
+    }
+    if (const vqjson::Value* t = s->get("snippet_start_tag")) si.snippet_start_tag = j_string(*t, "snippet_start_tag");
+    if (const vqjson::Value* t = s->get("snippet_end_tag")) si.snippet_end_tag = j_string(*t, "snippet_end_tag");
+    if (const vqjson::Value* t = s->get("snippet_connector")) si.snippet_connector = j_string(*t, "snippet_connector");
+    if (const vqjson::Value* m = s->get("max_snippets")) {
+        const size_t d = j_usize(*m, "max_snippets");
+        if (d > 0xFFFFFFFFull) json_fail("invalid value for max_snippets, expected u32");
+        si.max_snippets = uint32_t(d);
+    }
+    return si;
+}
+
 inline RequestSearchPart search_part_from_json(const vqjson::Value& v) {
     if (!v.is_object()) json_fail("RequestSearchPart: expected an object");
     RequestSearchPart p;
@@ -270,22 +290,8 @@ inline RequestSearchPart search_part_from_json(const vqjson::Value& v) {
     p.ignore_case = j_opt<bool>(v, "ignore_case", j_bool);
     p.snippet = j_opt<bool>(v, "snippet", j_bool);
     if (const vqjson::Value* s = v.get("snippet_info"); s && !s->is_null()) {
-        if (!s->is_object()) json_fail("SnippetInfo: expected an object");
         p.has_snippet_info = true;
-        SnippetInfo& si = p.snippet_info;
-        if (const vqjson::Value* n = s->get("num_words_around_snippet")) {
-            if (!n->is_number() || !n->is_integer || n->num < -9223372036854775808.0 || n->num >= 9223372036854775808.0)
-                json_fail("invalid type for num_words_around_snippet, expected i64");
-            si.num_words_around_snippet = int64_t(n->num);
-        }
-        if (const vqjson::Value* t = s->get("snippet_start_tag")) si.snippet_start_tag = j_string(*t, "snippet_start_tag");
-        if (const vqjson::Value* t = s->get("snippet_end_tag")) si.snippet_end_tag = j_string(*t, "snippet_end_tag");
-        if (const vqjson::Value* t = s->get("snippet_connector")) si.snippet_connector = j_string(*t, "snippet_connector");
-        if (const vqjson::Value* m = s->get("max_snippets")) {
-            const size_t d = j_usize(*m, "max_snippets");
-            if (d > 0xFFFFFFFFull) json_fail("invalid value for max_snippets, expected u32");
-            si.max_snippets = uint32_t(d);
-        }
+        p.snippet_info = snippet_info_from_json(*s);
     }
     p.top = j_opt<size_t>(v, "top", j_usize);
     p.skip = j_opt<size_t>(v, "skip", j_usize);

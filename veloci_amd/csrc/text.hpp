@@ -188,4 +188,43 @@ inline std::string normalize_text(const std::string& text) {
     return out;
 }
 
+// ---- SimpleTokenizerCharsIterateGroupTokens with DEFAULT_SEPERATORS (src/tokenizer/simple_tokenizer_group.rs:51-82, tokenizer/mod.rs:21-23): runs of
+// separator characters and runs of other characters alternate; byte spans [begin, end) of `text` plus whether the run is a separator run
+inline bool is_default_separator(uint32_t c) {
+    switch (c) {
+        case ' ': case '\t': case '\n': case '\r': case ':': case '(': case ')': case ',': case '.': case 0x2026: case ';': case 0x30FB: case 0x2019:
+        case 0x2014: case '-': case '\\': case '[': case ']': case '{': case '}': case '<': case '>': case '\'': case '"': case 0x201C: case 0x2122:
+            return true;
+        default: return false;
+    }
+}
+struct TokenSpan {
+    size_t begin, end;
+    bool separator;
+};
+inline std::vector<TokenSpan> tokenize_grouped(const std::string& text) {
+    std::vector<TokenSpan> out;
+    size_t start = 0;
+    bool in_separators = false;
+    for (size_t pos = 0; pos < text.size();) {
+        const unsigned char lead = (unsigned char)text[pos];
+        const size_t len = lead < 0x80 ? 1 : (lead >> 5) == 6 ? 2 : (lead >> 4) == 14 ? 3 : (lead >> 3) == 30 ? 4 : 1;
+        uint32_t cp = lead;
+        if (len > 1 && pos + len <= text.size()) {
+            cp = lead & (0xFFu >> (len + 1));
+            for (size_t k = 1; k < len; ++k) cp = (cp << 6) | ((unsigned char)text[pos + k] & 0x3Fu);
+        }
+        const bool sep = is_default_separator(cp);
+        if (pos == 0) in_separators = sep;
+        else if (sep != in_separators) {
+            out.push_back({start, pos, in_separators});
+            start = pos;
+            in_separators = sep;
+        }
+        pos += len;
+    }
+    if (start != text.size()) out.push_back({start, text.size(), in_separators});
+    return out;
+}
+
 }  // namespace vqtext

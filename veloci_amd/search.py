@@ -189,6 +189,28 @@ def highlight(part, index):
         L.vq_suggest_free(out)
 
 
+def highlight_text(text, terms, snippet_info=None, tokenized=True):
+    """== highlight_field::highlight_text (src/highlight_field.rs:92-146) — `vq_highlight_text`.  -> the snippet, or None."""
+    L = _lib.lib()
+    raw = text.encode()
+    enc = [t.encode() for t in terms]
+    arr = (C.c_char_p * len(enc))(*enc)
+    lens = (C.c_size_t * len(enc))(*[len(e) for e in enc])
+    si = json.dumps(snippet_info).encode() if snippet_info is not None else None
+    cap = 2 * len(raw) + 256
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = L.vq_highlight_text(raw, len(raw), arr, lens, len(enc), si, len(si) if si else 0, int(tokenized), buf, cap)
+        if n == C.c_size_t(-1).value:
+            return None
+        if n == C.c_size_t(-2).value:
+            msg = L.vq_last_error().decode("utf-8", "replace")
+            raise _lib.VelociError(1 if msg.startswith("InvalidRequest") else 7 if msg.startswith("JsonError") else 6, msg)
+        if n <= cap:
+            return buf.raw[:n].decode()
+        cap = n
+
+
 def search_batch(requests, index, raise_on_error=True):
     """n independent searches executed as one device batch (`vq_search_batch`)."""
     L = _lib.lib()
