@@ -767,7 +767,17 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             const char* e = std::getenv("VQ_FLAT_CHUNKS");
             return size_t(e ? std::max(1, std::atoi(e)) : 0);
         }();
-        const size_t nchunks = n >= 512 ? (chunks_env ? chunks_env : 4) : 1;
+        // Requests with pre-passes (dictionary scans of fuzzy / prefix leaves, then unions) make the HOST side of a chunk long: it waits for
+        // each pre-pass.  Two host threads, two chunks each, keep the GPU fed (config #4: 4.3 ms of kernels per chunk against 5 ms of
+        // host-visible time; one thread: 50 k requests/s).  Plain batches stay on the calling thread: their host side is short.
+        static const bool one_thread = std::getenv("VQ_FLAT_ONE_THREAD") != nullptr;
+        static const size_t small_chunks = [] {  // a batch of 128 .. 511 requests with pre-passes: chunks of the two-thread pipeline (1: one piece)
+            const char* e = std::getenv("VQ_FLAT_SMALL_CHUNKS");
+            const int v = e ? std::atoi(e) : 2;
+            return size_t(v == 4 ? 4 : v == 2 ? 2 : 1);
+        }();
+        const bool with_prepasses = kWorkspaces >= 4 && !one_thread && n >= 128 && batch_has_prepasses(reqs);
+        const size_t nchunks = n >= 512 ? (chunks_env ? chunks_env : 4) : with_prepasses ? small_chunks : 1;
         std::vector<std::unique_ptr<PartialBatch>> inflight(nchunks);
         auto bounds = [&](size_t c) { return std::make_pair(n * c / nchunks, n * (c + 1) / nchunks); };
         auto finish = [&](size_t c) {
@@ -779,19 +789,14 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             copy_flat(results, st, errs, bounds(c).first, stride, num_hits, counts, ids, scores, status);
             inflight[c].reset();
         };
-        // Requests with pre-passes (dictionary scans of fuzzy / prefix leaves, then unions) make the HOST side of a chunk long: it waits for
-        // each pre-pass.  Two host threads, two chunks each, keep the GPU fed (config #4: 4.3 ms of kernels per chunk against 5 ms of
-        // host-visible time; one thread: 50 k requests/s).  Plain batches stay on the calling thread: their host side is short.
-        static const bool one_thread = std::getenv("VQ_FLAT_ONE_THREAD") != nullptr;
-        const bool prepasses = nchunks == 4 && kWorkspaces >= 4 && !one_thread && batch_has_prepasses(reqs);
+        const bool prepasses = with_prepasses && (nchunks == 4 || nchunks == 2);
         if (prepasses) {
             auto half = [&](size_t t) {
-                for (size_t c : {t, t + 2}) {
+                for (size_t c = t; c < nchunks; c += 2) {
                     auto [b, e] = bounds(c);
                     inflight[c] = run_partial(*index->idx, reqs.data() + b, e - b, int(c));
                 }
-                finish(t);
-                finish(t + 2);
+                for (size_t c = t; c < nchunks; c += 2) finish(c);
             };
             auto other = std::async(std::launch::async, half, size_t(1));
             try {
