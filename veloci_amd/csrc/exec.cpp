@@ -66,7 +66,10 @@ LaunchTimer::~LaunchTimer() {
 static size_t host_threads() {
     static const size_t n = [] {
         const char* e = std::getenv("VQ_HOST_THREADS");
-        size_t v = e ? size_t(std::atoi(e)) : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+        size_t hw = std::max(1u, std::thread::hardware_concurrency());
+        if (const char* lws = std::getenv("LOCAL_WORLD_SIZE"); lws && std::atoi(lws) > 1)  // one process per GPU (torch.distributed.run): this rank's share of the node
+            hw = std::max<size_t>(hw / size_t(std::atoi(lws)), 2);
+        size_t v = e ? size_t(std::atoi(e)) : std::min<size_t>(16, hw);
         return std::min<size_t>(std::max<size_t>(v, 1), 64);
     }();
     return n;
