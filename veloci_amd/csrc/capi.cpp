@@ -777,7 +777,13 @@ int vq_search_batch_flat(const vq_index* index, const vq_request* const* request
             return size_t(v == 4 ? 4 : v == 2 ? 2 : 1);
         }();
         const bool with_prepasses = kWorkspaces >= 4 && !one_thread && n >= 128 && batch_has_prepasses(reqs);
-        const size_t nchunks = n >= 512 ? (chunks_env ? chunks_env : 4) : with_prepasses ? small_chunks : 1;
+        // Plain batches on a large index: two chunks — the second is compiled while the first scans; launches of 256 requests fill the chip less
+        // evenly than launches of 512 (100 M docs: 3-term AND 110.6 k requests/s with 2 chunks, 109.4 k with 1, 107.9 k with 4, 103.7 k with 8; the
+        // request mix of config #5 68.5 k against 58.5 k).  On a small index the scan of a chunk is short next to its compilation and four chunks
+        // hide more of the host side (10 M docs, AND + phrases + locality: 402 k with 4, 386 k with 2).
+        const uint64_t shard_docs = uint64_t(index->idx->doc_hi) - index->idx->doc_lo;
+        const size_t plain_chunks = shard_docs >= 32'000'000ull ? 2 : 4;
+        const size_t nchunks = n >= 512 ? (chunks_env ? chunks_env : with_prepasses ? 4 : plain_chunks) : with_prepasses ? small_chunks : 1;
         std::vector<std::unique_ptr<PartialBatch>> inflight(nchunks);
         auto bounds = [&](size_t c) { return std::make_pair(n * c / nchunks, n * (c + 1) / nchunks); };
         auto finish = [&](size_t c) {
