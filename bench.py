@@ -269,7 +269,8 @@ def roofline_object(table, docs, triples, batch, workload, world):
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 tr = json.load(f)
             c = tr["config"]
-            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (docs, triples, batch, workload, world):
+            same_launch = c.get("queries_per_launch") is None or abs(float(c["queries_per_launch"]) - float(roof["queries_per_launch"])) < 0.5
+            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (docs, triples, batch, workload, world) and same_launch:
                 roof["traffic_profiled_offline"] = {"bytes_per_launch": tr["traffic_bytes_per_launch"], "source": f"profiles/{fn}",
                                                     "how": tr.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
                 break
