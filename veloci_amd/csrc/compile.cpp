@@ -2125,7 +2125,7 @@ struct Compiler {
         }();
         const bool and_like = ((cq.simple_flags >> 18) & 1u) || (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND);  // rich, or a plain simple AND
         const bool wide_like = (cq.simple_flags >> 24) & 1u;  // k_scan_wide: its count-class pruning gains most from a long warm-up (OR over 8 terms: 27.6 k q/s at 256 Ki, 29.0 k at 512 Ki, 28.7 k at 1 Mi)
-        const uint64_t span_postings = span_env ? span_env : (and_like ? 131072 : wide_like ? 524288 : 262144);
+        const uint64_t span_postings = span_env ? span_env : (and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
         uint32_t ww = ww_max;  // W = 32 * ww docs
         const size_t TL = size_t(L) + cq.n_temps;
         while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
