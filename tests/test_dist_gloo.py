@@ -143,3 +143,59 @@ def test_shard_range_partitions_everything():
             edges = [shard_range(n, r, w) for r in range(w)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def test_sharded_deep_paging_loop_pages_until_reach_and_applies_skip_and_top():
+    """`search.complete_deep_pages` (the host loop a caller of the sharded merge runs) against a ranked list held in Python: page 0
+    arrives flagged, every further round is asked for with the last hit's (score, id), paging stops at top + skip, at the end of the hits, or
+    at an empty page; a failing round fails only its request; beyond 65 536 ranked hits the request is declined."""
+    import numpy as np
+    import importlib
+    S = importlib.import_module("veloci_amd.search")  # (the package re-exports a function of the same name)
+    from veloci_amd._lib import VelociError
+
+    class FakeRequest(S.Request):
+        def __init__(self, top, skip, ranked, fail_at=None):
+            self.h = None
+            self.top, self.skip, self.ranked, self.fail_at = top, skip, ranked, fail_at
+            self.after = None
+
+        def top_skip(self):
+            return self.top, self.skip
+
+        def page_after(self, score, doc_id):
+            page = FakeRequest(self.top, self.skip, self.ranked, self.fail_at)
+            page.after = (float(score), int(doc_id))
+            return page
+
+    def page_of(req):
+        start = 0 if req.after is None else 1 + next(i for i, (s, d) in enumerate(req.ranked) if (float(s), int(d)) == req.after)
+        if req.fail_at is not None and start >= req.fail_at:
+            return VelociError(5, "Device: injected")
+        rows = req.ranked[start:start + 1024]
+        res = S.SearchResult(len(req.ranked), np.array([d for _, d in rows], np.uint32), np.array([s for s, _ in rows], np.float32), None, 0)
+        return res
+
+    rounds = []
+
+    def run_page(pages):
+        rounds.append(len(pages))
+        return [page_of(p) for p in pages]
+
+    def ranked(n):
+        return [(np.float32(1000.0 - 0.01 * i), 7 * i + 3) for i in range(n)]
+
+    cases = [(1500, 0, 5000), (10, 3000, 5000), (2000, 1000, 2500), (7, 1024, 5000), (1025, 0, 1025), (5, 10**7, 5000), (6000, 0, 5000), (10, 4995, 5000), (3000, 0, 1024)]
+    reqs = [FakeRequest(t, s, ranked(n)) for t, s, n in cases] + [FakeRequest(4000, 0, ranked(5000), fail_at=2048), FakeRequest(10, 70000, ranked(80000)), FakeRequest(10, 0, ranked(50))]
+    first = [page_of(r) for r in reqs]
+    for r, res in zip(reqs, first):
+        res.is_page = r.top + r.skip > 1024
+    out = S.complete_deep_pages(reqs, first, run_page)
+    for (t, s, n), res in zip(cases, out):
+        want = ranked(n)[s:s + t]
+        assert list(res.ids) == [d for _, d in want] and not res.is_page, (t, s, n, len(res.ids))
+        assert np.array_equal(res.scores, np.array([x for x, _ in want], np.float32))
+    assert isinstance(out[len(cases)], VelociError) and out[len(cases)].kind == "Device"
+    assert isinstance(out[len(cases) + 1], VelociError) and out[len(cases) + 1].kind == "Unsupported"
+    assert len(out[-1].ids) == 50
+    assert rounds and max(rounds) <= len(reqs)  # every round carries only the requests that still page
