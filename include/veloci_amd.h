@@ -156,6 +156,9 @@ size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap
 /* util::normalize_text (src/util.rs:11-29) as vq_highlight_json applies it to a part's terms; same conventions.  Diagnostic: compared with an
  * independent regex engine by tests/test_request_parse.py. */
 size_t vq_debug_normalize_text(const char* utf8, size_t len, char* out, size_t cap);
+/* The request compiler's id-list sort (value ids behind 1:n boost lists: ascending, duplicate-free, in place; returns the new length).  Diagnostic:
+ * its three regimes are compared with an independent sort by tests/test_request_parse.py. */
+size_t vq_debug_sort_unique_u32(uint32_t* ids, size_t n);
 /* Compile a request against an index without launching anything (host-only): 0 = ready to scan, negative = a pre-pass would run first (-1 union /
  * locality jobs, -2 count pre-pass, -3 range jobs), otherwise the error code the search would return.  Diagnostic: the CPU sanitizer build (`make asan`) runs it over the
  * request fixtures; tools/compile_bench.py times it. */

@@ -114,3 +114,23 @@ def test_normalize_text_agrees_with_the_reference_regexes_run_by_an_independent_
     for _ in range(3000):
         s = "".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 14)))
         assert got(s) == want(s), repr(s)
+
+
+def test_id_list_sort_agrees_with_numpy_in_all_three_regimes():
+    """sort_unique_u32 (compile.cpp): short lists (std::sort), dense spans (bitmap), sparse spans (LSD radix passes) — against np.unique."""
+    import numpy as np
+    from veloci_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    regimes = set()
+    for it in range(120):
+        n = int(rng.integers(0, 3000)) if it < 30 else int(rng.integers(2048, 300_000))
+        span = [1_000_000, 4_000_000_000, 3 * n + 10, 40 * n + 10][it % 4]
+        v = (rng.integers(0, span, n, dtype=np.uint64) + int(rng.integers(0, 1000))).astype(np.uint32)
+        want = np.unique(v)
+        buf = np.ascontiguousarray(v)
+        m = L.vq_debug_sort_unique_u32(buf.ctypes.data_as(C.c_void_p), n)
+        assert m == len(want) and np.array_equal(buf[:m], want), (it, n, span)
+        if n >= 2048:
+            regimes.add("bitmap" if (int(v.max()) - int(v.min()) + 64) // 64 <= n else "radix")
+    assert regimes == {"bitmap", "radix"}

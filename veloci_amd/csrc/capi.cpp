@@ -445,6 +445,9 @@ size_t vq_debug_normalize_text(const char* utf8, size_t len, char* out, size_t c
     std::memcpy(out, norm.data(), norm.size());
     return norm.size();
 }
+// The request compiler's id-list sort (ascending, duplicate-free, in place; returns the new length): a bitmap over dense id spans, radix passes over
+// sparse ones, std::sort for short lists — swept against numpy by tests/test_request_parse.py.
+size_t vq_debug_sort_unique_u32(uint32_t* ids, size_t n) { return ids || !n ? vq::debug_sort_unique(ids, n) : 0; }
 // Compile `request` against `index` without launching anything: 0 when the query is ready to scan, negative when a pre-pass would run first
 // (-1 union / locality jobs, -2 count pre-pass, -3 range jobs), or the error code the search would return (message in vq_last_error).  Host-only work —
 // what the CPU sanitizer build exercises, and what tools/compile_bench.py times.

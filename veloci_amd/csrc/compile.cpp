@@ -155,8 +155,15 @@ void sort_unique_u32(std::vector<uint32_t>& v) {
         hi = std::max(hi, x);
     }
     const uint64_t span = uint64_t(hi) - lo + 1, words = (span + 63) / 64;
-    if (words <= 8 * n) {
+    constexpr size_t kKeepBytes = 8u << 20;  // scratch a compile thread keeps between calls; larger buffers are handed back
+    if (words <= n) {                        // (the bitmap is at most twice the ids' own size)
         thread_local std::vector<uint64_t> bits;
+        struct Trim {
+            std::vector<uint64_t>& v;
+            ~Trim() {
+                if (v.capacity() * sizeof(uint64_t) > kKeepBytes) std::vector<uint64_t>().swap(v);
+            }
+        } trim{bits};
         bits.assign(words, 0);
         for (uint32_t x : v) bits[(x - lo) >> 6] |= 1ull << ((x - lo) & 63);
         size_t k = 0;
@@ -171,6 +178,12 @@ void sort_unique_u32(std::vector<uint32_t>& v) {
         return;
     }
     thread_local std::vector<uint32_t> tmp;
+    struct TrimTmp {
+        std::vector<uint32_t>& v;
+        ~TrimTmp() {
+            if (v.capacity() * sizeof(uint32_t) > kKeepBytes) std::vector<uint32_t>().swap(v);
+        }
+    } trim_tmp{tmp};
     tmp.resize(n);
     uint32_t* a = v.data();
     uint32_t* b = tmp.data();
@@ -2210,6 +2223,12 @@ struct Compiler {
 }  // namespace
 
 float default_score_for_distance_host(uint8_t distance, bool prefix_matches) { return default_score_for_distance(distance, prefix_matches); }
+size_t debug_sort_unique(uint32_t* ids, size_t n) {  // (tests: the three regimes of sort_unique_u32 against an independent sort)
+    std::vector<uint32_t> v(ids, ids + n);
+    sort_unique_u32(v);
+    std::copy(v.begin(), v.end(), ids);
+    return v.size();
+}
 
 // suggest (search_field.rs:194-219): one part's matched terms with lower-cased texts and scores — get_term_ids_in_field with get_scores,
 // return_term and return_term_lowercase; the dictionary scan of a fuzzy / prefix part has run on the device (`fuzzy`).

@@ -149,6 +149,7 @@ struct Workspace;
 void run_fuzzy_probes(const Index& idx, Workspace& ws, FuzzyTable& table, hipStream_t st);
 void score_fuzzy_probe(const Index& idx, FuzzyProbe& probe);
 float default_score_for_distance_host(uint8_t distance, bool prefix_matches);  // search_field.rs:27-33
+size_t debug_sort_unique(uint32_t* ids, size_t n);
 struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, Score, TermId)>
     std::string text;
     float score;
