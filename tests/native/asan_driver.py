@@ -65,7 +65,8 @@ for name, reqs in by_corpus.items():
         stats["device_errors"] += e.kind == "Device"
     del idx
 
-# highlight (search_field.rs:233-245) with exact terms is host work from end to end: snippets under the sanitizers, compared with the oracle's
+# highlight (search_field.rs:233-245) with exact and prefix terms is host work from end to end here (the stub answers prefix probes with a loop):
+# snippets under the sanitizers, compared with the oracle's
 import test_reference_integration as T  # noqa: E402
 from oracle import binding as O  # noqa: E402
 data, docs, info = refcases.build("test_all")
@@ -73,8 +74,9 @@ idx = veloci_amd.Index(data, device=0)
 ora = O.OracleIndex(data.num_anchors)
 data.load_into(ora)
 stats["highlighted"] = stats["highlight_errors"] = 0
+os.environ["VQ_STUB_DICT_SCAN"] = "1"  # prefix probes answered by the stub's plain loop: the host side of a dictionary scan (probe tables, bucketing, scoring) runs too
 for part in T.highlight_parts():
-    if part.get("starts_with") or part.get("levenshtein_distance"):
+    if part.get("levenshtein_distance"):
         continue
     js = json.dumps(part)
     try:
