@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE — the device layer stubbed for the CPU sanitizer build (`make -C veloci_amd/csrc asan`, tests/test_host_asan.py): the HIP
-// runtime calls the host side makes are mapped to host memory, every kernel launcher throws.  What this build can run is everything in front of
+// runtime calls the host side makes are mapped to host memory, every kernel launcher throws (one exception, opt-in: with VQ_STUB_DICT_SCAN=1
+// exact / prefix dictionary probes are answered by a plain loop, see launch_dict_scan below).  What this build can run is everything in front of
 // the first launch: index staging (index.cpp), request parsing, query compilation (compile.cpp), the C ABI's argument handling — under
 // AddressSanitizer + UndefinedBehaviorSanitizer.  Never linked into the product library.
 #include <hip/hip_runtime_api.h>
