@@ -1,5 +1,5 @@
 """Generates tests/golden/reference_query_generator.json: the requests `query_generator::search_query` produces for the reference's own
-query-generator tests (tests/all/test_query_generator.rs, tests/all/test_code_search.rs:73-117), derived with the restatement in
+query-generator tests (tests/all/test_query_generator.rs, tests/all/test_code_search.rs:73-150, tests/all/test_scores.rs:157-237), derived with the restatement in
 tests/qgen.py, next to what each test asserts.  Run from the repo root: python tests/gen_query_generator_fixtures.py"""
 import json
 import os
@@ -37,6 +37,19 @@ CODE_DOCS = [{"line_number": 1, "line": "function myfun(param1: Type1)", "filena
 CODE_INDICES = {"*GLOBAL*": {"features": ["All"]}, "filepath": {"fulltext": {"tokenize": True, "tokenize_on_chars": ["/", "\\"]}}, "filename": {"fulltext": {"tokenize": True}},
                 "line": {"fulltext": {"tokenize": True}}, "line_number": {"boost": {"boost_type": "f32"}}}
 
+SCORE_DOCS = [  # tests/all/test_scores.rs:6-45
+    {"id": 1, "order": 500, "title": "greg tagebuch 05"},
+    {"id": 2, "order": 20, "title": "and some some text 05 this is not relevant let tagebuch greg"},
+    {"id": 3, "order": 1000, "title": "greg tagebuch"},
+    {"id": 4, "commonness": 41, "meanings": {"ger": [{"text": "Fernsehen-Schauen (n)", "boost": 20}]}},
+    {"id": 5, "commonness": 551, "meanings": {"ger": ["welch"]}},
+    {"id": 6, "commonness": 2, "meanings": {"ger": ["weich"]}},
+]
+SCORE_INDICES = {  # :50-61 (TOML there)
+    "title": {"fulltext": {"tokenize": True}}, "meanings.ger[].boost": {"boost": {"boost_type": "f32"}}, "meanings.ger[].text": {"fulltext": {"tokenize": True}},
+    "commonness": {"boost": {"boost_type": "f32"}}, "order": {"boost": {"boost_type": "f32"}},
+}
+
 E = lambda n, d=None, **kw: dict({"len": n}, **({"doc": d} if d else {}), **kw)
 URGE_DOC = [[0, ["ent_seq"], "1587690"], [0, ["commonness"], 20], [0, ["tags"], ["nice"]]]
 T = "tests/all/test_query_generator.rs"
@@ -69,6 +82,20 @@ CASES = [
     ("pattern_code_search_ignore_case_query_generator", "codeTest", "tests/all/test_code_search.rs:83-91", {"search_term": "*myfun*type1*"}, E(1, [[0, ["line"], "function myfun(param1: Type1)"]])),
     ("pattern_code_search_case_sensitive_query_generator", "codeTest", "tests/all/test_code_search.rs:93-103", {"search_term": "*myfun*type1*", "ignore_case": False}, E(0)),
     ("pattern_code_search_no_fuzzy_query_generator", "codeTest", "tests/all/test_code_search.rs:105-112", {"search_term": "*myfun*type2*"}, E(0)),
+    ("token_code_search_query_generator", "codeTest", "tests/all/test_code_search.rs:114-121", {"search_term": "myfun"}, E(1)),
+    ("token_code_search_disable_parser_query_generator", "codeTest", "tests/all/test_code_search.rs:123-138",
+     {"search_term": "*myfun(param1: Type1)*", "parser_options": {"no_parentheses": True, "no_attributes": True, "no_levensthein": True}}, E(1)),
+    ("token_code_phrase_pattern_query_generator", "codeTest", "tests/all/test_code_search.rs:140-148", {"search_term": "\"*myfun(param1: Type1)*\""}, E(1)),
+    # the reference's arithmetic pins: the scores themselves
+    ("check_score_boost_relative_field", "test_score", "tests/all/test_scores.rs:157-183",
+     {"search_term": "schauen", "fields": ["meanings.ger[].text"], "top": 3, "skip": 0, "why_found": True,
+      "boost_queries": [{"path": "meanings.ger[].boost", "boost_fun": "Log10", "param": 10}], "boost_fields": {"meanings.ger[].text": 2.0}}, {"score0_gt": 40.0}),
+    ("check_score_boost_add_value_from_field", "test_score", "tests/all/test_scores.rs:185-211",
+     {"search_term": "weich", "fields": ["meanings.ger[]"], "levenshtein": 0, "boost_queries": [{"path": "commonness", "boost_fun": "Add"}]},
+     {"score0_eq_base": {"base_params": {"search_term": "weich", "levenshtein": 0, "fields": ["meanings.ger[]"]}, "op": "add", "value": 2.0}}),
+    ("check_score_boost_multiply_value_from_field", "test_score", "tests/all/test_scores.rs:213-237",
+     {"search_term": "weich", "fields": ["meanings.ger[]"], "levenshtein": 0, "boost_queries": [{"path": "commonness", "boost_fun": "Multiply"}]},
+     {"score0_eq_base": {"base_params": {"search_term": "weich", "levenshtein": 0, "fields": ["meanings.ger[]"]}, "op": "mul", "value": 2.0}}),
 ]
 
 
@@ -84,6 +111,7 @@ def main():
     corpora = {
         "test_querygenerator": {"source": T + ":9-137", "indices": QG_INDICES, "docs": QG_DOCS, "token_values": [[{"text": "Begeisterung", "value": 20}], "meanings.ger[]"]},
         "codeTest": {"source": "tests/all/test_code_search.rs:11-41", "indices": CODE_INDICES, "docs": CODE_DOCS},
+        "test_score": {"source": "tests/all/test_scores.rs:6-64", "indices": SCORE_INDICES, "docs": SCORE_DOCS},
     }
     fields = {name: fields_of(c["docs"], c["indices"], tuple(c["token_values"]) if c.get("token_values") else None) for name, c in corpora.items()}
     for name, c in corpora.items():
@@ -93,6 +121,9 @@ def main():
         case = {"name": name, "corpus": corpus, "source": source, "params": params, "expect": expect}
         try:
             case["request"] = qgen.search_query(*fields[corpus], params)
+            if "score0_eq_base" in expect:  # the unboosted request of the same test, from its own parameters
+                expect = dict(expect, score0_eq_base=dict(expect["score0_eq_base"], request=qgen.search_query(*fields[corpus], expect["score0_eq_base"]["base_params"])))
+                case["expect"] = expect
         except qgen.GeneratorError as e:
             case["generator_error"] = str(e)
         cases.append(case)

@@ -3,11 +3,12 @@ tests/golden/reference_query_generator.json (tests/gen_query_generator_fixtures.
 
 Follows `query_generator::search_query` (src/query_generator.rs:175-246) and `ast_to_search_request`
 (src/query_generator/query_parser_to_veloci_request.rs:11-109) for the parameters the reference's own tests use
-(tests/all/test_query_generator.rs, tests/all/test_code_search.rs:73-117): search_term, parser_options.no_attributes, top, skip,
+(tests/all/test_query_generator.rs, tests/all/test_code_search.rs:73-150, tests/all/test_scores.rs:157-237): search_term, parser_options.no_attributes, top, skip,
 ignore_case, levenshtein, levenshtein_auto_limit, facets, facetlimit, why_found, text_locality, fields, boost_fields, boost_terms,
 explain, stopword_lists / stopwords (parsed and — as in the reference, :12 — without effect: filter_stopwords' result is dropped).
 The query language is restated for the forms those tests use (query_parser/src/parser.rs:100-186): literals, `attr:literal`,
-`AND` / `OR` (right-recursive), juxtaposition = OR; parentheses, quotes and `~n` are not needed by them and are rejected here.
+`AND` / `OR` (right-recursive), juxtaposition = OR, quoted literals, the parser options that turn `(` `)` `~` `:` into plain characters;
+parenthesised groups and `~n` are not needed by them and are rejected here.
 `metadata.get_all_fields()` iterates an FnvHashMap (src/metadata.rs:28-30): the field order is unspecified in the reference; sorted here.
 """
 import re
@@ -17,15 +18,41 @@ class GeneratorError(Exception):
     pass
 
 
-def parse(text, no_attributes=False):
-    """-> AST: ("leaf", phrase) | ("attr", field, ast) | ("bin", ast, "and"|"or", ast)   (query_parser/src/parser.rs:139-186)"""
-    if any(c in text for c in '()"~'):
-        raise GeneratorError("query form outside the restated subset: " + text)
-    tokens = text.split()
+def parse(text, no_attributes=False, no_parentheses=False, no_levensthein=False):
+    """-> AST: ("leaf", phrase) | ("attr", field, ast) | ("bin", ast, "and"|"or", ast)   (query_parser/src/parser.rs:139-186).
+    Lexer (query_parser/src/lexer.rs:20-41,114-196): whitespace separates literals; a double quote opens a literal that runs to the next
+    quote (whitespace and everything else inside it kept); '(' ')' are tokens unless `no_parentheses`, '~' unless `no_levensthein` — with
+    the option set they are ordinary characters of a literal."""
+    tokens, quoted = [], set()
+    i, n = 0, len(text)
+    while i < n:
+        if text[i].isspace():
+            i += 1
+            continue
+        if text[i] == '"':  # lexer.rs:132-159
+            j = text.find('"', i + 1)
+            j = n if j < 0 else j
+            quoted.add(len(tokens))
+            tokens.append(text[i + 1:j])
+            i = j + 1
+            continue
+        j = i
+        while j < n and not text[j].isspace():
+            j += 1
+        tokens.append(text[i:j])
+        i = j
+    for k, tok in enumerate(tokens):
+        if k in quoted:
+            continue
+        if (not no_parentheses and any(c in tok for c in "()")) or (not no_levensthein and "~" in tok) or '"' in tok:
+            raise GeneratorError("query form outside the restated subset: " + text)
     if not tokens:
         raise GeneratorError("empty query")
 
-    def atom(tok):
+    def atom(pos):
+        tok = tokens[pos]
+        if pos in quoted:  # (a quoted literal directly followed by ':' would be an attribute, lexer.rs:149-154: not needed here)
+            return ("leaf", tok)
         if not no_attributes and ":" in tok:
             field, phrase = tok.split(":", 1)
             if ":" in phrase or not phrase:
@@ -34,15 +61,15 @@ def parse(text, no_attributes=False):
         return ("leaf", tok)
 
     def expr(pos):
-        cur = atom(tokens[pos])
+        cur = atom(pos)
         pos += 1
         if pos == len(tokens):
             return cur
         # AND / OR are operators only between two operands: first or last they are literals (query_parser/src/lexer.rs:265-275: "OR OR" is
         # two literals, "OR OR OR" is Literal Or Literal)
-        if tokens[pos] == "AND" and pos + 1 < len(tokens):
+        if tokens[pos] == "AND" and pos not in quoted and pos + 1 < len(tokens):
             return ("bin", cur, "and", expr(pos + 1))
-        if tokens[pos] == "OR" and pos + 1 < len(tokens):
+        if tokens[pos] == "OR" and pos not in quoted and pos + 1 < len(tokens):
             return ("bin", cur, "or", expr(pos + 1))
         return ("bin", cur, "or", expr(pos))  # two literals next to each other: OR (parser.rs:113-115)
 
@@ -130,7 +157,8 @@ def search_query(all_fields, search_fields, opt):
         fields = list(search_fields)
     if not fields:
         raise GeneratorError(f"All fields filtered all_fields: {all_fields} filter: {opt.get('fields')}")
-    ast = parse(opt["search_term"], (opt.get("parser_options") or {}).get("no_attributes", False))
+    po = opt.get("parser_options") or {}
+    ast = parse(opt["search_term"], po.get("no_attributes", False), po.get("no_parentheses", False), po.get("no_levensthein", False))
     request = {"search_req": simplify(to_request(expand_fields(ast, fields), opt))}
     if opt.get("facets") is not None:
         for f in opt["facets"]:

@@ -70,6 +70,14 @@ def check_expectations(case, docs, info, run):
     if "score0_gt_request" in exp:
         other = run(exp["score0_gt_request"])
         assert res.scores[0] > other.scores[0], f"{name}: {res.scores[0]} !> {other.scores[0]}"
+    if "score0_gt" in exp:  # assert_gt!(res[0].hit.score, 40.0)
+        assert float(res.scores[0]) > exp["score0_gt"], f"{name}: {res.scores[0]} !> {exp['score0_gt']}"
+    if "score0_eq_base" in exp:  # assert_eq!(res_unboosted[0].hit.score + 2.0, res_boosted[0].hit.score): an exact f32 equality
+        import numpy as np
+        e = exp["score0_eq_base"]
+        base = np.float32(run(e["request"]).scores[0])
+        want = base + np.float32(e["value"]) if e["op"] == "add" else base * np.float32(e["value"])
+        assert np.float32(res.scores[0]) == np.float32(want), f"{name}: {res.scores[0]} != {base} {e['op']} {e['value']}"
     if "identity_column" in exp:
         assert info[exp["identity_column"]]["identity"], f"{name}: {exp['identity_column']} is not an identity column"
     return res

@@ -304,11 +304,11 @@ def test_generic_kernel_also_matches_for_simple_queries():
 
 
 @pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
-                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"},
+                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_NO_PROBE": "1"},
                                  {"VQ_NO_WEIGHTED_SPANS": "1", "VQ_UNION_SPAN": "512", "VQ_BATCH_HALVES": "0", "VQ_FLAT_SMALL_CHUNKS": "1", "VQ_FLAT_CHUNKS": "4"}],
                          ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
                               "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
-                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device",
+                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "ands_on_k_scan_simple",
                               "spans_chunks_and_host_threads_as_before_the_scheduling_changes"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results."""
@@ -916,6 +916,38 @@ def test_single_requests_split_into_many_spans_merge_exactly(big_corpus):
                 assert_same(req, got, want, exact_scores="boost" not in req)  # (Log10: device log vs glibc, 1e-5)
 
 
+def test_and_probe_kernel_shapes(corpus, big_corpus):
+    """k_scan_probe (ANDs of one id-list cover and 1-3 bitmap operands): every operand order (the summation order follows the list
+    lengths, set_op.rs:393), top from 1 to beyond one candidate buffer, skip, deep pages (key_upper), leaf boosts (term scores that differ
+    per operand, a negative one: nothing may be pruned then), single requests (many spans) and batches, against the oracle."""
+    import itertools
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    for cp in (corpus, big_corpus):
+        data, meta, idx, ora = cp
+        a, b = list(meta.triples[0]), list(meta.triples[1])
+        reqs = []
+        for terms in itertools.permutations(a):
+            reqs.append(synth.req_and(list(terms)))
+        reqs += [synth.req_and([a[0], a[2]]), synth.req_and([a[2], a[1]], top=1), synth.req_and([a[0], a[1], b[0], a[2]], top=20), synth.req_and([b[2], a[0], b[0], a[1]], top=3),
+                 synth.req_and([a[0], b[1], b[2]], top=100), dict(synth.req_and(a, top=700), skip=300), dict(synth.req_and(a, top=5), skip=2000), synth.req_and(a, top=1500),
+                 dict(synth.req_and([a[1], a[2]], top=10), skip=10**7)]
+        leaf = lambda t, boost=None: {"search": dict({"path": "body", "terms": [t]}, **({"boost": boost} if boost is not None else {}))}
+        reqs += [{"search_req": {"and": {"queries": [leaf(a[0], 2.5), leaf(a[1]), leaf(a[2], 0.5)]}}, "top": 10},
+                 {"search_req": {"and": {"queries": [leaf(a[0], -1.0), leaf(a[1]), leaf(a[2])]}}, "top": 10},
+                 {"search_req": {"and": {"queries": [leaf(a[0]), leaf(a[1]), leaf(a[2], -2.0)]}}, "top": 10},
+                 {"search_req": {"and": {"queries": [leaf(a[0], 0.0), leaf(a[2], 3.0)]}}, "top": 10}]
+        wants = [ora.search_json(json.dumps(r)) for r in reqs]
+        for r, w in zip(reqs, wants):
+            assert_same(r, veloci_amd.search(r, idx), w)
+        for r, g, w in zip(reqs * 3, veloci_amd.search_batch(reqs * 3, idx), wants * 3):
+            assert_same(r, g, w)
+        for r, g, w in zip(reqs, _search_batch_over_shards(data, reqs, 2), wants):
+            assert not isinstance(g, Exception), (str(g), json.dumps(r))
+            assert_same(r, g, w)
+
+
 def test_full_size_index_matches_the_oracle():
     """BASELINE.json's full size on one GPU: the bench's 100 M-doc index (one probe triple, all side stores), every bench request
     shape once as a single request (many spans) and once inside a batch, against the CPU oracle on the same arrays; plus the
@@ -1444,7 +1476,7 @@ def test_query_generator_requests_match_the_reference_and_the_oracle():
             wide = dict(request, **extra)
             assert_same(wide, veloci_amd.search(wide, idx), ora.search_json(json.dumps(wide)))
         ran += 1
-    assert ran == 23
+    assert ran == 29
 
 
 def test_explain_records_match_the_reference_and_the_oracle():

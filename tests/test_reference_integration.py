@@ -189,7 +189,7 @@ def test_oracle_reproduces_reference_query_generator_assertions():
             plain = ora.search_json(json.dumps({k: v for k, v in case["request"].items() if k != "explain"}))
             assert plain.ids.tolist() == res.ids.tolist() and plain.scores.tolist() == res.scores.tolist() and plain.explain == [None] * len(plain.ids)
         ran += 1
-    assert ran == 23
+    assert ran == 29
 
 
 # ---------------------------------------------------------------- explain

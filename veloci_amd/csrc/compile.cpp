@@ -746,6 +746,7 @@ struct Compiler {
                 h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[e.tid];
                 h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[e.tid];
             }
+            if (!ps.td_start.empty() && ps.td_start[e.tid] >= 0) h.d_tile_dir = ps.tile_dir.as<uint32_t>() + ps.td_start[e.tid];
             uint32_t li = add_list(h);
             info.cover.push_back(li);
             info.cover_len += h.len;
@@ -2077,12 +2078,29 @@ struct Compiler {
                               cq.facets.empty() && uint64_t(idx.doc_hi) - idx.doc_lo >= 65536;
             if (pure && !force_generic) {
                 uint32_t f = 1u << 17;
+                // An AND whose cover (sparsest operand) is ONE list with a tile directory (at least 1/4096 of the docs) and whose other operands
+                // all have bitmap images: k_scan_probe streams the cover's postings — as ids and scores, even when the cover has a bitmap
+                // image of its own — and tests their bits in the operands' LDS tiles (VQ_NO_PROBE=1: k_scan_simple instead).
+                static const bool no_probe = std::getenv("VQ_NO_PROBE") != nullptr;
+                bool probe = !no_probe && cq.simple_n >= 2 && cq.ops[cq.simple_n].kind == OP_AND;
+                if (probe) {
+                    uint32_t covers = 0;
+                    for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                        const HList& l = cq.lists[cq.ops[k].list_begin];
+                        if (l.flags & LIST_COVER) {
+                            ++covers;
+                            probe = probe && l.d_tile_dir;
+                        } else probe = probe && (l.flags & LIST_BITMAP);
+                    }
+                    probe = probe && covers == 1;
+                }
                 bool seq = false;
-                for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                for (uint32_t k = 0; k < cq.simple_n && !probe; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
                     if ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP)) seq = true;
                 }
                 if (seq) f |= 1u << 16;
+                if (probe) f |= 1u << 25;
                 for (uint32_t k = 0; k < cq.simple_n; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
                     const bool cover = l.flags & LIST_COVER;
@@ -2138,7 +2156,8 @@ struct Compiler {
         }();
         const bool and_like = ((cq.simple_flags >> 18) & 1u) || (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND);  // rich, or a plain simple AND
         const bool wide_like = (cq.simple_flags >> 24) & 1u;  // k_scan_wide: its count-class pruning gains most from a long warm-up (OR over 8 terms: 27.6 k q/s at 256 Ki, 29.0 k at 512 Ki, 28.7 k at 1 Mi)
-        const uint64_t span_postings = span_env ? span_env : (and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
+        const bool probe_like = (cq.simple_flags >> 25) & 1u;  // k_scan_probe prunes by the query's shared threshold: long spans warm up once (launches of 512: 4.29 ms at 128 Ki, 3.77 ms at 1 Mi)
+        const uint64_t span_postings = span_env ? span_env : (probe_like ? 1048576 : and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
         uint32_t ww = ww_max;  // W = 32 * ww docs
         const size_t TL = size_t(L) + cq.n_temps;
         while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
@@ -2188,7 +2207,7 @@ struct Compiler {
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
         const bool simple = cq.simple_flags != 0;
         const bool wide = (cq.simple_flags >> 24) & 1u;
-        const uint64_t tile_docs = wide ? 8192 : simple ? 16384 : uint64_t(cq.tile_words) << 5;
+        const uint64_t tile_docs = wide ? 8192 : ((cq.simple_flags >> 25) & 1u) ? (1u << kTileDirShift) : simple ? 16384 : uint64_t(cq.tile_words) << 5;
         const uint64_t tiles = std::max<uint64_t>((range + tile_docs - 1) / tile_docs, 1);
         const bool seq = wide ? cq.wide.seq != 0 : simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
         const uint64_t visited = seq ? tiles : std::min<uint64_t>(std::max<uint64_t>(cover_len, 1), tiles);
@@ -2199,6 +2218,9 @@ struct Compiler {
             b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
         else if (wide) {
             for (uint32_t k = 0; k < cq.wide.n_leaves; ++k) b += ((cq.wide.bitmap_mask >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[cq.wide.leaf_list[k]].len;
+        } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's ids and scores are streamed, the operands' tiles come with 32 rank entries
+            for (uint32_t k = 0; k < cq.simple_n; ++k)
+                b += ((cq.simple_flags >> k) & 1u) ? visited * (tile_docs / 8 + 4 * (tile_docs >> kRankShift)) : 6ull * cq.lists[cq.ops[k].list_begin].len;
         } else if (simple) {
             std::vector<bool> seen(cq.lists.size(), false);
             const bool rich = (cq.simple_flags >> 18) & 1u;

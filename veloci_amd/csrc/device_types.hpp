@@ -24,6 +24,8 @@ constexpr int kMaxChildren = 16;    // children per AND/OR node (the query gener
 constexpr int kMaxLists = 64;       // lists per query in one launch
 constexpr int kMaxOps = 160;
 constexpr int kMaxSkipWhen = 4;
+constexpr uint32_t kTileDirShift = 15;  // tile directory of an id list: one entry per 32768 docs (the tile of k_scan_probe)
+constexpr uint32_t kRankShift = 9;  // rank directory of a dense list: one entry per 512 docs (16 bitmap words = one 64-byte sector)
 
 enum ListFlags : uint32_t {
     LIST_HAS_SCORES = 1u,  // posting list: f16 anchor scores, value = term_score * (f16 / 100)
@@ -32,7 +34,7 @@ enum ListFlags : uint32_t {
     LIST_F32 = 8u,         // materialised leaf (k_union): scores are final f32 values, term_score is not applied
 };
 
-struct DList {  // 48 B
+struct DList {  // 56 B
     const uint32_t* docs;    // 16-byte aligned, padded to a multiple of 4 with 0xFFFFFFFF
     const uint16_t* scores;  // f16 bits, same indexing as docs (null for id-only lists)
     uint32_t len;
@@ -41,7 +43,8 @@ struct DList {  // 48 B
     uint16_t max_raw;        // largest f16 bit pattern among the list's scores (all non-negative): bounds every posting value of the list
     uint16_t pad;
     const uint32_t* bitmap;    // LIST_BITMAP: bit (doc - bitmap_base) set for every doc of the list
-    const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + 2048 * k
+    const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + (k << kRankShift)
+    const uint32_t* tile_dir;  // lists of at least 1/4096 of the shard's docs (null otherwise): entries below doc bitmap_base + (k << kTileDirShift)
 };
 
 enum OpKind : uint8_t { OP_LEAF = 0, OP_AND = 1, OP_OR = 2, OP_BOOST1N = 3, OP_LEAFMAX = 4 };  // OP_LEAFMAX: only as a DSimple2 group kind — one leaf over several posting lists, its value the largest of the present ones (search_field.rs:455-461);  // OP_BOOST1N: unary, 1:n field boost of the leaf below (list_begin = anchors + f32 values, child_slot[0] = index into cols)
@@ -170,6 +173,7 @@ struct QHeader {
     uint32_t n_pres, off_pres, off_pres_in, n_temps;
     uint32_t off_loc_idx;    // u16 list indices referenced by the identity-column DLocFields
     uint32_t off_simple2;    // DSimple2 (simple_flags bit 18) or DWide (simple_flags bit 24)
+    uint32_t off_pool;       // != 0: the query's shared top-k pool (DPool + top_k keys), written by the spans of k_scan_probe
     uint32_t prune_n;        // k_tile_scan top-k pruning: != 0: number of lists in prune_mask; a doc present in k of them scores at most
                              // unorder(prune_gbits[k]) (monotone in k), so docs with too few of them are counted as hits but never scored
     uint64_t prune_mask;     // the leaf lists of the score tree
@@ -188,7 +192,17 @@ struct QHeader {
     uint32_t simple_flags;   // bits 0-3: leaf k is read as a bitmap; bits 8-11: leaf k is in the cover; bit 16: tiles are
                              // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
                              // bit 18: rich simple query (DSimple2); bit 19: one materialised leaf (k_scan_leaf_f32); bits 20-23: leaf k has enough
-                             // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide)
+                             // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide); bit 25: AND whose
+                             // cover is ONE id list and whose other leaves are bitmap images (k_scan_probe)
+};
+
+// The best top_k keys any span of the query has scored so far (k_scan_probe, top_k <= kPoolMaxK): a span merges its own best keys in under
+// the lock and takes the pool's k-th key as its threshold — the k-th best of ALL spans' hits, which the largest of the spans' own k-th
+// bests (QHeader::gthr alone) approaches only slowly.  Keys are unique (score bits, doc id), the merge drops duplicates.
+constexpr uint32_t kPoolMaxK = 32;
+struct DPool {
+    uint32_t lock, n;
+    // unsigned long long keys[top_k] follow (descending)
 };
 
 // Layout of the packed partial buffer (one per shard and batch; identical size on every shard):

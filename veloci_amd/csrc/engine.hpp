@@ -279,7 +279,11 @@ struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segment
     std::vector<int64_t> bm_start;      // word offset of list t inside `bitmaps`, or -1
     std::vector<int64_t> rd_start;      // entry offset of list t inside `rank_dir`, or -1
     DevBuf bitmaps;                     // u32 words; bit (doc - Index::bitmap_base)
-    DevBuf rank_dir;                    // u32: entries below bitmap_base + 2048 * k
+    DevBuf rank_dir;                    // u32: entries below bitmap_base + (k << kRankShift)
+    // lists that hold at least 1/4096 of the shard's docs get a tile directory (k_scan_probe reads a tile's postings of
+    // its cover list without searching or counting): entries below bitmap_base + (k << kTileDirShift)
+    std::vector<int64_t> td_start;      // entry offset of list t inside `tile_dir`, or -1
+    DevBuf tile_dir;
 };
 
 struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device images
@@ -360,7 +364,7 @@ constexpr int kWorkspaces = 4;  // batches in flight per index (host compile of 
 
 // Kernels the profiler accounts separately (vq_profile_json): the pre-passes, one entry per scan class, the merges.
 enum KernelId : int {
-    K_DICT_SCAN = 0, K_UNION_COUNT, K_UNION_WRITE, K_RANGE_HITS, K_COUNT_PREPASS, K_SCAN_LEAF_F32, K_SCAN_RICH, K_SCAN_AND, K_SCAN_SIMPLE, K_SCAN_UNION,
+    K_DICT_SCAN = 0, K_UNION_COUNT, K_UNION_WRITE, K_RANGE_HITS, K_COUNT_PREPASS, K_SCAN_LEAF_F32, K_SCAN_RICH, K_SCAN_PROBE, K_SCAN_AND, K_SCAN_SIMPLE, K_SCAN_UNION,
     K_SCAN_WIDE, K_TILE_SCAN, K_MERGE_SPANS, K_FINALIZE, K_FACET_SELECT, K_LOCALITY, K_BOOST1N, K_COUNT_
 };
 extern const char* const kKernelNames[K_COUNT_];
@@ -476,6 +480,7 @@ struct HList {
     uint64_t global_len = 0;
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;
+    const uint32_t* d_tile_dir = nullptr;
     int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
     int inline_val_idx = -1;  // >= 0: f32 values come from inline_vals[inline_val_idx]
 };

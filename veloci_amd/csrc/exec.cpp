@@ -40,7 +40,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 const char* const kKernelNames[K_COUNT_] = {"k_dict_scan", "k_union<count>", "k_union<write>", "k_range_hits", "k_tile_scan<count pre-pass>", "k_scan_leaf_f32",
-                                            "k_scan_simple<2,rich>", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
+                                            "k_scan_simple<2,rich>", "k_scan_probe (AND)", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
                                             "k_merge_spans", "k_finalize", "k_facet_select", "k_locality", "k_boost1n"};
 
 LaunchTimer::LaunchTimer(bool on, Workspace& w, hipStream_t s, int kernel, uint64_t layout_bytes, uint64_t algorithmic_bytes, uint64_t queries) {
@@ -133,6 +133,8 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
     h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : (cq.simple_flags >> 24) & 1u ? sizeof(DWide) : 0));
+    const bool pool = ((cq.simple_flags >> 25) & 1u) && cq.top_k <= kPoolMaxK;
+    h.off_pool = pool ? uint32_t(section(sizeof(DPool) + 8 * size_t(cq.top_k))) : 0u;
     h.n_temps = cq.n_temps;
     h.n_counts = cq.n_counts;
     h.prune_n = cq.prune_n;
@@ -161,6 +163,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!dst) return off;
 
     std::memcpy(dst, &h, sizeof h);
+    if (h.off_pool) std::memset(dst + h.off_pool, 0, sizeof(DPool) + 8 * size_t(cq.top_k));
     DList* dl = reinterpret_cast<DList*>(dst + h.off_lists);
     for (size_t i = 0; i < cq.lists.size(); ++i) {
         const HList& l = cq.lists[i];
@@ -173,6 +176,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         d.max_raw = l.max_raw;
         d.bitmap = l.d_bitmap;
         d.rank_dir = l.d_rank_dir;
+        d.tile_dir = l.d_tile_dir;
         dl[i] = d;
     }
     if (!cq.ops.empty()) std::memcpy(dst + h.off_ops, cq.ops.data(), cq.ops.size() * sizeof(DOp));
@@ -1160,7 +1164,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_f = up_span_f + tbl;
     const size_t up_span_x = up_qmap_f + tbl;   // wide queries (DWide): k_scan_wide
     const size_t up_qmap_x = up_span_x + tbl;
-    const size_t up_jobs = up_qmap_x + tbl;
+    const size_t up_span_p = up_qmap_x + tbl;   // ANDs of one id-list cover and bitmap operands: k_scan_probe
+    const size_t up_qmap_p = up_span_p + tbl;
+    const size_t up_jobs = up_qmap_p + tbl;
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
@@ -1173,6 +1179,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     bool facets_rich = false;
     uint32_t n_leaf = 0, spans_leaf = 0;
     uint32_t n_xwide = 0, spans_xwide = 0, leaves_xwide = 0, scatter_xwide = 0;
+    uint32_t n_probe = 0, spans_probe = 0, nd_probe = 1;
     uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
     {
         size_t off = 0;
@@ -1202,7 +1209,9 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t accf = 0, accx = 0;
         uint32_t* sx = reinterpret_cast<uint32_t*>(hup + up_span_x);
         uint32_t* mx = reinterpret_cast<uint32_t*>(hup + up_qmap_x);
-        uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0;
+        uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0, accp = 0;
+        uint32_t* sp = reinterpret_cast<uint32_t*>(hup + up_span_p);
+        uint32_t* mp = reinterpret_cast<uint32_t*>(hup + up_qmap_p);
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
             const CompiledQuery& cq = pb->queries[i];
@@ -1240,6 +1249,12 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
+            } else if ((cq.simple_flags >> 25) & 1u) {
+                kclass = K_SCAN_PROBE;
+                nd_probe = std::max<uint32_t>(nd_probe, cq.simple_n - 1);
+                sp[n_probe] = accp;
+                mp[n_probe++] = qi;
+                accp += cq.n_spans;
             } else if (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND) {
                 kclass = K_SCAN_AND;
                 scatter_wide = std::max<uint32_t>(scatter_wide, cq.simple_n - uint32_t(__builtin_popcount(cq.simple_flags & 0xFu)));
@@ -1274,6 +1289,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         spans_leaf = accf;
         sx[n_xwide] = accx;
         spans_xwide = accx;
+        sp[n_probe] = accp;
+        spans_probe = accp;
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -1341,6 +1358,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (spans_rich) {
         LaunchTimer t(prof, ws, st, K_SCAN_RICH, cls_layout[K_SCAN_RICH], cls_algo[K_SCAN_RICH], cls_q[K_SCAN_RICH]);
         launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, tab(up_span_r), tab(up_qmap_r), n_rich, cand_cap, keys_ptr, hits_ptr, hist_ptr, facets_rich);
+    }
+    VQ_HIP(hipGetLastError());
+    if (spans_probe) {
+        LaunchTimer t(prof, ws, st, K_SCAN_PROBE, cls_layout[K_SCAN_PROBE], cls_algo[K_SCAN_PROBE], cls_q[K_SCAN_PROBE]);
+        launch_scan_probe(st, nd_probe, spans_probe, pb->d_blobs, pb->d_blob_off, tab(up_span_p), tab(up_qmap_p), n_probe, cand_cap, keys_ptr, hits_ptr);
     }
     VQ_HIP(hipGetLastError());
     if (spans_wide) {

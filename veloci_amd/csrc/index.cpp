@@ -190,7 +190,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         ps.rd_start.assign(ps.num_tokens, -1);
         {
             const uint64_t range = uint64_t(hi) - lo;
-            const uint64_t words = idx->bitmap_words, blocks = words / 64;  // rank directory: one entry per 2048 docs
+            const uint64_t words = idx->bitmap_words, blocks = words >> (kRankShift - 5);  // rank directory: one entry per 512 docs (kRankShift)
             std::vector<uint32_t> dense;
             for (uint32_t t = 0; t < ps.num_tokens; ++t)
                 if (range >= 65536 && uint64_t(ps.len[t]) * 64 >= range) dense.push_back(t);
@@ -205,7 +205,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
                     for (uint32_t i = 0; i < ps.len[t]; ++i) {
                         const uint32_t rel = d[i] - idx->bitmap_base;
                         bw[rel >> 5] |= 1u << (rel & 31u);
-                        rd[(rel >> 11) + 1] += 1;
+                        rd[(rel >> kRankShift) + 1] += 1;
                     }
                     for (uint64_t bl = 1; bl <= blocks; ++bl) rd[bl] += rd[bl - 1];
                     ps.bm_start[t] = int64_t(words * k);
@@ -216,6 +216,29 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
                 ps.rank_dir.alloc(rdir.size() * 4 + 16);
                 ps.rank_dir.upload(rdir.data(), rdir.size() * 4);
                 idx->device_bytes += ps.bitmaps.bytes + ps.rank_dir.bytes;
+            }
+        }
+        // ---- tile directories of the lists that hold at least 1/4096 of the shard's docs (dense ones included: one can be the cover of an AND)
+        ps.td_start.assign(ps.num_tokens, -1);
+        {
+            const uint64_t range = uint64_t(hi) - lo;
+            const uint64_t tiles = (idx->bitmap_words >> (kTileDirShift - 5)) + 1;
+            std::vector<uint32_t> tdir;
+            for (uint32_t t = 0; t < ps.num_tokens; ++t) {
+                if (range < 65536 || uint64_t(ps.len[t]) * 4096 < range) continue;
+                ps.td_start[t] = int64_t(tdir.size());
+                const uint32_t* d = docs.data() + ps.start[t];
+                uint32_t i = 0;
+                for (uint64_t k = 0; k <= tiles; ++k) {
+                    const uint64_t bound = uint64_t(idx->bitmap_base) + (k << kTileDirShift);
+                    while (i < ps.len[t] && d[i] < bound) ++i;
+                    tdir.push_back(i);
+                }
+            }
+            if (!tdir.empty()) {
+                ps.tile_dir.alloc(tdir.size() * 4 + 16);
+                ps.tile_dir.upload(tdir.data(), tdir.size() * 4);
+                idx->device_bytes += ps.tile_dir.bytes;
             }
         }
         ps.docs.alloc(docs.size() * 4 + 16);

@@ -1,0 +1,686 @@
+// k_scan_probe — AND of 2..4 single-list posting leaves whose cover (the sparsest operand) is an id list and whose other operands are
+// dense lists with bitmap images: the headline shape (3-term AND, df 10 % / 3 % / 1 % of the docs).
+//
+// The doc space is walked in tiles of 32768 docs.  The cover's tile directory (DList::tile_dir) says which of its postings fall into a
+// tile: their doc ids AND f16 scores are streamed (64 lanes x 16 B + 64 x 8 B per 256 postings) — no search, no counting, every lane
+// slot holds a posting of the tile.  The dense operands' bitmap words of the tile sit in LDS (coalesced 16 B/lane loads) and every
+// cover id tests its bit there.  Nothing is computed per bitmap word: the work per tile follows the COVER's postings (about 330 per
+// tile in the headline query), not the 1024 words per operand.
+//
+// Loads are only ISSUED at the top of a tile — the next tile's words, rank entries and cover postings, the score gathers of the flush
+// in flight, the query's shared threshold — and only consumed behind the top of the next one, which waits for everything in flight
+// once: nothing in the loop waits for a load it has just issued, and a whole tile of work hides the latency.
+//
+// A doc that is in every operand is a hit.  Its score is the AND's ordered sum (set_op.rs:415-416) of the posting values
+// s_t * (f16 / 100) (search_field.rs:426).  The top-k only needs the best few, so a hit is scored only if it can still enter:
+// the sum with the cover's value known and every other operand at its list maximum (DList::max_raw) bounds the score from
+// above — f32 add and mul are monotone — and that bound is monotone in the cover's raw f16 score, so the test per posting is one
+// integer compare against `raw_min`, recomputed whenever the threshold moves.  Pruned hits are still counted (num_hits is exact).
+//
+// Hits that stay live need their index in every dense operand (the f16 score is scores[index]): rank directory entry of the doc's
+// 512-doc group (staged in LDS with the tile) + popcount of the group's words below the doc.  Ranked hits are queued and scored
+// 64 at a time, all score gathers of a flush in flight together.
+// Same results as k_scan_simple / k_tile_scan bit for bit (tests run every such query through all three).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "device_types.hpp"
+#include "kernel_common.hpp"
+#include "kernels.hpp"
+
+namespace vq {
+
+// Diagnostic build only (make stamp): time shares of the kernel's phases, summed over all waves (s_memtime ticks), and event counts.
+#ifdef VQ_STAMP
+__device__ unsigned long long g_probe_stamp[16];
+#define PS_INIT                                             \
+    unsigned long long _st0 = __builtin_amdgcn_s_memtime(); \
+    unsigned long long _acc[16] = {0};
+#define PS_AT(k)                                                \
+    {                                                           \
+        unsigned long long _st1 = __builtin_amdgcn_s_memtime(); \
+        _acc[k] += _st1 - _st0;                                 \
+        _st0 = _st1;                                            \
+    }
+#define PS_COUNT(k) _acc[k] += 1ull;
+#define PS_FLUSH                                                                                             \
+    if (threadIdx.x == 0) {                                                                                  \
+        _Pragma("unroll") for (int _k = 0; _k < 16; ++_k) if (_acc[_k]) atomicAdd(&g_probe_stamp[_k], _acc[_k]); \
+    }
+void debug_read_probe_stamps(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_stamp), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_stamp), z, sizeof z);
+    }
+}
+#else
+#define PS_INIT
+#define PS_AT(k)
+#define PS_COUNT(k)
+#define PS_FLUSH
+#endif
+
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+constexpr uint32_t kPT = 1u << kTileDirShift;   // docs per tile (32768)
+constexpr uint32_t kPTW = kPT / 32;             // bitmap words per tile and dense operand (1024)
+constexpr uint32_t kPNV = kPTW / 256;           // 16-byte vectors per lane, tile and dense operand (4)
+constexpr uint32_t kPRk = kPT >> kRankShift;    // rank directory entries per tile and dense operand (64: one per lane)
+constexpr uint32_t kPMaxR = 2;                  // rounds of 256 cover postings of a tile that are prefetched into registers (more: fetched on the spot)
+constexpr uint32_t kPU = 64 + kPMaxR * 256;     // unranked queue: live hits of the current tile, (doc - tile_lo) << 16 | raw f16 score of the cover
+constexpr uint32_t kPR = 128;                   // ranked queue
+// LDS map (u32): misc[8] | shape[32] | uq[kPU] | rdoc[kPR] rraw[kPR] ridx[ND][kPR] | tile[ND][kPTW] | rank[ND][kPRk] | cand[2 * cand_cap]
+// (the candidate buffer, the only part sized at run time, comes last: every other offset is a constant of the instantiation)
+constexpr uint32_t kPLdsShape = 8;
+constexpr uint32_t kPLdsU = kPLdsShape + 32;
+constexpr uint32_t kPLdsR = kPLdsU + kPU;
+__host__ __device__ constexpr uint32_t probe_lds_tile(uint32_t nd) { return kPLdsR + (2 + nd) * kPR; }
+__host__ __device__ constexpr uint32_t probe_lds_cand(uint32_t nd) { return probe_lds_tile(nd) + nd * (kPTW + kPRk); }
+// shape words (what only the rare paths need — scoring a flush, recomputing raw_min — lives in LDS, not in registers)
+constexpr uint32_t kShCts = 0, kShTs = 1, kShVmax = 4, kShSrc = 7, kShPrunable = 11, kShScores = 12;  // scores: 3 x u64
+
+size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd) { return (size_t)(probe_lds_cand(nd) + 2 * cand_cap) * 4 + 16; }
+
+__device__ __forceinline__ void probe_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <uint32_t ND>
+struct ProbeShape {  // the query's arithmetic, read out of LDS where it is needed
+    float cts, ts[ND], vmax[ND];
+    uint32_t src[ND + 1];  // summation position j (set_op.rs:393,415-416: others first, shortest last) -> 0 = cover, 1 + i = dense operand i
+    bool prunable;         // the bound is monotone in the cover's raw score (cover term score > 0, no inf / NaN among its scores)
+};
+template <uint32_t ND>
+__device__ __forceinline__ ProbeShape<ND> probe_shape(const uint32_t* sh) {
+    ProbeShape<ND> S;
+    S.cts = __uint_as_float(sh[kShCts]);
+#pragma unroll
+    for (uint32_t i = 0; i < ND; ++i) {
+        S.ts[i] = __uint_as_float(sh[kShTs + i]);
+        S.vmax[i] = __uint_as_float(sh[kShVmax + i]);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j <= ND; ++j) S.src[j] = sh[kShSrc + j];
+    S.prunable = sh[kShPrunable] != 0u;
+    return S;
+}
+
+// the AND's score with the cover's value `vc` and the dense operands' values `vd`, summed in the reference's order
+template <uint32_t ND>
+__device__ __forceinline__ float probe_sum(const ProbeShape<ND>& S, float vc, const float (&vd)[ND]) {
+    float score = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j <= ND; ++j) {
+        float v = vc;
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i)
+            if (S.src[j] == 1u + i) v = vd[i];
+        score += v;
+    }
+    return score;
+}
+
+// Smallest raw f16 score of a cover posting whose hit can still reach the threshold score `thr_f` (wave-wide 64-ary search over the
+// finite non-negative f16 patterns; the bound is monotone in raw).  0: everything stays live.
+template <uint32_t ND>
+__device__ __forceinline__ uint32_t probe_raw_min(const uint32_t* sh, float thr_f) {
+    const ProbeShape<ND> S = probe_shape<ND>(sh);
+    if (!S.prunable) return 0u;
+    uint32_t lo = 0u, hi = 0x7C00u;
+    const uint32_t lane = threadIdx.x;
+    while (hi > lo) {  // uniform
+        const uint32_t step = (hi - lo + 63u) >> 6;
+        const uint32_t p = lo + lane * step;
+        bool dead = false;
+        if (p < hi) dead = probe_sum<ND>(S, posting_value_fast(S.cts, (uint16_t)p), S.vmax) < thr_f;  // (p is a finite f16: the short division is exact, tests check all 2^16)  NaN threshold (none yet): never dead
+        const uint32_t c = (uint32_t)__popcll(wballot(dead));
+        if (c == 0u) hi = lo;
+        else {
+            const uint32_t last = lo + (c - 1u) * step;
+            const uint32_t nhi = last + step;
+            lo = last + 1u;
+            hi = nhi < hi ? nhi : hi;
+        }
+    }
+    return lo;
+}
+
+// Merge the span's best keys (candidate buffer, any order) into the query's pool under its (try-)lock; the pool's k-th key becomes the
+// query's threshold (QHeader::gthr) and this span's.  k <= 32: the span's keys sit in lanes 0-31, the pool's in lanes 32-63, one
+// bitonic sort over the wave, duplicates (a key this span merged in before) dropped.
+__device__ void probe_pool_merge(const CandState& cs, uint32_t k, uint8_t* pool_bytes) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t* const lock = reinterpret_cast<uint32_t*>(pool_bytes);
+    uint32_t* const pn = lock + 1;
+    unsigned long long* const pk = reinterpret_cast<unsigned long long*>(pool_bytes + sizeof(DPool));
+    __syncthreads();
+    uint32_t n_own = *cs.n;
+    n_own = n_own < cs.cap ? n_own : cs.cap;
+    n_own = n_own < 32u ? n_own : 32u;  // (after a flush the buffer holds at most k <= 32 keys unless nothing was pruned yet)
+    unsigned long long key = lane < n_own ? cs.cand[lane] : 0ull;
+    // try-lock: a span that finds the pool busy leaves its keys for its next flush (a spinning wave would only delay the holder: every
+    // attempt is a memory-side atomic on the same word)
+    uint32_t got = 0u;
+    if (lane == 0) {
+        uint32_t expected = 0u;
+        got = __hip_atomic_compare_exchange_strong(lock, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
+    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    if (!got) return;  // uniform
+    const uint32_t gn = __hip_atomic_load(pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane >= 32u && lane - 32u < gn) key = __hip_atomic_load(pk + (lane - 32u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // bitonic sort, descending over the lanes
+#pragma unroll
+    for (uint32_t size = 2; size <= 64u; size <<= 1) {
+#pragma unroll
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned long long other = shfl_u64(key, lane ^ stride);
+            const bool desc = (lane & size) == 0u || size == 64u;
+            const bool lower = (lane & stride) == 0u;
+            const unsigned long long mx = key > other ? key : other, mn = key > other ? other : key;
+            key = (lower == desc) ? mx : mn;
+        }
+    }
+    const unsigned long long prev = shfl_u64(key, (lane + 63u) & 63u);
+    const bool uniq = key != 0ull && (lane == 0u || key != prev);
+    const unsigned long long um = wballot(uniq);
+    const uint32_t pos = (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+    const uint32_t total = (uint32_t)__popcll(um);
+    if (uniq && pos < k) __hip_atomic_store(pk + pos, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long kth = 0ull;
+    if (total >= k) {  // uniform: the k-th distinct key
+        const unsigned long long km = wballot(uniq && pos == k - 1u);
+        kth = shfl_u64(key, (uint32_t)__ffsll((long long)km) - 1u);
+    }
+    if (lane == 0) {
+        __hip_atomic_store(pn, total < k ? total : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kth) atomicMax(cs.gthr, kth);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (kth > *cs.thr) *cs.thr = kth;
+    }
+    __syncthreads();
+}
+
+template <uint32_t ND>
+__device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, const uint32_t span, const uint32_t q, const uint32_t cand_cap,
+                                           unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const VQ_CONST QHeader* H = as_const<QHeader>(blob);
+    const VQ_CONST DList* gl = as_const<DList>(blob + H->off_lists);
+    const VQ_CONST DOp* gops = as_const<DOp>(blob + H->off_ops);
+    const uint32_t sflags = H->simple_flags;
+    const uint32_t top_k = H->top_k;
+    constexpr uint32_t n = ND + 1u;
+    PS_INIT
+
+    unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t* cand_n = lds + 2;
+    uint32_t* sh = lds + kPLdsShape;
+    uint32_t* uq = lds + kPLdsU;
+    uint32_t* rq = lds + kPLdsR;  // rdoc[kPR] rraw[kPR] ridx[ND][kPR]
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + probe_lds_cand(ND));
+    uint32_t* tile = lds + probe_lds_tile(ND);  // [ND][kPTW]
+    uint32_t* rank = tile + ND * kPTW;          // [ND][kPRk]
+    unsigned long long* const gthr = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr));
+    CandState cs{cand, cand_n, thr, cand_cap, gthr};
+    cs.upper = H->key_upper;
+    uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;
+    uint8_t* const pool = H->off_pool ? const_cast<uint8_t*>(blob) + H->off_pool : nullptr;
+
+    // ---- the query's shape: the cover leaf streams its postings, the others are read as bitmap images
+    const uint32_t* cdocs = nullptr;
+    const uint16_t* cscores = nullptr;
+    const uint32_t* ctdir = nullptr;
+    uint32_t clen = 0;
+    const uint32_t* d_bitmap[ND];
+    const uint32_t* d_rank[ND];
+    {
+        const uint32_t ck = (uint32_t)__ffs((int)((sflags >> 8) & 0xFu)) - 1u;
+        uint32_t role_of[4] = {0u, 0u, 0u, 0u};  // leaf k -> 0 = cover, 1 + i = dense operand i
+        uint32_t i = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < n; ++k) {
+            const VQ_CONST DList& d = gl[gops[k].list_begin];
+            if (k == ck) {
+                cdocs = d.docs;
+                cscores = d.scores;
+                ctdir = d.tile_dir;
+                clen = d.len;
+                if (lane == 0) {
+                    sh[kShCts] = __float_as_uint(d.term_score);
+                    sh[kShPrunable] = (d.term_score > 0.0f && d.max_raw < 0x7C00u) ? 1u : 0u;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < ND; ++j)
+                    if (j == i) {
+                        d_bitmap[j] = d.bitmap;
+                        d_rank[j] = d.rank_dir;
+                        if (lane == 0) {
+                            const uint16_t mr = d.max_raw;
+                            sh[kShTs + j] = __float_as_uint(d.term_score);
+                            sh[kShVmax + j] = (d.term_score > 0.0f && mr < 0x7C00u) ? __float_as_uint(posting_value(d.term_score, mr)) : 0x7F800000u;  // +inf: no bound
+                            reinterpret_cast<unsigned long long*>(sh + kShScores)[j] = (unsigned long long)(uintptr_t)d.scores;
+                        }
+                    }
+                role_of[k] = 1u + i;
+                ++i;
+            }
+        }
+        const KOp root(gops + n);
+#pragma unroll
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t k = root.and_order(j);
+            if (lane == 0) sh[kShSrc + j] = k == 0u ? role_of[0] : k == 1u ? role_of[1] : k == 2u ? role_of[2] : role_of[3];
+        }
+    }
+
+    const uint32_t n_spans = H->n_spans;
+    const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(kPT - 1u));
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(kPT - 1u));
+    const uint32_t bitmap_base = H->bitmap_base;
+    const uint32_t keys_base = H->keys_base;
+
+    if (lane == 0) {
+        *thr = __hip_atomic_load(gthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what other spans of the query have already reached
+        *cand_n = 0;
+        lds[4] = 0u;
+    }
+    __syncthreads();
+    unsigned long long thr_seen = *thr;
+    uint32_t raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(thr_seen >> 32))));
+
+    const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const VQ_GLOBAL u32x4* cd4 = as_global(reinterpret_cast<const u32x4*>(cdocs));
+    const VQ_GLOBAL u32x2* cs2 = as_global(reinterpret_cast<const u32x2*>(cscores));
+    const uint32_t nvec = (clen + 3u) >> 2;
+
+    uint32_t un = 0, rn = 0;
+    unsigned long long hits = 0;
+    unsigned long long g_prev = 0ull;
+
+    // ---- tiles of the span; a slice of the cover's tile directory rides in a register (lane l: entries below tile dir_base + l)
+    const uint32_t t_first = (span_lo - bitmap_base) >> kTileDirShift;
+    const uint32_t t_end = span_hi > span_lo ? ((span_hi - 1u - bitmap_base) >> kTileDirShift) + 1u : t_first;  // one behind the last tile
+    uint32_t dir_base = t_first;
+    auto load_dir = [&]() { return as_global(ctdir)[dir_base + lane < t_end ? dir_base + lane : t_end]; };  // (entry t_end exists: one behind the last tile)
+    uint32_t dirv = load_dir();
+    auto dir_at = [&](uint32_t tt) { return (uint32_t)__builtin_amdgcn_readlane((int)dirv, (int)(tt - dir_base)); };
+
+    // registers of the tile in flight: its words and rank entries, its cover postings (the first kPMaxR rounds)
+    u32x4 wk[ND][kPNV];
+    uint32_t rk[ND];
+    u32x4 nid[kPMaxR], cid[kPMaxR];
+    u32x2 nsc[kPMaxR], csc[kPMaxR];
+#pragma unroll
+    for (uint32_t r = 0; r < kPMaxR; ++r) {
+        nid[r] = cid[r] = kSent;
+        nsc[r] = csc[r] = u32x2{0u, 0u};
+    }
+    uint32_t pf_rounds = 0, pf_v0 = 0;
+    auto issue_tile = [&](uint32_t tt) {  // uniform; tt < t_end, dir_base <= tt, tt + 1 - dir_base < 64
+        const uint32_t e0 = dir_at(tt), e1 = dir_at(tt + 1u);
+        pf_rounds = e1 > e0 ? ((e1 - (e0 & ~3u) + 255u) >> 8) : 0u;
+        pf_v0 = e0 >> 2;
+        if (pf_rounds) {  // uniform: a tile without cover postings has no hits — nothing of it is read
+#pragma unroll
+            for (uint32_t i = 0; i < ND; ++i) {
+                const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(d_bitmap[i] + (size_t)tt * kPTW));
+#pragma unroll
+                for (uint32_t h = 0; h < kPNV; ++h) wk[i][h] = gb[h * 64u + lane];
+                rk[i] = as_global(d_rank[i])[tt * kPRk + lane];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kPMaxR; ++r) {
+                const uint32_t v = pf_v0 + r * 64u + lane;
+                nid[r] = kSent;
+                nsc[r] = u32x2{0u, 0u};
+                if (r < pf_rounds && v < nvec) {
+                    nid[r] = cd4[v];
+                    nsc[r] = cs2[v];
+                }
+            }
+        }
+    };
+
+    uint32_t tile_lo = 0;
+    // ---- scoring of the ranked queue, 64 hits at a time, WITHOUT waiting for its gathers: a flush is a little pipeline that advances one
+    // stage per tile.  Stage i has the gather of dense operand i's scores in flight; when it is consumed — a tile later, the data has
+    // long arrived — the bound is taken again with the value now known, hits that can no longer reach the threshold drop out, and the
+    // next operand's gather is issued.  After the last operand the scores are final and the keys go to the candidate buffer.
+    uint32_t f_stage = 0;  // 0: idle; i + 1: operand i's gather is in flight
+    uint32_t f_doc = 0, f_idx[ND];
+    float f_vc = 0.0f, f_vd[ND];
+    uint16_t f_r = 0;
+    bool f_alive = false;
+#pragma unroll
+    for (uint32_t i = 0; i < ND; ++i) {
+        f_idx[i] = 0u;
+        f_vd[i] = 0.0f;
+    }
+    uint32_t rhead = 0;              // the ranked queue is a ring: entries [rhead, rhead + rn) mod kPR
+    uint32_t tiles_since_merge = 8;  // pool merges are spaced out: each is a round trip to memory under a lock
+    auto flush_service = [&](const bool final) {
+        if (f_stage) {  // uniform
+            const ProbeShape<ND> S = probe_shape<ND>(sh);
+            const float thr_f = __uint_as_float(unorder_f32((uint32_t)(*thr >> 32)));  // NaN while there is no threshold: nothing is dropped
+            bool done = false;
+#pragma unroll
+            for (uint32_t i = 0; i < ND; ++i) {
+                if (!done && f_stage == i + 1u) {  // uniform
+                    done = true;
+                    f_vd[i] = posting_value(S.ts[i], f_r);
+                    if (i + 1u < ND) {
+                        constexpr uint32_t nx = 0;
+                        f_alive = f_alive && !(probe_sum<ND>(S, f_vc, f_vd) < thr_f);
+                        if (stat && lane == 0) *stat += 2u * (uint32_t)__popcll(wballot(f_alive));
+                        const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[i + 1u < ND ? i + 1u : nx]);
+                        f_r = f_alive ? as_global(sp)[f_idx[i + 1u < ND ? i + 1u : nx]] : (uint16_t)0;
+                        f_stage = i + 2u;
+                    } else {
+                        const float score = probe_sum<ND>(S, f_vc, f_vd);
+                        const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)f_doc;
+                        bool pending = f_alive && key > *thr && key < cs.upper;
+                        f_stage = 0;
+                        PS_COUNT(12)
+                        if (wballot(pending)) {  // uniform; rare once the threshold has warmed up
+                            while (true) {
+                                if (pending) {
+                                    if (key > *thr) {
+                                        uint32_t pos = atomicAdd(cs.n, 1u);
+                                        if (pos < cs.cap) {
+                                            cs.cand[pos] = key;
+                                            pending = false;
+                                        }
+                                    } else pending = false;
+                                }
+                                probe_lds_fence();
+                                if (!wballot(pending)) break;  // (one wave per workgroup: a ballot is the workgroup's vote)
+                                cand_prune(cs, top_k);
+                            }
+                            if (pool && (tiles_since_merge >= 8u || final)) {  // uniform
+                                PS_COUNT(13)
+                                tiles_since_merge = 0;
+                                probe_pool_merge(cs, top_k, pool);
+                            }
+                            const unsigned long long tn = *thr;
+                            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))));
+                            thr_seen = tn;
+                        }
+                    }
+                }
+            }
+            return;
+        }
+        if (rn >= 64u || (final && rn)) {  // uniform: start a flush — the first operand's gather goes out, nothing is waited for
+            const uint32_t count = rn < 64u ? rn : 64u;
+            probe_lds_fence();
+            f_alive = lane < count;
+            uint32_t raw = 0;
+            const uint32_t slot = (rhead + lane) & (kPR - 1u);
+            if (f_alive) {
+                f_doc = rq[slot];
+                raw = rq[kPR + slot];
+#pragma unroll
+                for (uint32_t i = 0; i < ND; ++i) f_idx[i] = rq[(2u + i) * kPR + slot];
+            }
+            f_vc = posting_value(__uint_as_float(sh[kShCts]), (uint16_t)raw);
+#pragma unroll
+            for (uint32_t i = 0; i < ND; ++i) f_vd[i] = __uint_as_float(sh[kShVmax + i]);
+            if (stat && lane == 0) *stat += 2u * count;  // gathered bytes of the span
+            const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[0]);
+            f_r = f_alive ? as_global(sp)[f_idx[0]] : (uint16_t)0;
+            f_stage = 1u;
+            rhead = (rhead + count) & (kPR - 1u);
+            rn -= count;
+        }
+    };
+    // Rank the first `cnt` (<= 64) entries of the unranked queue — live hits of the CURRENT tile, whose words are in LDS — into the ranked
+    // queue: index in dense operand i = rank directory entry of the doc's 512-doc group + set bits of the group below the doc.  The rest
+    // of the unranked queue moves to the front.
+    auto rank_some = [&](const uint32_t cnt) {
+        while (rn + cnt > kPR) flush_service(false);  // uniform, warm-up only: the ranked queue is full, the flush in flight has to finish
+        probe_lds_fence();
+        if (ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
+            const uint32_t el = lane & 31u, role = lane >> 5;
+            if (el < cnt) {
+                const uint32_t e = uq[el];
+                const uint32_t rel = e >> 16;  // doc - tile_lo
+                const uint32_t slot = (rhead + rn + el) & (kPR - 1u);
+                if (role == 0u) {
+                    rq[slot] = tile_lo + rel;
+                    rq[kPR + slot] = e & 0xFFFFu;
+                }
+                const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
+                const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
+                const uint32_t* tl = tile + role * kPTW;
+                uint32_t acc = rank[role * kPRk + g] + (uint32_t)__popc(tl[rel >> 5] & below);
+                const u32x4* gw = reinterpret_cast<const u32x4*>(tl + g * 16u);
+#pragma unroll
+                for (uint32_t v4 = 0; v4 < 4; ++v4) {
+                    const u32x4 x = gw[v4];
+                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
+                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
+                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
+                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
+                }
+                rq[(2u + role) * kPR + slot] = acc;
+            }
+        } else if (lane < cnt) {
+            const uint32_t e = uq[lane];
+            const uint32_t rel = e >> 16;  // doc - tile_lo
+            const uint32_t slot = (rhead + rn + lane) & (kPR - 1u);
+            rq[slot] = tile_lo + rel;
+            rq[kPR + slot] = e & 0xFFFFu;
+            const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
+            const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
+#pragma unroll
+            for (uint32_t i = 0; i < ND; ++i) {
+                uint32_t acc = rank[i * kPRk + g] + (uint32_t)__popc(tile[i * kPTW + (rel >> 5)] & below);
+                const u32x4* gw = reinterpret_cast<const u32x4*>(tile + i * kPTW + g * 16u);
+#pragma unroll
+                for (uint32_t v4 = 0; v4 < 4; ++v4) {
+                    const u32x4 x = gw[v4];
+                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
+                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
+                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
+                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
+                }
+                rq[(2u + i) * kPR + slot] = acc;
+            }
+        }
+        rn += cnt;
+        if (un > cnt) {  // uniform
+            const uint32_t rem = un - cnt;
+            constexpr uint32_t kMove = kPU / 64u;
+            uint32_t t[kMove];
+#pragma unroll
+            for (uint32_t r = 0; r < kMove; ++r) t[r] = r * 64u + lane < rem ? uq[cnt + r * 64u + lane] : 0u;
+            probe_lds_fence();
+#pragma unroll
+            for (uint32_t r = 0; r < kMove; ++r)
+                if (r * 64u + lane < rem) uq[r * 64u + lane] = t[r];
+        }
+        un -= cnt;
+    };
+    // one round of 256 cover postings (lane l: four consecutive ones) against the tile in LDS
+    uint32_t lo_bound = 0, width = 0;
+    struct ProbeWords {
+        uint32_t w[4];
+    };
+    auto probe_read = [&](const u32x4 d4) {  // the operands' words at the four postings of a lane (AND of the operands)
+        const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        ProbeWords pw;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const uint32_t a = (dd[c] >> 5) & (kPTW - 1u);
+            pw.w[c] = tile[a];
+#pragma unroll
+            for (uint32_t i = 1; i < ND; ++i) pw.w[c] &= tile[i * kPTW + a];
+        }
+        return pw;
+    };
+    auto probe_eval = [&](const u32x4 d4, const u32x2 s2, const ProbeWords& pw) {
+        const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        const uint32_t rw[4] = {s2.x & 0xFFFFu, s2.x >> 16, s2.y & 0xFFFFu, s2.y >> 16};
+        unsigned long long lm[4];
+        bool live[4];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const bool in = (dd[c] - lo_bound) < width;  // (the span's first and last tile are cut; the padding behind the list's end is outside too)
+            const bool surv = in && ((pw.w[c] >> (dd[c] & 31u)) & 1u);
+            hits += (unsigned long long)__popcll(wballot(surv));
+            live[c] = surv && rw[c] >= raw_min;
+            lm[c] = wballot(live[c]);
+        }
+        if (lm[0] | lm[1] | lm[2] | lm[3]) {  // uniform
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                if (live[c]) uq[un + (uint32_t)__popcll(lm[c] & ((1ull << lane) - 1ull))] = ((dd[c] - tile_lo) << 16) | rw[c];
+                un += (uint32_t)__popcll(lm[c]);
+            }
+        }
+    };
+
+    uint32_t t = t_first;
+    tile_lo = bitmap_base + (t_first << kTileDirShift);
+    if (t < t_end) issue_tile(t);
+    PS_AT(0)
+    while (t < t_end) {  // uniform
+        PS_COUNT(8)
+        // ---- top of the tile: everything in flight lands here
+        const uint32_t rounds = pf_rounds, v0 = pf_v0;
+        if (rounds) {  // uniform
+#pragma unroll
+            for (uint32_t i = 0; i < ND; ++i) {
+#pragma unroll
+                for (uint32_t h = 0; h < kPNV; ++h) reinterpret_cast<u32x4*>(tile + i * kPTW)[h * 64u + lane] = wk[i][h];
+                rank[i * kPRk + lane] = rk[i];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kPMaxR; ++r) {
+                cid[r] = nid[r];
+                csc[r] = nsc[r];
+            }
+        }
+        // ---- first everything that CONSUMES a load of the last period (the flush in flight, the shared threshold word) ...
+        PS_AT(1)
+        if (f_stage || rn >= 64u) PS_COUNT(11)
+        flush_service(false);  // takes the gather issued a tile ago, issues the next one
+        PS_AT(4)
+        if (lane == 0 && g_prev > *thr) *thr = g_prev;  // what other spans of the query have published (QHeader::gthr), asked for a tile ago
+        // ---- ... then everything the NEXT tile needs is asked for, and nothing below waits for any of it
+        if (t + 1u < t_end) {  // uniform
+            if (t + 2u - dir_base >= 64u) {  // the directory slice is used up (62 tiles): the next one (a wait, once per 62 tiles)
+                dir_base = t + 1u;
+                dirv = load_dir();
+            }
+            issue_tile(t + 1u);
+        } else pf_rounds = 0;
+        if (lane == 0) g_prev = __hip_atomic_load(gthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        probe_lds_fence();
+        {
+            const unsigned long long tn = *thr;
+            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))));  // uniform
+            thr_seen = tn;
+            ++tiles_since_merge;
+        }
+        PS_AT(5)
+#ifdef VQ_PROBE_STREAM_ONLY  // diagnostic build: the loads and the LDS fill only (what the memory side alone takes)
+        hits += (unsigned long long)__popcll(wballot((cid[0].x ^ csc[0].x ^ cid[1].y ^ csc[1].y) == 0x12345u));  // (keeps the cover loads alive)
+        if (rounds && span == 0xFFFFFFFFu) {
+#else
+        if (rounds) {  // uniform
+#endif
+            // ---- the cover's postings of the tile against the operands' words
+            const uint32_t tile_end = tile_lo + kPT;
+            const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
+            lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
+            width = tile_hi - lo_bound;
+            {  // the register rounds: every LDS read of the tile's postings goes out first, then the few hits are picked up
+                ProbeWords pw[kPMaxR];
+#pragma unroll
+                for (uint32_t r = 0; r < kPMaxR; ++r)
+                    if (r < rounds) pw[r] = probe_read(cid[r]);  // uniform
+#pragma unroll
+                for (uint32_t r = 0; r < kPMaxR; ++r)
+                    if (r < rounds) {  // uniform
+                        PS_COUNT(9)
+                        probe_eval(cid[r], csc[r], pw[r]);
+                    }
+            }
+            for (uint32_t r = kPMaxR; r < rounds; ++r) {  // a dense stretch of the cover: further rounds are fetched on the spot
+                while (un >= kPU - 256u) rank_some(64u);  // uniform: room for another round
+                const uint32_t v = v0 + r * 64u + lane;
+                u32x4 d4 = kSent;
+                u32x2 s2 = u32x2{0u, 0u};
+                if (v < nvec) {
+                    d4 = cd4[v];
+                    s2 = cs2[v];
+                }
+                PS_COUNT(9)
+                const ProbeWords pw = probe_read(d4);
+                probe_eval(d4, s2, pw);
+            }
+            PS_AT(2)
+            while (un) {  // uniform: the tile's live hits are ranked while its words are still in LDS
+                PS_COUNT(10)
+                rank_some(un < 64u ? un : 64u);
+            }
+            PS_AT(3)
+        }
+        ++t;
+        tile_lo += kPT;
+    }
+    while (f_stage || rn) flush_service(true);  // uniform: drain
+    __syncthreads();
+    cand_prune(cs, top_k);
+    {
+        const uint32_t cn = *cand_n;
+        unsigned long long* out = span_keys + (size_t)keys_base + (size_t)span * top_k;
+        for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
+    }
+    if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
+    if (lane == 0 && H->stat_off && lds[4]) atomicAdd(&num_hits[H->stat_off], (unsigned long long)lds[4]);
+    PS_AT(6)
+    PS_FLUSH
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_scan_probe(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                                                               const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                                                               uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
+                                                                                               unsigned long long* __restrict__ num_hits) {
+    uint32_t ql;
+    {
+        uint32_t lo = 0, hi = nq;
+        const uint32_t wg = blockIdx.x;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (span_base[mid] <= wg) lo = mid;
+            else hi = mid;
+        }
+        ql = lo;
+    }
+    const uint32_t span = blockIdx.x - span_base[ql];
+    const uint32_t q = qmap[ql];
+    const uint8_t* blob = blobs + blob_off[q];
+    const uint32_t n = as_const<QHeader>(blob)->simple_n;
+    if (n == 2u) probe_body<1>(blob, span, q, cand_cap, span_keys, num_hits);
+    else if (n == 3u) probe_body<2>(blob, span, q, cand_cap, span_keys, num_hits);
+    else probe_body<3>(blob, span, q, cand_cap, span_keys, num_hits);
+}
+
+// max_nd: most dense operands of a query of the launch (sizes the LDS tile area)
+void launch_scan_probe(hipStream_t st, uint32_t max_nd, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
+                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+    if (!total_spans) return;
+    hipLaunchKernelGGL(k_scan_probe, dim3(total_spans), dim3(64), scan_probe_lds_bytes(cand_cap, max_nd), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+}
+
+}  // namespace vq
