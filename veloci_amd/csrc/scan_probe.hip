@@ -324,8 +324,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         nsc[r] = csc[r] = u32x2{0u, 0u};
     }
     uint32_t pf_rounds = 0, pf_v0 = 0;
-    auto issue_tile = [&](uint32_t tt) {  // uniform; tt < t_end, dir_base <= tt, tt + 1 - dir_base < 64
-        const uint32_t e0 = dir_at(tt), e1 = dir_at(tt + 1u);
+    auto issue_tile = [&](const uint32_t tt, const uint32_t e0, const uint32_t e1) {  // uniform; tt < t_end; [e0, e1): the cover's postings in tile tt
         pf_rounds = e1 > e0 ? ((e1 - (e0 & ~3u) + 255u) >> 8) : 0u;
         pf_v0 = e0 >> 2;
         if (pf_rounds) {  // uniform: a tile without cover postings has no hits — nothing of it is read
@@ -341,7 +340,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 const uint32_t v = pf_v0 + r * 64u + lane;
                 nid[r] = kSent;
                 nsc[r] = u32x2{0u, 0u};
-                if (r < pf_rounds && v < nvec) {
+                if (r < pf_rounds && v * 4u < e1) {  // (only the lanes that hold postings of the tile; e1 <= the list's length)
                     nid[r] = cd4[v];
                     nsc[r] = cs2[v];
                 }
@@ -366,59 +365,68 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     }
     uint32_t rhead = 0;              // the ranked queue is a ring: entries [rhead, rhead + rn) mod kPR
     uint32_t tiles_since_merge = 8;  // pool merges are spaced out: each is a round trip to memory under a lock
+    // keys of scored hits -> the candidate buffer (prune when it is full, merge into the query's pool now and then, take the new threshold)
+    auto push_keys = [&](const unsigned long long key, bool pending, const bool final) {
+        if (wballot(pending)) {  // uniform; rare once the threshold has warmed up
+            while (true) {
+                if (pending) {
+                    if (key > *thr) {
+                        uint32_t pos = atomicAdd(cs.n, 1u);
+                        if (pos < cs.cap) {
+                            cs.cand[pos] = key;
+                            pending = false;
+                        }
+                    } else pending = false;
+                }
+                probe_lds_fence();
+                if (!wballot(pending)) break;  // (one wave per workgroup: a ballot is the workgroup's vote)
+                cand_prune(cs, top_k);
+            }
+            if (pool && (tiles_since_merge >= 8u || final)) {  // uniform
+                PS_COUNT(13)
+                tiles_since_merge = 0;
+                probe_pool_merge(cs, top_k, pool);
+            }
+            const unsigned long long tn = *thr;
+            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))));
+            thr_seen = tn;
+        }
+    };
+    // the last stage of a flush: the scores are final, the keys go to the candidate buffer
+    auto flush_final = [&](const ProbeShape<ND>& S, const bool final) {
+        const float score = probe_sum<ND>(S, f_vc, f_vd);
+        const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)f_doc;
+        f_stage = 0;
+        PS_COUNT(12)
+        push_keys(key, f_alive && key > *thr && key < cs.upper, final);
+    };
+    // One call per tile: the flush in flight advances by one stage, or a new flush starts.  Whatever happens, exactly ONE gather goes out, at
+    // one place, straight into f_r (idle: entry 0 of operand 0, a line every wave keeps hitting) — its register is then nowhere a temporary of
+    // some other path, which the compiler could only protect with a wait for everything in flight.
     auto flush_service = [&](const bool final) {
-        if (f_stage) {  // uniform
+        const unsigned long long* sptr = reinterpret_cast<const unsigned long long*>(sh + kShScores);
+        unsigned long long gp = sptr[0];
+        uint32_t gidx = 0u;
+        if (f_stage) {  // uniform: one more operand's value is known
             const ProbeShape<ND> S = probe_shape<ND>(sh);
             const float thr_f = __uint_as_float(unorder_f32((uint32_t)(*thr >> 32)));  // NaN while there is no threshold: nothing is dropped
-            bool done = false;
+            bool last = true;
 #pragma unroll
-            for (uint32_t i = 0; i < ND; ++i) {
-                if (!done && f_stage == i + 1u) {  // uniform
-                    done = true;
+            for (uint32_t i = 0; i < ND; ++i)
+                if (f_stage == i + 1u) {  // uniform
                     f_vd[i] = posting_value(S.ts[i], f_r);
-                    if (i + 1u < ND) {
-                        constexpr uint32_t nx = 0;
+                    if (i + 1u < ND) {  // hits that can no longer reach the threshold drop out, the next operand's gather goes out
+                        constexpr uint32_t zero = 0;
                         f_alive = f_alive && !(probe_sum<ND>(S, f_vc, f_vd) < thr_f);
                         if (stat && lane == 0) *stat += 2u * (uint32_t)__popcll(wballot(f_alive));
-                        const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[i + 1u < ND ? i + 1u : nx]);
-                        f_r = f_alive ? as_global(sp)[f_idx[i + 1u < ND ? i + 1u : nx]] : (uint16_t)0;
-                        f_stage = i + 2u;
-                    } else {
-                        const float score = probe_sum<ND>(S, f_vc, f_vd);
-                        const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)f_doc;
-                        bool pending = f_alive && key > *thr && key < cs.upper;
-                        f_stage = 0;
-                        PS_COUNT(12)
-                        if (wballot(pending)) {  // uniform; rare once the threshold has warmed up
-                            while (true) {
-                                if (pending) {
-                                    if (key > *thr) {
-                                        uint32_t pos = atomicAdd(cs.n, 1u);
-                                        if (pos < cs.cap) {
-                                            cs.cand[pos] = key;
-                                            pending = false;
-                                        }
-                                    } else pending = false;
-                                }
-                                probe_lds_fence();
-                                if (!wballot(pending)) break;  // (one wave per workgroup: a ballot is the workgroup's vote)
-                                cand_prune(cs, top_k);
-                            }
-                            if (pool && (tiles_since_merge >= 8u || final)) {  // uniform
-                                PS_COUNT(13)
-                                tiles_since_merge = 0;
-                                probe_pool_merge(cs, top_k, pool);
-                            }
-                            const unsigned long long tn = *thr;
-                            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))));
-                            thr_seen = tn;
-                        }
+                        gp = sptr[i + 1u < ND ? i + 1u : zero];
+                        gidx = f_alive ? f_idx[i + 1u < ND ? i + 1u : zero] : 0u;
+                        last = false;
                     }
                 }
-            }
-            return;
-        }
-        if (rn >= 64u || (final && rn)) {  // uniform: start a flush — the first operand's gather goes out, nothing is waited for
+            if (last) flush_final(S, final);
+            else ++f_stage;
+        } else if (rn >= 64u || (final && rn)) {  // uniform: start a flush — the first operand's gather goes out
             const uint32_t count = rn < 64u ? rn : 64u;
             probe_lds_fence();
             f_alive = lane < count;
@@ -434,18 +442,40 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 #pragma unroll
             for (uint32_t i = 0; i < ND; ++i) f_vd[i] = __uint_as_float(sh[kShVmax + i]);
             if (stat && lane == 0) *stat += 2u * count;  // gathered bytes of the span
-            const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[0]);
-            f_r = f_alive ? as_global(sp)[f_idx[0]] : (uint16_t)0;
+            gidx = f_alive ? f_idx[0] : 0u;
             f_stage = 1u;
             rhead = (rhead + count) & (kPR - 1u);
             rn -= count;
         }
+        f_r = as_global(reinterpret_cast<const uint16_t*>((uintptr_t)gp))[gidx];
+    };
+    // The ranked queue is full while a flush is still in flight (warm-up, or a dense stretch of hits): 64 entries are scored on the spot —
+    // all operands gathered at once and waited for.  (Its own code and its own registers: the pipelined flush has ONE place that issues a
+    // gather, so that gather's register is never a temporary somewhere else that the compiler would have to wait on.)
+    auto flush_sync = [&]() {
+        const ProbeShape<ND> S = probe_shape<ND>(sh);
+        probe_lds_fence();
+        const uint32_t slot = (rhead + lane) & (kPR - 1u);
+        const uint32_t doc = rq[slot];
+        const float vc = posting_value(S.cts, (uint16_t)rq[kPR + slot]);
+        float vd[ND];
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+            const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[i]);
+            vd[i] = posting_value(S.ts[i], as_global(sp)[rq[(2u + i) * kPR + slot]]);
+        }
+        if (stat && lane == 0) *stat += 2u * ND * 64u;
+        const float score = probe_sum<ND>(S, vc, vd);
+        const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+        rhead = (rhead + 64u) & (kPR - 1u);
+        rn -= 64u;
+        push_keys(key, key > *thr && key < cs.upper, false);
     };
     // Rank the first `cnt` (<= 64) entries of the unranked queue — live hits of the CURRENT tile, whose words are in LDS — into the ranked
     // queue: index in dense operand i = rank directory entry of the doc's 512-doc group + set bits of the group below the doc.  The rest
     // of the unranked queue moves to the front.
     auto rank_some = [&](const uint32_t cnt) {
-        while (rn + cnt > kPR) flush_service(false);  // uniform, warm-up only: the ranked queue is full, the flush in flight has to finish
+        while (rn + cnt > kPR) flush_sync();  // uniform, warm-up only
         probe_lds_fence();
         if (ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
             const uint32_t el = lane & 31u, role = lane >> 5;
@@ -534,10 +564,13 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) {
             const bool in = (dd[c] - lo_bound) < width;  // (the span's first and last tile are cut; the padding behind the list's end is outside too)
-            const bool surv = in && ((pw.w[c] >> (dd[c] & 31u)) & 1u);
-            hits += (unsigned long long)__popcll(wballot(surv));
-            live[c] = surv && rw[c] >= raw_min;
-            lm[c] = wballot(live[c]);
+            const bool bit = ((pw.w[c] >> (dd[c] & 31u)) & 1u) != 0u;
+            const bool strong = rw[c] >= raw_min;
+            // (ballots of the plain compares, joined as masks: a ballot of a joined bool costs two more vector instructions)
+            const unsigned long long sm = wballot(in) & wballot(bit);
+            hits += (unsigned long long)__popcll(sm);
+            lm[c] = sm & wballot(strong);
+            live[c] = in && bit && strong;
         }
         if (lm[0] | lm[1] | lm[2] | lm[3]) {  // uniform
 #pragma unroll
@@ -550,11 +583,13 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 
     uint32_t t = t_first;
     tile_lo = bitmap_base + (t_first << kTileDirShift);
-    if (t < t_end) issue_tile(t);
+    if (t < t_end) issue_tile(t, dir_at(t), dir_at(t + 1u));
     PS_AT(0)
     while (t < t_end) {  // uniform
         PS_COUNT(8)
-        // ---- top of the tile: everything in flight lands here
+        // ---- top of the tile: everything in flight lands here — one wait for all of it (vmcnt(0); the compiler's own bookkeeping sees the
+        // instruction and knows of nothing in flight behind it, so none of ITS waits can fall behind the next tile's loads)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         const uint32_t rounds = pf_rounds, v0 = pf_v0;
         if (rounds) {  // uniform
 #pragma unroll
@@ -567,22 +602,37 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             for (uint32_t r = 0; r < kPMaxR; ++r) {
                 cid[r] = nid[r];
                 csc[r] = nsc[r];
+                // (a use the compiler cannot rename away: it has to wait for the postings HERE, where everything in flight has landed — not
+                //  later, behind the next tile's loads, where its only safe wait is for all of them)
+                asm volatile("" : "+v"(cid[r]), "+v"(csc[r]));
             }
         }
         // ---- first everything that CONSUMES a load of the last period (the flush in flight, the shared threshold word) ...
+        {  // (every register a load of the last period wrote is touched here, where all of them have landed: behind this point the compiler
+           //  knows of nothing in flight, and none of its waits can fall behind the next tile's loads)
+            uint32_t fr = f_r, glo = (uint32_t)g_prev, ghi = (uint32_t)(g_prev >> 32);
+            asm volatile("" : "+v"(fr), "+v"(glo), "+v"(ghi), "+v"(dirv));
+            f_r = (uint16_t)fr;
+            g_prev = ((unsigned long long)ghi << 32) | glo;
+        }
         PS_AT(1)
-        if (f_stage || rn >= 64u) PS_COUNT(11)
-        flush_service(false);  // takes the gather issued a tile ago, issues the next one
-        PS_AT(4)
         if (lane == 0 && g_prev > *thr) *thr = g_prev;  // what other spans of the query have published (QHeader::gthr), asked for a tile ago
-        // ---- ... then everything the NEXT tile needs is asked for, and nothing below waits for any of it
-        if (t + 1u < t_end) {  // uniform
+        const bool more = t + 1u < t_end;
+        uint32_t ne0 = 0, ne1 = 0;  // the next tile's slice of the cover (directory entries)
+        if (more) {  // uniform
             if (t + 2u - dir_base >= 64u) {  // the directory slice is used up (62 tiles): the next one (a wait, once per 62 tiles)
                 dir_base = t + 1u;
                 dirv = load_dir();
             }
-            issue_tile(t + 1u);
-        } else pf_rounds = 0;
+            ne0 = dir_at(t + 1u);
+            ne1 = dir_at(t + 2u);
+        }
+        if (f_stage || rn >= 64u) PS_COUNT(11)
+        flush_service(false);  // takes the gather issued a tile ago, issues the next one (the LAST consumer of an old load: behind it only new ones go out)
+        PS_AT(4)
+        // ---- ... then everything the NEXT tile needs is asked for, and nothing below waits for any of it
+        if (more) issue_tile(t + 1u, ne0, ne1);  // uniform
+        else pf_rounds = 0;
         if (lane == 0) g_prev = __hip_atomic_load(gthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         probe_lds_fence();
         {
@@ -620,7 +670,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 const uint32_t v = v0 + r * 64u + lane;
                 u32x4 d4 = kSent;
                 u32x2 s2 = u32x2{0u, 0u};
-                if (v < nvec) {
+                if (v < nvec) {  // (a few postings of the next tile may ride along: they fail the range test)
                     d4 = cd4[v];
                     s2 = cs2[v];
                 }
@@ -638,7 +688,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         ++t;
         tile_lo += kPT;
     }
-    while (f_stage || rn) flush_service(true);  // uniform: drain
+    while (f_stage || rn) flush_service(true);  // uniform: the flush pipeline drains (these gathers are waited for where they are used)
     __syncthreads();
     cand_prune(cs, top_k);
     {
