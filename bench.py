@@ -204,7 +204,7 @@ class Bench:
             else:
                 num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(batch, index, stride=10)
             assert not status.any(), f"request failed: status {status[status != 0][:4]}"
-            return num_hits
+            return num_hits, counts, ids, scores
 
         def sync():
             torch.cuda.synchronize()
@@ -213,15 +213,15 @@ class Bench:
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        hits = None
+        last = None
         for _ in range(warmup):
-            hits = step()
+            last = step()
         index.profile_enable(os.environ.get("VQ_NO_PROFILE") != "1")  # (VQ_NO_PROFILE=1: what the event brackets and counters cost)
         index.profile_json(reset=True)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            hits = step()
+            last = step()
         sync()
         dt = time.perf_counter() - t0
         prof = index.profile_json(reset=True)
@@ -240,7 +240,8 @@ class Bench:
                 veloci_amd.search_batch([reqs[i % len(reqs)]], index)
             lat.append((time.perf_counter() - a) * 1e3)
         p50 = float(np.median(lat[10:])) if lat else None
-        return batch_size * steps / dt, dt / steps * 1e3, p50, kernel_table(prof), [int(x) for x in hits[:3]], reqs_json
+        self.last_outputs = tuple(np.array(x) for x in last)  # (num_hits, counts, ids, scores) of the LAST TIMED step: what main() diffs against the oracle
+        return batch_size * steps / dt, dt / steps * 1e3, p50, kernel_table(prof), [int(x) for x in last[0][:3]], reqs_json
 
 
 def roofline_object(table, docs, triples, batch, workload, world):
@@ -293,6 +294,7 @@ def main():
     ap.add_argument("--workload", default="and", choices=sorted(WORKLOADS),
                     help="and = the headline metric; config2 / config3 / config4 = BASELINE configs (config4: use --docs 10000000 --terms 1000000); the rest are extra shapes")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the last timed step's outputs (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of BASELINE configs #2-#4 behind the headline (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -351,8 +353,17 @@ def main():
             "roofline": roofline_object(table, args.docs, args.triples, args.batch, args.workload, world),
             "kernels": table,
         }
-        if world == 1 and not args.no_cpu and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(bench.data, bench.meta, reqs_json, args)
+        want_cpu = not args.no_cpu and args.cpu_seconds > 0
+        if world == 1 and not dist_on and args.workload in ("and", "or", "single") and (want_cpu or not args.no_parity):
+            n_tri = min(2, len(bench.meta.triples))
+            t0 = time.time()
+            ora = sample_oracle(bench.data, bench.meta, n_tri)
+            if not args.no_parity:
+                # the timed path checks itself: the last timed step's rows of the first triples against the CPU oracle (outside the timed region)
+                out["parity_checked"] = check_timed_outputs(ora, bench.last_outputs, reqs_json, bench.meta, n_tri)
+                log(f"parity: {out['parity_checked']} rows of the last timed step equal the oracle's (hit counts, ids, score bits); oracle setup + check {time.time() - t0:.1f}s")
+            if want_cpu:
+                out["cpu_baseline"] = cpu_baseline(ora, bench.data, bench.meta, reqs_json, args, n_tri)
 
     # ---- BASELINE configs #2 - #4, a few steps each (N=1): the other named shapes, same accounting
     if rank == 0 and world == 1 and not dist_on and not args.no_extra and args.workload == "and":
@@ -392,16 +403,13 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(data, meta, reqs_json, args):
-    """CPU oracle on a bounded sample: the first probe triples' posting lists, the same AND requests; >= 1000 measured queries in the
-    all-core mode (one independent query per thread: how the reference is driven by its server threads), single-thread p50 beside it."""
+def sample_oracle(data, meta, n_tri):
+    """The CPU oracle over the posting lists of the first `n_tri` probe triples (the full lists of the index, nothing else)."""
     import numpy as np
     from oracle import binding as O
     from veloci_amd.index import IndexData
-    t0 = time.time()
     path = "body.textindex.to_anchor_id_score"
     offsets, anchors, scores, _ = data.token_to_anchor_score[path]
-    n_tri = min(2, len(meta.triples))
     keep = set()
     for tri in meta.triples[:n_tri]:
         for t in tri:
@@ -419,30 +427,85 @@ def cpu_baseline(data, meta, reqs_json, args):
     sample.add_token_to_anchor_score(path, so, sa, ss)
     ora = O.OracleIndex(data.num_anchors)
     sample.load_into(ora)
+    return ora
+
+
+def check_timed_outputs(ora, outputs, reqs_json, meta, n_tri, max_distinct=8):
+    """The rows of the LAST TIMED step whose terms all lie in the sample's triples against the oracle: hit counts, doc ids and score bits.
+    -> number of rows checked; raises SystemExit(1) on the first difference (a fast wrong answer is not a result)."""
+    import numpy as np
+    num_hits, counts, ids, scores = outputs
+    kept = {t for tri in meta.triples[:n_tri] for t in tri}
+
+    def terms_of(node, out):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                if k == "terms":
+                    out.update(v)
+                else:
+                    terms_of(v, out)
+        elif isinstance(node, list):
+            for v in node:
+                terms_of(v, out)
+        return out
+
+    want = {}
+    checked = 0
+    for i, r in enumerate(reqs_json):
+        if not terms_of(r, set()) <= kept:
+            continue
+        key = json.dumps(r, sort_keys=True)
+        if key not in want:
+            if len(want) >= max_distinct:
+                continue
+            want[key] = ora.search_json(json.dumps(r))
+        w = want[key]
+        c = int(counts[i])
+        ok = int(num_hits[i]) == w.num_hits and c == len(w.ids) and np.array_equal(ids[i, :c], np.asarray(w.ids, np.uint32)) and \
+            np.array_equal(np.asarray(scores[i, :c], np.float32).view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
+        if not ok:
+            log(f"PARITY FAILURE: row {i} of the last timed step differs from the oracle: {json.dumps(r)}\n  got  {int(num_hits[i])} hits {ids[i, :c].tolist()} {scores[i, :c].tolist()}"
+                f"\n  want {w.num_hits} hits {list(w.ids)} {list(w.scores)}")
+            raise SystemExit(1)
+        checked += 1
+    return checked
+
+
+def cpu_baseline(ora, data, meta, reqs_json, args, n_tri):
+    """CPU oracle on a bounded sample: the first probe triples' posting lists, the same AND requests; >= 1000 measured queries in the
+    all-core mode (one independent query per thread: how the reference is driven by its server threads), single-thread p50 beside it."""
+    import numpy as np
+    t0 = time.time()
     sample_reqs = [json.dumps(r) for r in reqs_json[:n_tri]]
     try:
         visible = len(os.sched_getaffinity(0))
     except AttributeError:
         visible = os.cpu_count() or 1
-    # one GPU's share of the host on this pool is 16 cores (8 GPUs per node; the pool's process guard sizes worker pools to it).  More
-    # threads do not help this memory-bound path anyway: measured on the 256-thread box, 256 threads gave 15 q/s, 16 threads 56-63 q/s.
-    cores = max(1, min(visible, int(os.environ.get("VQ_CPU_THREADS", "16"))))
-    # single thread: a few queries for the latency (the budget goes to the all-core throughput run)
+    # single thread: a few queries for the latency (the budget goes to the throughput run)
     secs, lat, _ = ora.bench(sample_reqs, repeat=1, threads=1)
     per_q = secs / len(sample_reqs)
-    rep1 = max(1, int(args.cpu_seconds * 0.25 / max(per_q, 1e-6) / len(sample_reqs)))
+    rep1 = max(1, int(args.cpu_seconds * 0.2 / max(per_q, 1e-6) / len(sample_reqs)))
     secs1, lat1, _ = ora.bench(sample_reqs, repeat=rep1, threads=1)
-    # all cores: calibrate (it does not scale linearly: allocation + memory bound), then >= 1000 queries or the budget, whichever is more
-    repc = max(1, cores // len(sample_reqs))
-    secsc, _, _ = ora.bench(sample_reqs, repeat=repc, threads=cores)
-    per_rep = secsc / repc
-    repn = max(int(np.ceil(1000 / len(sample_reqs))), int(args.cpu_seconds * 0.75 / max(per_rep, 1e-6)))
-    if repn * per_rep > 4 * args.cpu_seconds:  # a slow host: stay bounded, say so in `sample`
-        repn = max(repc, int(4 * args.cpu_seconds / max(per_rep, 1e-6)))
+    # one independent query per thread, on 16 threads (one GPU's share of this pool's hosts), 64, and all visible cores (at most 128: every
+    # thread materialises its operands' hit lists, ~250 MB): the best of them is the baseline (VQ_CPU_THREADS pins one count)
+    if os.environ.get("VQ_CPU_THREADS"):
+        candidates = [max(1, min(visible, int(os.environ["VQ_CPU_THREADS"])))]
+    else:
+        candidates = sorted({max(1, min(visible, c)) for c in (16, 64, min(visible, 128))})
+    sweep = {}
+    for c in candidates:
+        repc = max(1, (2 * c) // len(sample_reqs))  # two queries per thread: the second runs on warm arenas
+        secsc, _, _ = ora.bench(sample_reqs, repeat=repc, threads=c)
+        sweep[c] = len(sample_reqs) * repc / secsc
+    cores = max(sweep, key=sweep.get)
+    per_rep = len(sample_reqs) / sweep[cores]
+    repn = max(int(np.ceil(1000 / len(sample_reqs))), int(args.cpu_seconds * 0.6 / max(per_rep, 1e-6)))
+    if repn * per_rep > 3 * args.cpu_seconds:  # a slow host: stay bounded, say so in `sample`
+        repn = max(1, int(3 * args.cpu_seconds / max(per_rep, 1e-6)))
     secsn, latn, _ = ora.bench(sample_reqs, repeat=repn, threads=cores)
     qps_n = len(sample_reqs) * repn / secsn
     log(f"cpu baseline: setup {time.time() - t0:.1f}s, 1 thread {len(sample_reqs) * rep1 / secs1:.2f} q/s, {cores} threads {qps_n:.2f} q/s over {len(sample_reqs) * repn} queries")
-    return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "cores_visible": visible, "kind": "port",
+    return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "cores_visible": visible, "kind": "port", "threads_tried_qps": {str(c): round(v, 2) for c, v in sweep.items()},
             "measured_queries": len(sample_reqs) * repn, "p50_ms_all_cores": round(float(np.median(latn)) / 1e6, 3), "p95_ms_all_cores": round(float(np.percentile(latn, 95)) / 1e6, 3),
             "single_thread_qps": round(len(sample_reqs) * rep1 / secs1, 3), "single_thread_p50_ms": round(float(np.median(lat1)) / 1e6, 3),
             "sample": f"C++ restatement of the reference algorithm (oracle/, not the Rust binary); {n_tri} of the {len(meta.triples)} probe triples, "

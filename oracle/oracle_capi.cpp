@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.  C entry points (ctypes) for the CPU oracle.
 // Index loading mirrors include/veloci_amd.h one to one (vo_ instead of vq_) so tests feed the
 // oracle and the HIP library from the same arrays.
+#include <malloc.h>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -236,6 +237,15 @@ void vo_result_free(void* r) { delete static_cast<ResultBox*>(r); }
 // Returns wall seconds; per-query latencies (ns) are written to lat_ns[n*repeat] when non-null.
 double vo_bench_search(const void* index, const char* const* jsons, const size_t* lens, size_t n, size_t repeat, int threads, uint64_t* lat_ns,
                        uint64_t* checksum) {
+    // A query over 100 M documents materialises its operands' hit lists (tens of MB each, as the reference does).  glibc hands such
+    // blocks back to the kernel on every free: with many threads the page faults of the next query then serialise on the process's
+    // address-space lock (256 threads ran 4x SLOWER than 16).  Keep them in the threads' arenas instead.
+    static const bool tuned = [] {
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, -1);
+        return true;
+    }();
+    (void)tuned;
     std::vector<Request> reqs;
     reqs.reserve(n);
     for (size_t i = 0; i < n; ++i) reqs.push_back(request_from_json_text(jsons[i], lens[i]));

@@ -1279,10 +1279,8 @@ def _search_batch_over_shards(data, reqs, shards):
     return got
 
 
-def _random_synthetic(corpus, n_requests, seed, shards=1):
-    import veloci_amd
-    from parity import assert_same
-    data, meta, idx, ora = corpus
+def _random_synthetic_requests(meta, n_requests, seed, flat=False):
+    """flat: only what the flat entry points report (no facets, top + skip within one scan's ranking)"""
     rng = np.random.default_rng(seed)
     pool = [t for tri in meta.triples for t in tri] + list(meta.extra_probes) + list(meta.background[:25])
 
@@ -1307,8 +1305,10 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
     reqs = []
     for _ in range(n_requests):
         req = {"search_req": tree(0), "top": int(rng.choice([1, 10, 40]))}
-        if rng.random() < 0.06:  # deep paging: beyond what one scan ranks
+        if not flat and rng.random() < 0.06:  # deep paging: beyond what one scan ranks
             req["top"], req["skip"] = int(rng.choice([10, 1200])), int(rng.choice([0, 1100, 2500]))
+        if flat and rng.random() < 0.2:
+            req["skip"] = int(rng.choice([1, 7]))
         if rng.random() < 0.25:
             req["filter"] = tree(1)
         if rng.random() < 0.3:
@@ -1318,11 +1318,19 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
             req["phrase_boosts"] = [{"search1": {"path": "body", "terms": [a]}, "search2": {"path": "body", "terms": [b]}}]
         if rng.random() < 0.3:
             req["text_locality"] = True
-        if rng.random() < 0.25:
+        if not flat and rng.random() < 0.25:
             req["facets"] = [{"field": str(rng.choice(["cat", "tags[]"])), "top": int(rng.choice([3, 10]))}]
         if rng.random() < 0.2:
             req["boost_term"] = [{"path": "body", "terms": [meta.background[int(rng.integers(0, 30))]], "boost": 3.0}]
         reqs.append(req)
+    return reqs
+
+
+def _random_synthetic(corpus, n_requests, seed, shards=1):
+    import veloci_amd
+    from parity import assert_same
+    data, meta, idx, ora = corpus
+    reqs = _random_synthetic_requests(meta, n_requests, seed)
     if shards == 1:
         got = veloci_amd.search_batch(reqs, idx, raise_on_error=False)
     else:
@@ -1335,6 +1343,33 @@ def _random_synthetic(corpus, n_requests, seed, shards=1):
         assert not isinstance(g, Exception), (str(g), json.dumps(req))
         assert_same(req, g, ora.search_json(json.dumps(req)))
     assert declined == 0, declined
+
+
+def test_flat_batch_of_1100_mixed_requests_matches_the_oracle(corpus):
+    """vq_search_batch_flat with more than 1024 requests — the bench's entry point: two pipelined chunks over two workspaces — against the
+    ORACLE row by row (hit counts, ids, score bits): random trees, leaf boosts, prefix / fuzzy leaves, filters, column boosts, phrase pairs,
+    text locality, boost_term, skip, plus the bench's own request shapes."""
+    import veloci_amd
+    from veloci_amd import synth
+    data, meta, idx, ora = corpus
+    a, b = list(meta.triples[0]), list(meta.triples[1])
+    reqs = _random_synthetic_requests(meta, 1000, int(os.environ.get("VQ_TEST_SEED", "1100")), flat=True)
+    reqs += [synth.req_and(a), synth.req_or(a), synth.req_single(a[0]), synth.req_and(b[::-1], top=40), synth.req_and([a[0], a[2]], top=1)] * 20
+    stride = 48
+    num_hits, counts, ids, scores, status = veloci_amd.search_batch_flat(reqs, idx, stride=stride)
+    assert len(reqs) >= 1100 and not status.any(), status[status != 0][:5]
+    cache = {}
+    for i, r in enumerate(reqs):
+        key = json.dumps(r, sort_keys=True)
+        if key not in cache:
+            cache[key] = ora.search_json(json.dumps(r))
+        w = cache[key]
+        c = int(counts[i])
+        assert int(num_hits[i]) == w.num_hits and c == len(w.ids), (i, key, int(num_hits[i]), w.num_hits, c, len(w.ids))
+        assert ids[i, :c].tolist() == list(w.ids), (i, key)
+        exact = "boost" not in r or all(bq["boost_fun"] not in ("Log10", "Log2") for bq in r["boost"])
+        if exact:
+            assert np.array_equal(scores[i, :c].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32)), (i, key, scores[i, :c].tolist(), list(w.scores))
 
 
 def test_rccl_collective_path_with_one_rank(corpus):
