@@ -213,15 +213,35 @@ class Bench:
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        last = None
-        for _ in range(warmup):
-            last = step()
+        native = searcher is not None and getattr(searcher, "native", False)
+
+        def run_steps(k):
+            """k whole steps -> the outputs of the last one.  On the in-library sharded path (vq_shard_step_begin / _end) two steps are kept in
+            flight: step i + 1 is compiled and its scans are queued before step i's exchange and merge are waited for."""
+            if not native:
+                out = None
+                for _ in range(k):
+                    out = step()
+                return out
+            out, pending = None, None
+            for _ in range(k):
+                h = searcher.step_begin(batch)
+                if pending is not None:
+                    out = searcher.step_end(pending, 10)
+                pending = h
+            if pending is not None:
+                out = searcher.step_end(pending, 10)
+            if out is not None:
+                assert not out[4].any(), f"request failed: status {out[4][out[4] != 0][:4]}"
+                out = out[:4]
+            return out
+
+        last = run_steps(warmup)
         index.profile_enable(os.environ.get("VQ_NO_PROFILE") != "1")  # (VQ_NO_PROFILE=1: what the event brackets and counters cost)
         index.profile_json(reset=True)
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            last = step()
+        last = run_steps(steps) or last
         sync()
         dt = time.perf_counter() - t0
         prof = index.profile_json(reset=True)

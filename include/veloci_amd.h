@@ -299,6 +299,33 @@ int vq_merge_partials_flat_strided(const vq_index*, vq_partial_batch* local, con
                                    size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status);
 void vq_partial_free(vq_partial_batch*);
 
+/* ---- the sharded step inside the library (no counterpart in the reference, which does not shard).
+ * One communicator per index / rank: rank 0 takes a unique id (`vq_comm_unique_id`, VQ_COMM_ID_BYTES bytes), hands it to the other ranks
+ * by whatever means the host program has, every rank calls `vq_comm_init` (ncclCommInitRank on the index's device; RCCL is loaded at run
+ * time).  From then on `vq_shard_step_flat` is one whole step on this rank: compile -> scans -> RCCL all-gather of the packed partials
+ * (hit counts + top-k keys of every query; every rank must pass the SAME requests) and all-reduce of the facet histograms -> merge ->
+ * one download; the communicator also serves the sums over the shards that some requests need before compilation (what
+ * `vq_index_set_allreduce` asks a caller for).  `vq_shard_step_begin` returns as soon as the step's work is queued, `vq_shard_step_end`
+ * delivers it: a caller that begins step i+1 before it ends step i keeps two steps in flight (the scans of one overlap the exchange and
+ * merge of the other; at most two).  Results are those of `vq_search_batch_flat` on the unsharded index, bit for bit; requests whose
+ * top + skip exceeds 1024 are declined here (page them through vq_merge_partials).
+ * `vq_comm_init_custom` takes the exchange from the caller instead (all-gather of `bytes_per_rank` bytes per rank into a rank-major
+ * buffer; in-place sum of u32 counters — both on device memory, to be ordered on `hip_stream` or finished before they return): several
+ * shards inside one process, tests. */
+#define VQ_COMM_ID_BYTES 128
+typedef struct vq_shard_step vq_shard_step;
+typedef int (*vq_allgather_fn)(void* ctx, const void* local_device, void* gathered_device, size_t bytes_per_rank, void* hip_stream);
+typedef int (*vq_allreduce_u32_fn)(void* ctx, void* inout_device, size_t count, void* hip_stream);
+int vq_comm_unique_id(void* id_out);
+int vq_comm_init(vq_index*, int nranks, int rank, const void* unique_id);
+int vq_comm_init_custom(vq_index*, int nranks, int rank, vq_allgather_fn allgather, vq_allreduce_u32_fn allreduce_u32, void* ctx);
+int vq_comm_destroy(vq_index*);
+int vq_shard_step_begin(const vq_index*, const vq_request* const* requests, size_t n, vq_shard_step** out);
+int vq_shard_step_end(vq_shard_step*, size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status); /* frees the step */
+void vq_shard_step_free(vq_shard_step*); /* a step that is given up instead of ended */
+int vq_shard_step_flat(const vq_index*, const vq_request* const* requests, size_t n, size_t stride, uint64_t* num_hits, uint32_t* counts,
+                       uint32_t* ids, float* scores, int* status);
+
 /* ------------------------------------------------------------ measurement */
 
 /* Device time (ms, HIP events on the index's stream) and launch count of the

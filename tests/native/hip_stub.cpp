@@ -41,6 +41,15 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) {
     *s = reinterpret_cast<hipStream_t>(std::malloc(8));
     return hipSuccess;
 }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned int, int) {
+    *s = reinterpret_cast<hipStream_t>(std::malloc(8));
+    return hipSuccess;
+}
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) {
+    *lo = 0;
+    *hi = -1;
+    return hipSuccess;
+}
 hipError_t hipStreamDestroy(hipStream_t s) {
     std::free(s);
     return hipSuccess;
@@ -53,6 +62,7 @@ hipError_t hipEventCreate(hipEvent_t* e) {
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { return hipEventCreate(e); }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) {
     std::free(e);
     return hipSuccess;

@@ -1372,10 +1372,119 @@ def test_flat_batch_of_1100_mixed_requests_matches_the_oracle(corpus):
             assert np.array_equal(scores[i, :c].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32)), (i, key, scores[i, :c].tolist(), list(w.scores))
 
 
-def test_rccl_collective_path_with_one_rank(corpus):
-    """dist.ShardedSearcher on the `nccl` (= RCCL) backend with a single rank: the scans run on a torch side stream handed to the
-    index (vq_index_set_stream), the packed partial is all-gathered by RCCL as a zero-copy uint8 view, the merge reads the gathered
-    buffer, the all-reduce hook goes through RCCL — everything the multi-GPU bench does, minus the other ranks."""
+def _check_flat_rows(reqs, out, ora, cache):
+    num_hits, counts, ids, scores, status = out
+    assert not status.any(), status[status != 0][:5]
+    for i, r in enumerate(reqs):
+        key = json.dumps(r, sort_keys=True)
+        if key not in cache:
+            cache[key] = ora.search_json(json.dumps({k: v for k, v in r.items() if k != "facets"}))
+        w = cache[key]
+        c = int(counts[i])
+        assert int(num_hits[i]) == w.num_hits and c == len(w.ids) and ids[i, :c].tolist() == list(w.ids), (i, key, int(num_hits[i]), w.num_hits)
+        if "boost" not in r:
+            assert np.array_equal(scores[i, :c].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32)), (i, key)
+
+
+def test_sharded_step_inside_the_library_two_shards_on_one_gpu(corpus):
+    """vq_shard_step_begin / _end (compile -> scans -> exchange -> merge inside the library) over two uneven doc-range shards that live in this
+    process, one thread each, with the exchange handed in through vq_comm_init_custom: every row equals the ORACLE's on the unsharded
+    corpus — batches of 1100 (two chunks per step on a large shard are forced by VQ_SHARD_CHUNKS in the RCCL test; here one), requests
+    with facets (their histograms are summed by the all-reduce hook), and two steps in flight (begin, begin, end, end)."""
+    import threading
+    import veloci_amd
+    from veloci_amd import synth
+    from veloci_amd.dist import LocalExchange, shard_step_begin, shard_step_end
+    data, meta, idx, ora = corpus
+    N = data.num_anchors
+    cuts = [0, N * 2 // 5, N]
+    parts = [veloci_amd.Index(data, device=0, doc_lo=cuts[i], doc_hi=cuts[i + 1]) for i in range(2)]
+    ex = LocalExchange(parts)
+    barrier = threading.Barrier(2)
+    slots, totals = [None, None], [None]
+
+    def make_hook(rank):
+        def hook(values):
+            slots[rank] = values.copy()
+            barrier.wait()
+            if rank == 0:
+                totals[0] = np.sum(np.stack(slots), axis=0, dtype=np.uint64)
+            barrier.wait()
+            values[:] = totals[0]
+            barrier.wait()
+        return hook
+
+    a = list(meta.triples[0])
+    reqs1 = _random_synthetic_requests(meta, 500, 77, flat=True) + [synth.req_and(a), synth.req_or(a), synth.req_single(a[0])] * 30
+    reqs1 += [dict(synth.req_and(a[1:]), facets=[{"field": "cat"}, {"field": "tags[]", "top": 5}]), dict(synth.req_single(a[1]), facets=[{"field": "cat", "top": 3}])] * 5
+    reqs2 = _random_synthetic_requests(meta, 300, 78, flat=True)
+    b1, b2 = veloci_amd.RequestBatch(reqs1), veloci_amd.RequestBatch(reqs2)
+    outs, errs = [None, None], []
+
+    def run(rank):
+        try:
+            parts[rank].set_allreduce(make_hook(rank))
+            s1 = shard_step_begin(parts[rank], b1)
+            s2 = shard_step_begin(parts[rank], b2)  # two steps in flight
+            o1 = shard_step_end(s1, 48)
+            o2 = shard_step_end(s2, 48)
+            s3 = shard_step_begin(parts[rank], b2)
+            o3 = shard_step_end(s3, 48)
+            outs[rank] = (o1, o2, o3)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+            barrier.abort()
+            ex.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    cache = {}
+    for rank in range(2):  # every rank holds the merged result
+        _check_flat_rows(reqs1, outs[rank][0], ora, cache)
+        _check_flat_rows(reqs2, outs[rank][1], ora, cache)
+        _check_flat_rows(reqs2, outs[rank][2], ora, cache)
+
+
+def test_sharded_step_inside_the_library_over_rccl_with_one_rank(corpus):
+    """The same step with the library's own RCCL communicator (vq_comm_unique_id / vq_comm_init; one rank: what a 1-GPU box can rehearse):
+    ncclAllGather of the partials, ncclAllReduce of the facet histograms and of the sums some requests need before compilation, one and two
+    chunks per step, two steps in flight — against the oracle."""
+    import ctypes as C
+    import veloci_amd
+    from veloci_amd import _lib, synth
+    from veloci_amd.dist import shard_step_begin, shard_step_end
+    data, meta, idx0, ora = corpus
+    idx = veloci_amd.Index(data, device=0)
+    L = _lib.lib()
+    ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    _lib.check(L.vq_comm_unique_id(ident))
+    _lib.check(L.vq_comm_init(idx.h, 1, 0, bytes(ident)))
+    a = list(meta.triples[0])
+    reqs = _random_synthetic_requests(meta, 700, 79, flat=True) + [synth.req_and(a), synth.req_or(a)] * 20
+    reqs += [dict(synth.req_and(a[1:]), facets=[{"field": "cat"}, {"field": "tags[]", "top": 5}])] * 4
+    batch = veloci_amd.RequestBatch(reqs)
+    cache = {}
+    s1 = shard_step_begin(idx, batch)
+    s2 = shard_step_begin(idx, batch)
+    _check_flat_rows(reqs, shard_step_end(s1, 48), ora, cache)
+    _check_flat_rows(reqs, shard_step_end(s2, 48), ora, cache)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    out = (np.zeros(len(reqs), np.uint64), np.zeros(len(reqs), np.uint32), np.zeros((len(reqs), 48), np.uint32), np.zeros((len(reqs), 48), np.float32), np.zeros(len(reqs), np.int32))
+    _lib.check(L.vq_shard_step_flat(idx.h, batch.arr, batch.n, 48, *[p(x) for x in out]))
+    _check_flat_rows(reqs, out, ora, cache)
+    _lib.check(L.vq_comm_destroy(idx.h))
+
+
+def test_rccl_collective_path_with_one_rank(corpus, monkeypatch):
+    """dist.ShardedSearcher on the `nccl` (= RCCL) backend with a single rank.  First the module's own exchange (VQ_PY_COLLECTIVE=1): the
+    scans run on a torch side stream handed to the index (vq_index_set_stream), the packed partial is all-gathered by RCCL as a zero-copy
+    uint8 view, the merge reads the gathered buffer, the all-reduce hook goes through RCCL.  Then the default: the library's own
+    communicator (the id travels through the process group), steps through vq_shard_step_begin / _end — what the multi-GPU bench does,
+    minus the other ranks."""
     import socket
     import torch
     import torch.distributed as dist
@@ -1391,8 +1500,9 @@ def test_rccl_collective_path_with_one_rank(corpus):
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         idx2 = veloci_amd.Index(data, device=0)
+        monkeypatch.setenv("VQ_PY_COLLECTIVE", "1")
         searcher = ShardedSearcher(idx2, always_collective=True)
-        assert searcher.stream is not None
+        assert searcher.stream is not None and not searcher.native
         t = [list(x) for x in meta.triples]
         reqs = []
         for i in range(96):
@@ -1434,6 +1544,21 @@ def test_rccl_collective_path_with_one_rank(corpus):
         v = np.array([1, 2, 2**40 + 7], dtype=np.uint64)
         searcher._sum_over_ranks(v)
         assert v.tolist() == [1, 2, 2**40 + 7]
+        # ---- the default: the exchange inside the library
+        monkeypatch.delenv("VQ_PY_COLLECTIVE")
+        idx3 = veloci_amd.Index(data, device=0)
+        native = ShardedSearcher(idx3, always_collective=True)
+        assert native.native
+        for a, b in zip(native.search_batch_flat(plain * 8, stride=25), f_want):
+            assert np.array_equal(a, b)
+        s1, s2 = native.step_begin(with_facets), native.step_begin(plain * 8)  # two steps in flight
+        for a, b in zip(native.step_end(s1, 25), m_want):
+            assert np.array_equal(a, b)
+        for a, b in zip(native.step_end(s2, 25), f_want):
+            assert np.array_equal(a, b)
+        for g, w in zip(native.search_batch(reqs), want):  # result objects still go through the module's exchange
+            assert g.num_hits == w.num_hits and list(g.ids) == list(w.ids)
+            assert sorted(map(repr, (g.facets or {}).items())) == sorted(map(repr, (w.facets or {}).items()))
     finally:
         dist.destroy_process_group()
 

@@ -21,8 +21,12 @@ SYMBOLS = [
     "vq_search_batch", "vq_search_batch_flat", "vq_search_batch_partial", "vq_partial_bytes", "vq_partial_device_ptr", "vq_partial_hist_bytes",
     "vq_partial_hist_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
     "vq_search_batch_partial_at", "vq_partial_slots", "vq_index_partial_arena_ptr", "vq_partial_total_bytes", "vq_merge_partials_flat_strided",
+    "vq_comm_unique_id", "vq_comm_init", "vq_comm_init_custom", "vq_comm_destroy", "vq_shard_step_begin", "vq_shard_step_end", "vq_shard_step_free", "vq_shard_step_flat",
     "vq_profile_read", "vq_profile_enable", "vq_profile_json", "vq_debug_div100_mismatches", "vq_version",
 ]
+COMM_ID_BYTES = 128
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLREDUCE_U32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class VelociError(RuntimeError):
@@ -122,6 +126,14 @@ def lib():
         "vq_index_partial_arena_ptr": (vp, [vp]),
         "vq_partial_total_bytes": (sz, [vp]),
         "vq_merge_partials_flat_strided": (i, [vp, vp, vp, u32, sz, sz, vp, vp, vp, vp, vp]),
+        "vq_comm_unique_id": (i, [vp]),
+        "vq_comm_init": (i, [vp, i, i, vp]),
+        "vq_comm_init_custom": (i, [vp, i, i, ALLGATHER_FN, ALLREDUCE_U32_FN, vp]),
+        "vq_comm_destroy": (i, [vp]),
+        "vq_shard_step_begin": (i, [vp, vp, sz, C.POINTER(vp)]),
+        "vq_shard_step_end": (i, [vp, sz, vp, vp, vp, vp, vp]),
+        "vq_shard_step_free": (None, [vp]),
+        "vq_shard_step_flat": (i, [vp, vp, sz, sz, vp, vp, vp, vp, vp]),
         "vq_profile_read": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]),
         "vq_profile_enable": (i, [vp, i]),
     }

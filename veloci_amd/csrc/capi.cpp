@@ -8,6 +8,9 @@
 #include <functional>
 #include <future>
 
+#include <dlfcn.h>
+#include <unistd.h>
+
 #include "engine.hpp"
 #include "text.hpp"
 
@@ -221,7 +224,7 @@ void dump_parts(std::string& s, const std::optional<std::vector<vqreq::RequestSe
 extern "C" {
 
 const char* vq_last_error(void) { return g_err.c_str(); }
-const char* vq_version(void) { return "veloci_amd 0.1 (gfx950)"; }
+const char* vq_version(void) { return "veloci_amd 0.2 (gfx950)"; }
 /* self-check (tests): inputs for which the kernels' fast a/100 differs from the correctly rounded division, over all f16 values */
 uint32_t vq_debug_div100_mismatches(void) { return vq::debug_div100_mismatches(); }
 
@@ -931,6 +934,296 @@ int vq_merge_partials_flat_strided(const vq_index* index, vq_partial_batch* loca
     });
 }
 void vq_partial_free(vq_partial_batch* p) { delete p; }
+
+// ------------------------------------------------------------------ the sharded step inside the library
+// compile -> scans (scan stream) -> all-gather of the packed partials + all-reduce of the facet histograms (RCCL, collective stream) ->
+// merge + download (finish stream): one call per step, no interpreter and no tensor library between the stages.  RCCL is loaded at run time
+// (librccl.so.1 — the copy already in the process when the caller's framework brought one).
+namespace {
+typedef struct ncclComm* ncclComm_t;
+struct NcclId {
+    char internal[VQ_COMM_ID_BYTES];
+};
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t (rccl.h)
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.h) break;
+        }
+        if (!x.h) return x;
+        auto sym = [&](const char* n) { return dlsym(x.h, n); };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        return x;
+    }();
+    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce)
+        throw VelociError(VQ_ERR_DEVICE, "RCCL (librccl.so.1) is not available: the in-library exchange of a sharded step needs it");
+    return r;
+}
+// RCCL greets on stdout when it starts up: a host program's stdout is not this library's to write to (the greeting goes to stderr)
+int quiet_stdout(const std::function<int()>& f) {
+    std::fflush(stdout);
+    const int keep = dup(1);
+    if (keep >= 0) (void)dup2(2, 1);
+    const int rc = f();
+    std::fflush(stdout);
+    if (keep >= 0) {
+        (void)dup2(keep, 1);
+        (void)close(keep);
+    }
+    return rc;
+}
+void nccl_check(int rc, const char* what) {
+    if (rc != 0) throw VelociError(VQ_ERR_DEVICE, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"));
+}
+// sums over the shards before compilation (result sizes of count pre-passes, merged list lengths): the in-library form of vq_index_set_allreduce
+int comm_sum_u64(void* ctx, uint64_t* values, size_t n) {
+    const Index& idx = *static_cast<const Index*>(ctx);
+    ShardComm& c = *idx.comm;
+    std::lock_guard<std::mutex> g(c.mu);
+    try {
+        VQ_HIP(hipSetDevice(idx.device));
+        c.red.ensure(n * 8);
+        VQ_HIP(hipMemcpyAsync(c.red.p, values, n * 8, hipMemcpyHostToDevice, c.stream));
+        nccl_check(rccl().AllReduce(c.red.p, c.red.p, n, kNcclUint64, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
+        VQ_HIP(hipMemcpyAsync(values, c.red.p, n * 8, hipMemcpyDeviceToHost, c.stream));
+        VQ_HIP(hipStreamSynchronize(c.stream));
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+void comm_setup(Index& idx, std::unique_ptr<ShardComm> c) {
+    VQ_HIP(hipSetDevice(idx.device));
+    {
+        int lo = 0, hi = 0;
+        VQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        VQ_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));  // (collectives are short and latency-bound: ahead of the next step's scans)
+    }
+    for (int k = 0; k < 2; ++k) {
+        VQ_HIP(hipEventCreateWithFlags(&c->ev_scan[k], hipEventDisableTiming));
+        VQ_HIP(hipEventCreateWithFlags(&c->ev_xchg[k], hipEventDisableTiming));
+        VQ_HIP(hipEventCreateWithFlags(&c->ev_fin[k], hipEventDisableTiming));
+    }
+    idx.comm = std::move(c);
+}
+}  // namespace
+
+vq::ShardComm::~ShardComm() {
+    if (nccl) (void)rccl().CommDestroy(static_cast<ncclComm_t>(nccl));
+    for (int k = 0; k < 2; ++k) {
+        if (ev_scan[k]) (void)hipEventDestroy(ev_scan[k]);
+        if (ev_xchg[k]) (void)hipEventDestroy(ev_xchg[k]);
+        if (ev_fin[k]) (void)hipEventDestroy(ev_fin[k]);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int vq_comm_unique_id(void* id_out) {
+    return guard([&] {
+        if (!id_out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_unique_id: null argument");
+        NcclId id;
+        nccl_check(quiet_stdout([&] { return rccl().GetUniqueId(&id); }), "ncclGetUniqueId");
+        std::memcpy(id_out, &id, sizeof id);
+    });
+}
+int vq_comm_init(vq_index* index, int nranks, int rank, const void* unique_id) {
+    return guard([&] {
+        if (!index || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_init: bad argument");
+        Index& idx = *index->idx;
+        idx.comm.reset();
+        VQ_HIP(hipSetDevice(idx.device));
+        auto c = std::make_unique<ShardComm>();
+        c->nranks = nranks;
+        c->rank = rank;
+        NcclId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        ncclComm_t comm = nullptr;
+        nccl_check(quiet_stdout([&] { return rccl().CommInitRank(&comm, nranks, id, rank); }), "ncclCommInitRank");
+        c->nccl = comm;
+        comm_setup(idx, std::move(c));
+        idx.allreduce_fn = comm_sum_u64;
+        idx.allreduce_ctx = &idx;
+    });
+}
+int vq_comm_init_custom(vq_index* index, int nranks, int rank, vq_allgather_fn allgather, vq_allreduce_u32_fn allreduce_u32, void* ctx) {
+    return guard([&] {
+        if (!index || !allgather || nranks < 1 || rank < 0 || rank >= nranks) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_init_custom: bad argument");
+        auto c = std::make_unique<ShardComm>();
+        c->nranks = nranks;
+        c->rank = rank;
+        c->allgather = allgather;
+        c->allreduce_u32 = allreduce_u32;
+        c->ctx = ctx;
+        index->idx->comm.reset();
+        comm_setup(*index->idx, std::move(c));
+    });
+}
+int vq_comm_destroy(vq_index* index) {
+    return guard([&] {
+        if (!index) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_destroy: null index");
+        Index& idx = *index->idx;
+        if (idx.comm && idx.allreduce_fn == comm_sum_u64) {
+            idx.allreduce_fn = nullptr;
+            idx.allreduce_ctx = nullptr;
+        }
+        idx.comm.reset();
+    });
+}
+
+struct vq_shard_step {
+    const Index* idx = nullptr;
+    std::vector<std::unique_ptr<PartialBatch>> pbs;
+    std::vector<size_t> first, arena_off;  // chunk c: its first request, its partial's offset inside the step's part of the arena
+    size_t n = 0, used = 0;
+    int parity = 0;
+    bool merge_queued = false;
+    ~vq_shard_step() {
+        if (idx && idx->comm && idx->comm->unmerged == this) idx->comm->unmerged = nullptr;
+    }
+};
+namespace {
+// The step's merge and download go onto the finish stream, behind its exchange.  The NEXT step's scans are ordered behind them (ev_fin): a
+// scan launch fills every wave slot of the chip at once, and a merge queued beside it would wait for slots to free up (measured: 0.8-1.5 ms
+// for a kernel that takes 8 us on an idle chip) — the GPU idles for the tens of microseconds of the exchange instead.
+void step_queue_merge(vq_shard_step& step) {
+    if (step.merge_queued) return;
+    step.merge_queued = true;
+    const Index& idx = *step.idx;
+    ShardComm& c = *idx.comm;
+    if (c.unmerged == &step) c.unmerged = nullptr;
+    if (step.used) VQ_HIP(hipStreamWaitEvent(idx.fin_stream, c.ev_xchg[step.parity], 0));
+    const uint8_t* gathered = static_cast<const uint8_t*>(c.gathered[step.parity].p);
+    for (size_t k = 0; k < step.pbs.size(); ++k)
+        finish_launch(idx, *step.pbs[k], step.used ? gathered + step.arena_off[k] : nullptr, uint32_t(c.nranks), step.used);
+    VQ_HIP(hipEventRecord(c.ev_fin[step.parity], idx.fin_stream));
+}
+}  // namespace
+
+int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests, size_t n, vq_shard_step** out) {
+    return guard([&] {
+        if (!index || !out || (n && !requests)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: null argument");
+        *out = nullptr;
+        const Index& idx = *index->idx;
+        if (!idx.comm) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: no communicator (vq_comm_init)");
+        ShardComm& c = *idx.comm;
+        static const bool timing = std::getenv("VQ_TIMING") != nullptr;
+        const auto tb0 = std::chrono::steady_clock::now();
+        VQ_HIP(hipSetDevice(idx.device));
+        std::vector<const Request*> reqs(n);
+        for (size_t i = 0; i < n; ++i) reqs[i] = requests[i] ? &requests[i]->req : nullptr;
+        if (c.unmerged) {  // the step before this one: its merge goes out first, this step's scans run behind it
+            vq_shard_step& prev = *static_cast<vq_shard_step*>(c.unmerged);
+            step_queue_merge(prev);
+            VQ_HIP(hipStreamWaitEvent(idx.stream, c.ev_fin[prev.parity], 0));
+        }
+        const auto tb1 = std::chrono::steady_clock::now();
+        auto step = std::make_unique<vq_shard_step>();
+        step->idx = &idx;
+        step->n = n;
+        step->parity = int(c.seq++ & 1u);
+        // chunks per step from the GLOBAL doc count and the world size (the same on every rank): pipelining compile against scan pays while a
+        // chunk's scan is long next to a chunk's fixed costs.  Two steps may be in flight over the four workspaces: at most two chunks each.
+        static const size_t chunks_env = [] {
+            const char* e = std::getenv("VQ_SHARD_CHUNKS");
+            return size_t(e ? std::min(2, std::max(1, std::atoi(e))) : 0);
+        }();
+        const uint64_t per_shard = uint64_t(idx.num_anchors) / uint64_t(std::max(c.nranks, 1));
+        const size_t nchunks = chunks_env ? chunks_env : (n < 512 || per_shard < 40'000'000ull) ? 1 : 2;
+        const size_t arena_base = size_t(step->parity) * (Index::kArenaBytes / 2);
+        size_t off = 0;
+        for (size_t k = 0; k < nchunks; ++k) {
+            const size_t b = n * k / nchunks, e = n * (k + 1) / nchunks;
+            if (off % 256 || arena_base + off >= arena_base + Index::kArenaBytes / 2) throw VelociError(VQ_ERR_UNSUPPORTED, "sharded step: the partial arena is too small for this batch");
+            auto pb = run_partial(idx, reqs.data() + b, e - b, step->parity * 2 + int(k), int64_t(arena_base + off));
+            if (arena_base + off + pb->layout.bytes > arena_base + Index::kArenaBytes / 2) throw VelociError(VQ_ERR_UNSUPPORTED, "sharded step: the partial arena is too small for this batch");
+            step->first.push_back(b);
+            step->arena_off.push_back(off);
+            off += (size_t(pb->layout.bytes) + 255) / 256 * 256;
+            step->pbs.push_back(std::move(pb));
+        }
+        step->used = off;
+        const auto tb2 = std::chrono::steady_clock::now();
+        // ---- the exchange: behind the step's scans, on the collective stream
+        if (off) {
+            VQ_HIP(hipEventRecord(c.ev_scan[step->parity], idx.stream));
+            VQ_HIP(hipStreamWaitEvent(c.stream, c.ev_scan[step->parity], 0));
+            uint8_t* local = idx.arena.as<uint8_t>() + arena_base;
+            c.gathered[step->parity].ensure(size_t(c.nranks) * off);
+            void* gathered = c.gathered[step->parity].p;
+            if (c.nccl) nccl_check(rccl().AllGather(local, gathered, off, kNcclUint8, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllGather");
+            else if (c.allgather(c.ctx, local, gathered, off, c.stream) != 0) throw VelociError(VQ_ERR_DEVICE, "sharded step: the caller's all-gather failed");
+            for (auto& pb : step->pbs)
+                if (pb->nq_dev && pb->layout.total_hist) {  // facet counts are additive: summed in place, read by this rank's merge
+                    void* h = pb->d_partial + pb->layout.off_hist;
+                    if (c.nccl) nccl_check(rccl().AllReduce(h, h, size_t(pb->layout.total_hist), kNcclUint32, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
+                    else if (!c.allreduce_u32 || c.allreduce_u32(c.ctx, h, size_t(pb->layout.total_hist), c.stream) != 0)
+                        throw VelociError(VQ_ERR_DEVICE, "sharded step: the caller's all-reduce failed");
+                }
+            VQ_HIP(hipEventRecord(c.ev_xchg[step->parity], c.stream));
+        }
+        c.unmerged = step.get();
+        *out = step.release();
+        if (timing) {
+            const auto tb3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[vq timing] shard step begin %.3f ms (queue the previous merge %.3f, compile + scans %.3f, exchange calls %.3f)\n", ms(tb0, tb3), ms(tb0, tb1), ms(tb1, tb2), ms(tb2, tb3));
+        }
+    });
+}
+
+int vq_shard_step_end(vq_shard_step* step_raw, size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids, float* scores, int* status) {
+    std::unique_ptr<vq_shard_step> step(step_raw);  // freed whatever happens
+    return guard([&] {
+        if (!step || (step->n && (!num_hits || !counts || !ids || !scores))) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_end: null argument");
+        const Index& idx = *step->idx;
+        ShardComm& c = *idx.comm;
+        VQ_HIP(hipSetDevice(idx.device));
+        static const bool timing = std::getenv("VQ_TIMING") != nullptr;
+        const auto te0 = std::chrono::steady_clock::now();
+        step_queue_merge(*step);
+        if (timing) {
+            VQ_HIP(hipStreamSynchronize(idx.fin_stream));
+            std::fprintf(stderr, "[vq timing] shard step end: waited %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count());
+        }
+        const uint8_t* gathered = static_cast<const uint8_t*>(c.gathered[step->parity].p);
+        for (size_t k = 0; k < step->pbs.size(); ++k) {
+            std::vector<std::unique_ptr<Result>> results;
+            std::vector<int> st;
+            std::vector<std::string> errs;
+            finish_batch(idx, *step->pbs[k], step->used ? gathered + step->arena_off[k] : nullptr, uint32_t(c.nranks), results, st, errs, step->used);
+            decline_deep(results, st, errs);
+            decline_explain(results, st, errs, "the sharded step");
+            copy_flat(results, st, errs, step->first[k], stride, num_hits, counts, ids, scores, status);
+            step->pbs[k].reset();
+        }
+        if (timing) std::fprintf(stderr, "[vq timing] shard step end total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count());
+    });
+}
+void vq_shard_step_free(vq_shard_step* step) { delete step; }
+
+int vq_shard_step_flat(const vq_index* index, const vq_request* const* requests, size_t n, size_t stride, uint64_t* num_hits, uint32_t* counts, uint32_t* ids,
+                       float* scores, int* status) {
+    vq_shard_step* step = nullptr;
+    const int rc = vq_shard_step_begin(index, requests, n, &step);
+    if (rc != VQ_OK) return rc;
+    return vq_shard_step_end(step, stride, num_hits, counts, ids, scores, status);
+}
 
 // ------------------------------------------------------------------ measurement
 int vq_profile_enable(vq_index* i, int on) {

@@ -2081,8 +2081,12 @@ struct Compiler {
                 // An AND whose cover (sparsest operand) is ONE list with a tile directory (at least 1/4096 of the docs) and whose other operands
                 // all have bitmap images: k_scan_probe streams the cover's postings — as ids and scores, even when the cover has a bitmap
                 // image of its own — and tests their bits in the operands' LDS tiles (VQ_NO_PROBE=1: k_scan_simple instead).
+                // On shards below ~40 M docs k_scan_simple is still ahead (a span is then a few dozen tiles: the probe kernel's start-up, threshold
+                // warm-up and pipeline drain weigh more — 12.5 M docs: 1.13 against 1.55 ms per 1024 queries; 25 M: 2.18 / 2.47; 50 M: 4.34 / 4.19;
+                // 100 M: 8.5 / 7.2).  VQ_PROBE_MIN_DOCS moves the line (the tests put it at 0).
                 static const bool no_probe = std::getenv("VQ_NO_PROBE") != nullptr;
-                bool probe = !no_probe && cq.simple_n >= 2 && cq.ops[cq.simple_n].kind == OP_AND;
+                static const uint64_t probe_min_docs = std::getenv("VQ_PROBE_MIN_DOCS") ? uint64_t(std::atoll(std::getenv("VQ_PROBE_MIN_DOCS"))) : 40'000'000ull;
+                bool probe = !no_probe && cq.simple_n >= 2 && cq.ops[cq.simple_n].kind == OP_AND && uint64_t(idx.doc_hi) - idx.doc_lo >= probe_min_docs;
                 if (probe) {
                     uint32_t covers = 0;
                     for (uint32_t k = 0; k < cq.simple_n; ++k) {
@@ -2157,7 +2161,9 @@ struct Compiler {
         const bool and_like = ((cq.simple_flags >> 18) & 1u) || (cq.simple_flags && cq.simple_n > 1 && cq.ops.back().kind == OP_AND);  // rich, or a plain simple AND
         const bool wide_like = (cq.simple_flags >> 24) & 1u;  // k_scan_wide: its count-class pruning gains most from a long warm-up (OR over 8 terms: 27.6 k q/s at 256 Ki, 29.0 k at 512 Ki, 28.7 k at 1 Mi)
         const bool probe_like = (cq.simple_flags >> 25) & 1u;  // k_scan_probe prunes by the query's shared threshold: long spans warm up once (launches of 512: 4.29 ms at 128 Ki, 3.77 ms at 1 Mi)
-        const uint64_t span_postings = span_env ? span_env : (probe_like ? 1048576 : and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
+        // (on a small shard the same number of spans per query is kept — a 1/8 shard with 1 Mi-posting spans would leave half the chip without a wave)
+        const uint64_t probe_span = std::min<uint64_t>(std::max<uint64_t>(range / 96, 131072), 1048576);
+        const uint64_t span_postings = span_env ? span_env : (probe_like ? probe_span : and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
         uint32_t ww = ww_max;  // W = 32 * ww docs
         const size_t TL = size_t(L) + cq.n_temps;
         while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;

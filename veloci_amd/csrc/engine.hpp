@@ -420,6 +420,25 @@ struct LaunchTimer {
 // A few persistent host threads for the per-request work of a batch (query compilation): spawning threads per chunk costs more
 // than compiling a small chunk.
 
+// The exchange step of a sharded search inside the library (vq_comm_*): RCCL — loaded at run time, one communicator per index / rank — or the
+// caller's own all-gather / all-reduce (vq_comm_init_custom: rehearsals with several shards in one process).  Collectives run on their own
+// stream between the scan stream and the finish stream, so that step i's exchange and merge overlap step i+1's scans (two steps in flight).
+struct ShardComm {
+    int nranks = 1, rank = 0;
+    void* nccl = nullptr;  // ncclComm_t
+    int (*allgather)(void* ctx, const void* local, void* gathered, size_t bytes_per_rank, void* stream) = nullptr;
+    int (*allreduce_u32)(void* ctx, void* inout, size_t count, void* stream) = nullptr;
+    void* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_xchg[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr};
+    void* unmerged = nullptr;  // the step in flight whose merge is not queued yet (vq_shard_step*)
+    DevBuf gathered[2];
+    DevBuf red;  // scratch of the sums-over-shards hook (u64)
+    uint32_t seq = 0;
+    std::mutex mu;  // the hook may be called from compile threads of two steps
+    ~ShardComm();
+};
+
 struct Index {
     int device = 0;
     // sums over all shards (vq_index_set_allreduce); null: requests that need them are declined on a sharded index
@@ -462,6 +481,7 @@ struct Index {
     // prefix's size as the shard stride.  Fixed size: a step that does not fit is told so and takes the per-chunk path.
     mutable DevBuf arena;
     static constexpr size_t kArenaBytes = 64ull << 20;
+    mutable std::unique_ptr<ShardComm> comm;  // vq_comm_init / vq_comm_init_custom
     ~Index();
     bool is_anchor_identity(const std::string& textindex_path) const;
 };
@@ -623,12 +643,17 @@ struct PartialBatch {
     uint32_t n_facet_jobs = 0;
     uint32_t total_facet_out = 0;
     bool profiled = false;
+    bool launched = false, finished = false;  // scans queued / results taken
+    bool merge_launched = false;              // finish_batch phase 1 done (merge + download queued on the finish stream)
     std::chrono::steady_clock::time_point t0;
+    ~PartialBatch();  // a batch given up before its merge waits for its scans: the workspace (pinned staging, blobs) is handed on only when the device is done with it
 };
 
 std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot = -1, int64_t arena_offset = -1);
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
                   std::vector<int>& status, std::vector<std::string>& errors, size_t shard_stride = 0);  // shard_stride: bytes between the shards'
                                                                                                          // copies in `gathered_device` (0: the partial's own size)
+// the two halves of finish_batch: queue merge + download on the finish stream (nothing is waited for) / wait for them and build the results
+void finish_launch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, size_t shard_stride = 0);
 
 }  // namespace vq

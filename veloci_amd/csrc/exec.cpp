@@ -1398,6 +1398,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     }
     VQ_HIP(hipGetLastError());
     VQ_HIP(hipEventRecord(ws.ev_done, st));
+    pb->launched = true;
     if (timing_enabled())
         std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], spans generic/simple/and/rich/union %u/%u/%u/%u/%u, pack+launch %.3f ms\n", n,
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
@@ -1747,6 +1748,69 @@ void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Res
     }
 }
 
+PartialBatch::~PartialBatch() {
+    if (ws && launched && !finished && ws->ev_done) (void)hipEventSynchronize(ws->ev_done);
+}
+
+namespace {
+struct DownLayout {  // download area: [hits u64 nq][n u32 nq][ids u32 K][scores f32 K][facet_n u32 J][facet_vals u32 F][facet_counts u32 F]
+    size_t K, J, F, o_hits, o_n, o_ids, o_scores, o_fn, o_fv, o_fc, o_stat, bytes;
+    explicit DownLayout(const PartialBatch& pb) {
+        const uint32_t nq = pb.nq_dev;
+        K = size_t(pb.layout.total_keys);
+        J = pb.n_facet_jobs;
+        F = pb.total_facet_out;
+        o_hits = 0;
+        o_n = align_up(o_hits + size_t(nq) * 8, 16);
+        o_ids = align_up(o_n + size_t(nq) * 4, 16);
+        o_scores = align_up(o_ids + K * 4, 16);
+        o_fn = align_up(o_scores + K * 4, 16);
+        o_fv = align_up(o_fn + J * 4, 16);
+        o_fc = align_up(o_fv + F * 4, 16);
+        o_stat = align_up(o_fc + F * 4, 16);  // profiling: gathered bytes per query (its own copy, straight into the pinned area)
+        bytes = align_up(o_stat + size_t(nq) * 8, 256);
+    }
+};
+}  // namespace
+
+void finish_launch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, size_t shard_stride) {
+    if (pb.merge_launched) return;
+    pb.merge_launched = true;
+    Workspace& ws = *pb.ws;
+    hipStream_t st = idx.fin_stream;
+    const PartialLayout& lay = pb.layout;
+    const uint32_t nq = pb.nq_dev;
+    VQ_HIP(hipSetDevice(idx.device));
+    const DownLayout D(pb);
+    const size_t K = D.K, J = D.J;
+    if (!nq) return;
+    const uint8_t* gathered = gathered_device ? static_cast<const uint8_t*>(gathered_device) : pb.d_partial;
+    if (!gathered_device) num_shards = 1;
+    ws.d_down.ensure(D.bytes);
+    ws.h_down.ensure(D.bytes);
+    if (st != idx.stream) VQ_HIP(hipStreamWaitEvent(st, ws.ev_done, 0));
+    uint8_t* dd = ws.d_down.as<uint8_t>();
+    const bool prof = pb.profiled;
+    {
+        LaunchTimer t(prof, ws, st, K_FINALIZE, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, nq);
+        launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, shard_stride ? shard_stride : size_t(lay.off_hist), lay, reinterpret_cast<uint32_t*>(dd + D.o_ids),
+                        reinterpret_cast<float*>(dd + D.o_scores), reinterpret_cast<uint32_t*>(dd + D.o_n), reinterpret_cast<unsigned long long*>(dd + D.o_hits));
+    }
+    VQ_HIP(hipGetLastError());
+    if (J) {
+        // the batch's own histogram area: the caller of the sharded path has summed it over the shards in place (all-reduce)
+        const uint32_t* hist = reinterpret_cast<const uint32_t*>(pb.d_partial + lay.off_hist);
+        LaunchTimer t(prof, ws, st, K_FACET_SELECT, lay.total_hist * 4, lay.total_hist * 4, J);
+        launch_facet_select(st, uint32_t(J), pb.d_facet_jobs, hist, reinterpret_cast<uint32_t*>(dd + D.o_fv), reinterpret_cast<uint32_t*>(dd + D.o_fc),
+                            reinterpret_cast<uint32_t*>(dd + D.o_fn));
+        VQ_HIP(hipGetLastError());
+    }
+    VQ_HIP(hipMemcpyAsync(ws.h_down.p, dd, D.o_stat, hipMemcpyDeviceToHost, st));
+    if (prof)  // bytes the scans read through per-hit gathers (counted by the kernels), per query — into PINNED memory: a copy into pageable memory
+               // would hold this thread until the stream gets there
+        VQ_HIP(hipMemcpyAsync(ws.h_down.as<uint8_t>() + D.o_stat, pb.d_partial + lay.off_stats, size_t(nq) * 8, hipMemcpyDeviceToHost, st));
+}
+
 void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_device, uint32_t num_shards, std::vector<std::unique_ptr<Result>>& out,
                   std::vector<int>& status, std::vector<std::string>& errors, size_t shard_stride) {
     const size_t n = pb.queries.size();
@@ -1754,52 +1818,18 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
     out.resize(n);
     status.assign(n, 0);
     errors.assign(n, std::string());
+    finish_launch(idx, pb, gathered_device, num_shards, shard_stride);
     Workspace& ws = *pb.ws;
     hipStream_t st = idx.fin_stream;
     const PartialLayout& lay = pb.layout;
     const uint32_t nq = pb.nq_dev;
-    VQ_HIP(hipSetDevice(idx.device));
-
-    // download area: [hits u64 nq][n u32 nq][ids u32 K][scores f32 K][facet_n u32 J][facet_vals u32 F][facet_counts u32 F]
-    const size_t K = size_t(lay.total_keys), J = pb.n_facet_jobs, F = pb.total_facet_out;
-    const size_t o_hits = 0;
-    const size_t o_n = align_up(o_hits + size_t(nq) * 8, 16);
-    const size_t o_ids = align_up(o_n + size_t(nq) * 4, 16);
-    const size_t o_scores = align_up(o_ids + K * 4, 16);
-    const size_t o_fn = align_up(o_scores + K * 4, 16);
-    const size_t o_fv = align_up(o_fn + J * 4, 16);
-    const size_t o_fc = align_up(o_fv + F * 4, 16);
-    const size_t down_bytes = align_up(o_fc + F * 4, 256);
-
+    const DownLayout D(pb);
+    const size_t o_hits = D.o_hits, o_n = D.o_n, o_ids = D.o_ids, o_scores = D.o_scores, o_fn = D.o_fn, o_fv = D.o_fv, o_fc = D.o_fc;
     if (nq) {
-        const uint8_t* gathered = gathered_device ? static_cast<const uint8_t*>(gathered_device) : pb.d_partial;
-        if (!gathered_device) num_shards = 1;
-        ws.d_down.ensure(down_bytes);
-        ws.h_down.ensure(down_bytes);
-        if (st != idx.stream) VQ_HIP(hipStreamWaitEvent(st, ws.ev_done, 0));
-        uint8_t* dd = ws.d_down.as<uint8_t>();
         const bool prof = pb.profiled;
-        {
-            LaunchTimer t(prof, ws, st, K_FINALIZE, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, uint64_t(num_shards) * (K * 8 + nq * 8) + K * 8, nq);
-            launch_finalize(st, nq, pb.d_blobs, pb.d_blob_off, gathered, num_shards, shard_stride ? shard_stride : size_t(lay.off_hist), lay, reinterpret_cast<uint32_t*>(dd + o_ids),
-                            reinterpret_cast<float*>(dd + o_scores), reinterpret_cast<uint32_t*>(dd + o_n), reinterpret_cast<unsigned long long*>(dd + o_hits));
-        }
-        VQ_HIP(hipGetLastError());
-        if (J) {
-            // the batch's own histogram area: the caller of the sharded path has summed it over the shards in place (all-reduce)
-            const uint32_t* hist = reinterpret_cast<const uint32_t*>(pb.d_partial + lay.off_hist);
-            LaunchTimer t(prof, ws, st, K_FACET_SELECT, lay.total_hist * 4, lay.total_hist * 4, J);
-            launch_facet_select(st, uint32_t(J), pb.d_facet_jobs, hist, reinterpret_cast<uint32_t*>(dd + o_fv), reinterpret_cast<uint32_t*>(dd + o_fc),
-                                reinterpret_cast<uint32_t*>(dd + o_fn));
-            VQ_HIP(hipGetLastError());
-        }
-        VQ_HIP(hipMemcpyAsync(ws.h_down.p, dd, down_bytes, hipMemcpyDeviceToHost, st));
-        std::vector<uint64_t> gathered_bytes;
-        if (prof) {  // bytes the scans read through per-hit gathers (counted by the kernels), per query
-            gathered_bytes.resize(nq);
-            VQ_HIP(hipMemcpyAsync(gathered_bytes.data(), pb.d_partial + lay.off_stats, size_t(nq) * 8, hipMemcpyDeviceToHost, st));
-        }
         VQ_HIP(hipStreamSynchronize(st));
+        const uint64_t* gathered_bytes = reinterpret_cast<const uint64_t*>(ws.h_down.as<uint8_t>() + D.o_stat);
+        pb.finished = true;
         if (prof) {
             std::lock_guard<std::mutex> g(idx.profile_mutex);
             Profile& P = idx.profile;

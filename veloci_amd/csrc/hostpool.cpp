@@ -42,14 +42,21 @@ void HostPool::worker() {
         }
         while ((g = generation_.load(std::memory_order_acquire)) == seen) futex_wait(&generation_, seen);
         if (stop_.load()) return;
-        inside_.fetch_add(1, std::memory_order_acq_rel);
+        // (seq_cst on the inside_ / ticket_ pair, on both sides: the worker's "I am inside" must be visible before it reads the ticket, the
+        //  runner's "closed" before it reads inside_ — a store followed by a load of another word needs more than release / acquire)
+        inside_.fetch_add(1, std::memory_order_seq_cst);
         while (true) {
-            uint64_t t = ticket_.load(std::memory_order_acquire);
+            uint64_t t = ticket_.load(std::memory_order_seq_cst);
             if (t == kClosed || uint32_t(t >> 32) != g) break;
             const size_t part = size_t(t & 0xFFFFFFFFull);
             if (part >= parts_) break;
             if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
-            (*fn_)(part);
+            try {
+                (*fn_)(part);
+            } catch (...) {  // kept for the caller of run(): a worker must neither die with it nor leave the part uncounted
+                std::lock_guard<std::mutex> g2(err_mu_);
+                if (!error_) error_ = std::current_exception();
+            }
             if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 done_word_.store(1, std::memory_order_release);
                 futex_wake_all(&done_word_);
@@ -76,16 +83,29 @@ void HostPool::run(size_t parts, const std::function<void(size_t)>& fn) {
         const size_t part = size_t(t & 0xFFFFFFFFull);
         if (part >= parts) break;
         if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
-        fn(part);
+        try {
+            fn(part);
+        } catch (...) {
+            std::lock_guard<std::mutex> g2(err_mu_);
+            if (!error_) error_ = std::current_exception();
+        }
         if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) done_word_.store(1, std::memory_order_release);
     }
     for (int spin = 0; done_word_.load(std::memory_order_acquire) == 0; ++spin) {
         if (spin < 4000) __builtin_ia32_pause();
         else futex_wait(&done_word_, 0);
     }
-    ticket_.store(kClosed, std::memory_order_release);
-    while (inside_.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // nobody still looks at fn_ / parts_ (or holds &fn)
+    ticket_.store(kClosed, std::memory_order_seq_cst);
+    while (inside_.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();  // nobody still looks at fn_ / parts_ (or holds &fn)
     fn_ = nullptr;
+    if (error_) {  // the first exception of any part, rethrown on the calling thread once every part is accounted for
+        std::exception_ptr e;
+        {
+            std::lock_guard<std::mutex> g2(err_mu_);
+            std::swap(e, error_);
+        }
+        std::rethrow_exception(e);
+    }
 }
 
 }  // namespace vq

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -31,6 +32,8 @@ private:
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t parts_ = 0;
     std::atomic<bool> stop_{false};
+    std::mutex err_mu_;
+    std::exception_ptr error_;  // the first exception thrown by a part of the running job (rethrown by run())
 };
 
 }  // namespace vq

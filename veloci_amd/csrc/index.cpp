@@ -115,7 +115,11 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
     idx->doc_hi = b.doc_hi;
     idx->columns = b.columns;
     VQ_HIP(hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking));
-    VQ_HIP(hipStreamCreateWithFlags(&idx->own_fin_stream, hipStreamNonBlocking));
+    {  // merges and downloads are short and somebody waits for them: ahead of the scans of the next batch wherever a wave slot frees up
+        int lo = 0, hi = 0;
+        VQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        VQ_HIP(hipStreamCreateWithPriority(&idx->own_fin_stream, hipStreamNonBlocking, hi));
+    }
     VQ_HIP(hipStreamCreateWithFlags(&idx->pre_stream, hipStreamNonBlocking));
     idx->stream = idx->own_stream;
     idx->fin_stream = idx->own_fin_stream;

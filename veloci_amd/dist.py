@@ -5,6 +5,7 @@ New surface — the reference has no sharding.  The collective is the only excha
 per batch each rank contributes `PartialBatch.nbytes` bytes to one all-gather (top-(top+skip) keys and hit counts
 of every query, identical in size on every rank) and sums the batch's facet histograms with one all-reduce.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -104,6 +105,23 @@ class ShardedSearcher:
         self._garbage = []  # finished partials: freed while the NEXT step's scan runs (destroying 1024 compiled queries takes 0.14 ms)
         from . import _lib
         self.slots = int(_lib.lib().vq_partial_slots())
+        # The step itself runs inside the library when the ranks talk RCCL: rank 0 takes a communicator id, the process group carries it to
+        # the others, every rank joins (vq_comm_init) — from then on a step is one or two C calls (VQ_PY_COLLECTIVE=1: the older path, where
+        # this module drives partial -> torch.distributed all-gather -> merge).
+        self.native = bool(self.collective and dist.get_backend(group) == "nccl" and not os.environ.get("VQ_PY_COLLECTIVE"))
+        if self.native:
+            L = _lib.lib()
+            rank = dist.get_rank(group)
+            ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+                _lib.check(L.vq_comm_unique_id(buf))
+                ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            ident = ident.cuda()
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            raw = bytes(ident.cpu().numpy().tobytes())
+            _lib.check(L.vq_comm_init(index.h, self.world, rank, raw))
+            return
         if self.collective and dist.get_backend(group) == "nccl":
             # scans on one side stream, RCCL all-gather + merge on another that waits for the batch's scan through an event:
             # no host synchronisation between the shard scan and the collective.  (Not torch's default stream: its handle
@@ -181,24 +199,20 @@ class ShardedSearcher:
         import torch.distributed as dist
         from .search import PartialBatch
         from . import _lib
+        # Which path a step takes is decided BEFORE anything is scanned and from rank-invariant facts only (the requests are the same on every
+        # rank): steps with facet histograms take the per-chunk path (their histograms are summed by an all-reduce per chunk).  A partial that
+        # does not fit the arena — or any other failure while the chunks are queued — is an error of the step on every rank alike, never a
+        # silent switch of path on one of them (the ranks' collectives would no longer match).
+        if any(sb.has_facets for sb in subs):
+            return False
         pbs, arena_off = [], 0
-        try:
-            for c, sb in enumerate(subs):
-                pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)
-                if c == 0:
-                    self._free_finished()
-                pbs.append(pb)
-                arena_off += (pb.total_nbytes + 255) // 256 * 256
-        except _lib.VelociError as e:
-            if e.kind != "Unsupported":
-                raise
-            for pb in pbs:
-                pb.close()
-            return False
-        if any(pb.hist_nbytes for pb in pbs):
-            for pb in pbs:
-                pb.close()
-            return False
+        for c, sb in enumerate(subs):
+            pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)
+            if c == 0:
+                self._free_finished()
+            pbs.append(pb)
+            arena_off += (pb.total_nbytes + 255) // 256 * 256
+        assert not any(pb.hist_nbytes for pb in pbs)
         self._ev = (self._ev + 1) % len(self._events)
         scanned = self._events[self._ev]
         scanned.record(self.stream)
@@ -242,12 +256,23 @@ class ShardedSearcher:
         return results
 
 
+    def step_begin(self, requests):
+        """Queue a whole step (native path); at most two steps may be in flight: begin(i + 1) before end(i)."""
+        from .search import RequestBatch
+        batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
+        return shard_step_begin(self.index, batch)
+
+    def step_end(self, step, stride=10):
+        return shard_step_end(step, stride)
+
     def search_batch_flat(self, requests, stride=10, chunks=None):
         """Flat-output variant (see veloci_amd.search_batch_flat): no per-result Python objects.  A large batch runs as
         a pipeline of chunks over the index's two workspaces: the host compiles chunk c+1 while the GPU scans chunk c;
         every chunk has its own all-gather (equal sizes on all ranks by construction)."""
         from .search import PartialBatch, RequestBatch
         batch = requests if isinstance(requests, RequestBatch) else RequestBatch(requests)
+        if self.native:
+            return self.step_end(self.step_begin(batch), stride)
         if chunks is None:
             # chunks per step, from the GLOBAL doc count and the world size (identical on every rank).  Pipelining pays while a chunk's scan is long
             # next to the fixed cost of a chunk (compile hand-over, launch gaps; 256-query launches also run at a lower rate than 1024-query ones
@@ -283,6 +308,77 @@ class ShardedSearcher:
         while inflight:
             finish(*inflight.pop(0))
         return out
+
+
+class LocalExchange:
+    """The exchange of `vq_comm_init_custom` for several doc-range shards living in ONE process, one thread per shard (tests, rehearsals on a
+    single GPU): an all-gather and a u32 sum over device buffers, done with copies between barriers."""
+
+    def __init__(self, indexes):
+        import threading
+        from . import _lib
+        self.n = len(indexes)
+        self.barrier = threading.Barrier(self.n)
+        self.slots = [None] * self.n
+        self._keep = []
+        L = _lib.lib()
+        for rank, index in enumerate(indexes):
+            ag = _lib.ALLGATHER_FN(lambda ctx, local, gathered, nbytes, stream, rank=rank: self._allgather(rank, local, gathered, nbytes))
+            ar = _lib.ALLREDUCE_U32_FN(lambda ctx, inout, count, stream, rank=rank: self._allreduce(rank, inout, count))
+            self._keep += [ag, ar]
+            _lib.check(L.vq_comm_init_custom(index.h, self.n, rank, ag, ar, None))
+
+    def _allgather(self, rank, local, gathered, nbytes):
+        try:
+            torch.cuda.synchronize()
+            self.slots[rank] = (local, nbytes)
+            self.barrier.wait()
+            out = device_view(gathered, self.n * nbytes)
+            for r, (ptr, nb) in enumerate(self.slots):
+                assert nb == nbytes, "the shards' partials differ in size"
+                out[r * nbytes:(r + 1) * nbytes].copy_(device_view(ptr, nbytes))
+            torch.cuda.synchronize()
+            self.barrier.wait()
+            return 0
+        except Exception:  # noqa: BLE001 — reported through the C ABI's error code
+            self.barrier.abort()
+            return -1
+
+    def _allreduce(self, rank, inout, count):
+        try:
+            torch.cuda.synchronize()
+            self.slots[rank] = (inout, count)
+            self.barrier.wait()
+            total = torch.zeros(count, dtype=torch.int32, device="cuda")
+            for ptr, cnt in self.slots:
+                total += device_view(ptr, cnt * 4).view(torch.int32)
+            torch.cuda.synchronize()
+            self.barrier.wait()
+            device_view(inout, count * 4).view(torch.int32).copy_(total)
+            torch.cuda.synchronize()
+            self.barrier.wait()
+            return 0
+        except Exception:  # noqa: BLE001
+            self.barrier.abort()
+            return -1
+
+
+def shard_step_begin(index, batch):
+    """`vq_shard_step_begin`: the step's compile, scans and exchange are queued; -> handle for shard_step_end."""
+    from . import _lib
+    h = C.c_void_p()
+    _lib.check(_lib.lib().vq_shard_step_begin(index.h, batch.arr, batch.n, C.byref(h)))
+    return (h, batch.n)
+
+
+def shard_step_end(step, stride=10):
+    """`vq_shard_step_end`: (num_hits u64[n], counts u32[n], ids u32[n, stride], scores f32[n, stride], status i32[n])."""
+    from . import _lib
+    h, n = step
+    out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, stride), np.uint32), np.zeros((n, stride), np.float32), np.zeros(n, np.int32))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.lib().vq_shard_step_end(h, stride, *[p(a) for a in out]))
+    return out
 
 
 def search_shards_local(shards, requests):

@@ -55,6 +55,7 @@ class Request:
         h = C.c_void_p()
         _lib.check(self.L.vq_request_parse(request, len(request), C.byref(h)))
         self.h = h
+        self.has_facets = b'"facets"' in request  # (a hint for schedulers: a false positive only costs the slower path)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -66,7 +67,7 @@ class Request:
         h = C.c_void_p()
         _lib.check(self.L.vq_request_page_after(self.h, C.c_float(float(score)), int(doc_id), C.byref(h)))
         page = Request.__new__(Request)
-        page.L, page.h = self.L, h
+        page.L, page.h, page.has_facets = self.L, h, False  # (a continuation page carries no facets: page 0 counted them)
         return page
 
     def top_skip(self):
@@ -136,9 +137,11 @@ def _take_result(L, h):
                                                                    for i in range(fl)]
         res = SearchResult(L.vq_result_num_hits(h), ids, scores, facets, L.vq_result_execution_time_ns(h))
         res.is_page = bool(L.vq_result_is_page(h))  # page 0 of a request that reaches beyond one scan's ranking (sharded merge only)
-        res.why_found_terms = json.loads(L.vq_result_why_found_terms_json(h).decode())
-        res.explain_json = L.vq_result_explain_json(h).decode()  # per hit: null or its Explain records (src/search.rs:86,96); "null" without `explain`
-        res.explain = json.loads(res.explain_json)
+        wf = L.vq_result_why_found_terms_json(h)  # (requests without why_found / explain: two short strings, no JSON parsing per result)
+        res.why_found_terms = {} if wf == b"{}" else json.loads(wf.decode())
+        ex = L.vq_result_explain_json(h)  # per hit: null or its Explain records (src/search.rs:86,96); "null" without `explain`
+        res.explain_json = ex.decode()
+        res.explain = None if ex == b"null" else json.loads(res.explain_json)
         return res
     finally:
         L.vq_result_free(h)
@@ -241,6 +244,7 @@ class RequestBatch:
         self.reqs = [_as_request(r) for r in requests]
         self.n = len(self.reqs)
         self.arr = (C.c_void_p * self.n)(*[r.h for r in self.reqs])
+        self.has_facets = any(getattr(r, "has_facets", True) for r in self.reqs)
         self._splits = {}
 
     def split(self, k):
