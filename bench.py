@@ -214,23 +214,30 @@ class Bench:
                 torch.cuda.synchronize()
 
         native = searcher is not None and getattr(searcher, "native", False)
+        from veloci_amd import dist as vdist
+        step_begin = searcher.step_begin if native else (lambda b: vdist.shard_step_begin(index, b))
+        step_end = searcher.step_end if native else vdist.shard_step_end
+        # (VQ_BENCH_SYNC_STEPS=1: one vq_search_batch_flat call per step.  Requests with pre-passes — config #4's dictionary scans and unions — stay on
+        #  that entry point: it runs such batches on two host threads, which hides more than a second step in flight does: 72 k against 53 k requests/s)
+        pipelined = native or (searcher is None and workload != "config4" and os.environ.get("VQ_BENCH_SYNC_STEPS") != "1")
 
         def run_steps(k):
-            """k whole steps -> the outputs of the last one.  On the in-library sharded path (vq_shard_step_begin / _end) two steps are kept in
-            flight: step i + 1 is compiled and its scans are queued before step i's exchange and merge are waited for."""
-            if not native:
+            """k whole steps -> the outputs of the last one.  Through vq_shard_step_begin / _end (the in-library sharded step; on one GPU the same
+            pipeline without an exchange) two steps are kept in flight: step i + 1 is compiled and its scans are queued before step i's
+            exchange and merge are waited for."""
+            if not pipelined:
                 out = None
                 for _ in range(k):
                     out = step()
                 return out
             out, pending = None, None
             for _ in range(k):
-                h = searcher.step_begin(batch)
+                h = step_begin(batch)
                 if pending is not None:
-                    out = searcher.step_end(pending, 10)
+                    out = step_end(pending, 10)
                 pending = h
             if pending is not None:
-                out = searcher.step_end(pending, 10)
+                out = step_end(pending, 10)
             if out is not None:
                 assert not out[4].any(), f"request failed: status {out[4][out[4] != 0][:4]}"
                 out = out[:4]
@@ -324,6 +331,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries ONE line — the result; whatever a library prints there (RCCL greets on stdout when a communicator is made) goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np  # noqa: F401
     import torch
 
@@ -416,7 +428,8 @@ def main():
         out["configs"] = extras
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         import torch.distributed as dist
         dist.barrier()

@@ -954,7 +954,7 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t (rccl.h)
-Rccl& rccl() {
+static Rccl& rccl_api() {
     static Rccl r = [] {
         Rccl x;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -989,7 +989,7 @@ int quiet_stdout(const std::function<int()>& f) {
     return rc;
 }
 void nccl_check(int rc, const char* what) {
-    if (rc != 0) throw VelociError(VQ_ERR_DEVICE, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"));
+    if (rc != 0) throw VelociError(VQ_ERR_DEVICE, std::string(what) + ": " + (rccl_api().GetErrorString ? rccl_api().GetErrorString(rc) : "RCCL error"));
 }
 // sums over the shards before compilation (result sizes of count pre-passes, merged list lengths): the in-library form of vq_index_set_allreduce
 int comm_sum_u64(void* ctx, uint64_t* values, size_t n) {
@@ -1000,7 +1000,7 @@ int comm_sum_u64(void* ctx, uint64_t* values, size_t n) {
         VQ_HIP(hipSetDevice(idx.device));
         c.red.ensure(n * 8);
         VQ_HIP(hipMemcpyAsync(c.red.p, values, n * 8, hipMemcpyHostToDevice, c.stream));
-        nccl_check(rccl().AllReduce(c.red.p, c.red.p, n, kNcclUint64, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
+        nccl_check(rccl_api().AllReduce(c.red.p, c.red.p, n, kNcclUint64, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
         VQ_HIP(hipMemcpyAsync(values, c.red.p, n * 8, hipMemcpyDeviceToHost, c.stream));
         VQ_HIP(hipStreamSynchronize(c.stream));
         return 0;
@@ -1025,7 +1025,7 @@ void comm_setup(Index& idx, std::unique_ptr<ShardComm> c) {
 }  // namespace
 
 vq::ShardComm::~ShardComm() {
-    if (nccl) (void)rccl().CommDestroy(static_cast<ncclComm_t>(nccl));
+    if (nccl) (void)rccl_api().CommDestroy(static_cast<ncclComm_t>(nccl));
     for (int k = 0; k < 2; ++k) {
         if (ev_scan[k]) (void)hipEventDestroy(ev_scan[k]);
         if (ev_xchg[k]) (void)hipEventDestroy(ev_xchg[k]);
@@ -1038,7 +1038,7 @@ int vq_comm_unique_id(void* id_out) {
     return guard([&] {
         if (!id_out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_unique_id: null argument");
         NcclId id;
-        nccl_check(quiet_stdout([&] { return rccl().GetUniqueId(&id); }), "ncclGetUniqueId");
+        nccl_check(quiet_stdout([&] { return rccl_api().GetUniqueId(&id); }), "ncclGetUniqueId");
         std::memcpy(id_out, &id, sizeof id);
     });
 }
@@ -1054,7 +1054,7 @@ int vq_comm_init(vq_index* index, int nranks, int rank, const void* unique_id) {
         NcclId id;
         std::memcpy(&id, unique_id, sizeof id);
         ncclComm_t comm = nullptr;
-        nccl_check(quiet_stdout([&] { return rccl().CommInitRank(&comm, nranks, id, rank); }), "ncclCommInitRank");
+        nccl_check(quiet_stdout([&] { return rccl_api().CommInitRank(&comm, nranks, id, rank); }), "ncclCommInitRank");
         c->nccl = comm;
         comm_setup(idx, std::move(c));
         idx.allreduce_fn = comm_sum_u64;
@@ -1089,12 +1089,14 @@ int vq_comm_destroy(vq_index* index) {
 struct vq_shard_step {
     const Index* idx = nullptr;
     std::vector<std::unique_ptr<PartialBatch>> pbs;
-    std::vector<size_t> first, arena_off;  // chunk c: its first request, its partial's offset inside the step's part of the arena
+    std::vector<size_t> first, arena_off;  // chunk c: its first request, the offset of its gathered copies inside the step's gather buffer
     size_t n = 0, used = 0;
     int parity = 0;
     bool merge_queued = false;
+    bool counted = false;
     ~vq_shard_step() {
         if (idx && idx->comm && idx->comm->unmerged == this) idx->comm->unmerged = nullptr;
+        if (counted && idx && idx->comm) idx->comm->live -= 1;
     }
 };
 namespace {
@@ -1110,7 +1112,7 @@ void step_queue_merge(vq_shard_step& step) {
     if (step.used) VQ_HIP(hipStreamWaitEvent(idx.fin_stream, c.ev_xchg[step.parity], 0));
     const uint8_t* gathered = static_cast<const uint8_t*>(c.gathered[step.parity].p);
     for (size_t k = 0; k < step.pbs.size(); ++k)
-        finish_launch(idx, *step.pbs[k], step.used ? gathered + step.arena_off[k] : nullptr, uint32_t(c.nranks), step.used);
+        finish_launch(idx, *step.pbs[k], step.used && step.pbs[k]->nq_dev ? gathered + step.arena_off[k] : nullptr, uint32_t(c.nranks));
     VQ_HIP(hipEventRecord(c.ev_fin[step.parity], idx.fin_stream));
 }
 }  // namespace
@@ -1120,8 +1122,12 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
         if (!index || !out || (n && !requests)) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: null argument");
         *out = nullptr;
         const Index& idx = *index->idx;
-        if (!idx.comm) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: no communicator (vq_comm_init)");
+        if (!idx.comm) {  // no communicator: the index is the only shard — the same pipeline without an exchange (two steps in flight on one GPU)
+            auto local = std::make_unique<ShardComm>();
+            comm_setup(const_cast<Index&>(idx), std::move(local));
+        }
         ShardComm& c = *idx.comm;
+        const bool exchange = c.nccl != nullptr || c.allgather != nullptr;
         static const bool timing = std::getenv("VQ_TIMING") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
         VQ_HIP(hipSetDevice(idx.device));
@@ -1133,48 +1139,52 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
             VQ_HIP(hipStreamWaitEvent(idx.stream, c.ev_fin[prev.parity], 0));
         }
         const auto tb1 = std::chrono::steady_clock::now();
+        if (c.live >= 2) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: two steps are in flight already (end one first)");
         auto step = std::make_unique<vq_shard_step>();
         step->idx = &idx;
+        step->counted = true;
+        c.live += 1;
         step->n = n;
         step->parity = int(c.seq++ & 1u);
-        // chunks per step from the GLOBAL doc count and the world size (the same on every rank): pipelining compile against scan pays while a
-        // chunk's scan is long next to a chunk's fixed costs.  Two steps may be in flight over the four workspaces: at most two chunks each.
+        // One launch per step: with two steps in flight the compilation of step i + 1 already overlaps the scans of step i, and one launch of
+        // 1024 requests fills the chip more evenly than two of 512 (100 M docs: 7.25 against 7.41 ms per step).  VQ_SHARD_CHUNKS=2 cuts a step in two.
         static const size_t chunks_env = [] {
             const char* e = std::getenv("VQ_SHARD_CHUNKS");
             return size_t(e ? std::min(2, std::max(1, std::atoi(e))) : 0);
         }();
-        const uint64_t per_shard = uint64_t(idx.num_anchors) / uint64_t(std::max(c.nranks, 1));
-        const size_t nchunks = chunks_env ? chunks_env : (n < 512 || per_shard < 40'000'000ull) ? 1 : 2;
-        const size_t arena_base = size_t(step->parity) * (Index::kArenaBytes / 2);
-        size_t off = 0;
+        const size_t nchunks = chunks_env && n >= 512 ? chunks_env : 1;
         for (size_t k = 0; k < nchunks; ++k) {
             const size_t b = n * k / nchunks, e = n * (k + 1) / nchunks;
-            if (off % 256 || arena_base + off >= arena_base + Index::kArenaBytes / 2) throw VelociError(VQ_ERR_UNSUPPORTED, "sharded step: the partial arena is too small for this batch");
-            auto pb = run_partial(idx, reqs.data() + b, e - b, step->parity * 2 + int(k), int64_t(arena_base + off));
-            if (arena_base + off + pb->layout.bytes > arena_base + Index::kArenaBytes / 2) throw VelociError(VQ_ERR_UNSUPPORTED, "sharded step: the partial arena is too small for this batch");
             step->first.push_back(b);
+            step->pbs.push_back(run_partial(idx, reqs.data() + b, e - b, step->parity * 2 + int(k)));
+        }
+        const auto tb2 = std::chrono::steady_clock::now();
+        // ---- the exchange: behind the step's scans, on the collective stream.  Per chunk the part of its partial in front of the histograms
+        // (hit counts, statistics, top-k keys: the same size on every rank) is all-gathered, the histograms are summed in place.
+        size_t off = 0;
+        for (auto& pb : step->pbs) {
             step->arena_off.push_back(off);
-            off += (size_t(pb->layout.bytes) + 255) / 256 * 256;
-            step->pbs.push_back(std::move(pb));
+            if (exchange && pb->nq_dev) off += (size_t(pb->layout.off_hist) * size_t(c.nranks) + 255) / 256 * 256;
         }
         step->used = off;
-        const auto tb2 = std::chrono::steady_clock::now();
-        // ---- the exchange: behind the step's scans, on the collective stream
         if (off) {
             VQ_HIP(hipEventRecord(c.ev_scan[step->parity], idx.stream));
             VQ_HIP(hipStreamWaitEvent(c.stream, c.ev_scan[step->parity], 0));
-            uint8_t* local = idx.arena.as<uint8_t>() + arena_base;
-            c.gathered[step->parity].ensure(size_t(c.nranks) * off);
-            void* gathered = c.gathered[step->parity].p;
-            if (c.nccl) nccl_check(rccl().AllGather(local, gathered, off, kNcclUint8, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllGather");
-            else if (c.allgather(c.ctx, local, gathered, off, c.stream) != 0) throw VelociError(VQ_ERR_DEVICE, "sharded step: the caller's all-gather failed");
-            for (auto& pb : step->pbs)
-                if (pb->nq_dev && pb->layout.total_hist) {  // facet counts are additive: summed in place, read by this rank's merge
-                    void* h = pb->d_partial + pb->layout.off_hist;
-                    if (c.nccl) nccl_check(rccl().AllReduce(h, h, size_t(pb->layout.total_hist), kNcclUint32, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
-                    else if (!c.allreduce_u32 || c.allreduce_u32(c.ctx, h, size_t(pb->layout.total_hist), c.stream) != 0)
+            c.gathered[step->parity].ensure(off);
+            uint8_t* gathered = c.gathered[step->parity].as<uint8_t>();
+            for (size_t k = 0; k < step->pbs.size(); ++k) {
+                PartialBatch& pb = *step->pbs[k];
+                if (!pb.nq_dev) continue;
+                const size_t bytes = size_t(pb.layout.off_hist);
+                if (c.nccl) nccl_check(rccl_api().AllGather(pb.d_partial, gathered + step->arena_off[k], bytes, kNcclUint8, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllGather");
+                else if (c.allgather(c.ctx, pb.d_partial, gathered + step->arena_off[k], bytes, c.stream) != 0) throw VelociError(VQ_ERR_DEVICE, "sharded step: the caller's all-gather failed");
+                if (pb.layout.total_hist) {  // facet counts are additive: summed in place, read by this rank's merge
+                    void* h = pb.d_partial + pb.layout.off_hist;
+                    if (c.nccl) nccl_check(rccl_api().AllReduce(h, h, size_t(pb.layout.total_hist), kNcclUint32, kNcclSum, static_cast<ncclComm_t>(c.nccl), c.stream), "ncclAllReduce");
+                    else if (!c.allreduce_u32 || c.allreduce_u32(c.ctx, h, size_t(pb.layout.total_hist), c.stream) != 0)
                         throw VelociError(VQ_ERR_DEVICE, "sharded step: the caller's all-reduce failed");
                 }
+            }
             VQ_HIP(hipEventRecord(c.ev_xchg[step->parity], c.stream));
         }
         c.unmerged = step.get();
@@ -1206,7 +1216,7 @@ int vq_shard_step_end(vq_shard_step* step_raw, size_t stride, uint64_t* num_hits
             std::vector<std::unique_ptr<Result>> results;
             std::vector<int> st;
             std::vector<std::string> errs;
-            finish_batch(idx, *step->pbs[k], step->used ? gathered + step->arena_off[k] : nullptr, uint32_t(c.nranks), results, st, errs, step->used);
+            finish_batch(idx, *step->pbs[k], step->used && step->pbs[k]->nq_dev ? gathered + step->arena_off[k] : nullptr, uint32_t(c.nranks), results, st, errs);
             decline_deep(results, st, errs);
             decline_explain(results, st, errs, "the sharded step");
             copy_flat(results, st, errs, step->first[k], stride, num_hits, counts, ids, scores, status);

@@ -432,6 +432,7 @@ struct ShardComm {
     hipStream_t stream = nullptr;
     hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_xchg[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr};
     void* unmerged = nullptr;  // the step in flight whose merge is not queued yet (vq_shard_step*)
+    int live = 0;              // steps begun and not yet ended / freed (at most two: each holds workspaces of its own)
     DevBuf gathered[2];
     DevBuf red;  // scratch of the sums-over-shards hook (u64)
     uint32_t seq = 0;

@@ -112,16 +112,32 @@ class ShardedSearcher:
         if self.native:
             L = _lib.lib()
             rank = dist.get_rank(group)
-            ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
-            if rank == 0:
-                buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-                _lib.check(L.vq_comm_unique_id(buf))
-                ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            failed = 0
+            try:
+                ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+                if rank == 0:
+                    buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+                    _lib.check(L.vq_comm_unique_id(buf))
+                    ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            except Exception as e:  # noqa: BLE001 — e.g. no RCCL library to load: every rank must learn of it (below)
+                failed, err = 1, e
             ident = ident.cuda()
             dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            raw = bytes(ident.cpu().numpy().tobytes())
-            _lib.check(L.vq_comm_init(index.h, self.world, rank, raw))
-            return
+            if not failed:
+                try:
+                    _lib.check(L.vq_comm_init(index.h, self.world, rank, bytes(ident.cpu().numpy().tobytes())))
+                except Exception as e:  # noqa: BLE001
+                    failed, err = 1, e
+            # the ranks agree on the path: one rank on the library's exchange and another on this module's would never meet in a collective
+            flag = torch.tensor([failed], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()) == 0:
+                return
+            if failed:
+                print(f"[veloci_amd.dist] rank {rank}: the in-library exchange is not available ({err}); all ranks use the module's own path", flush=True)
+            else:
+                L.vq_comm_destroy(index.h)
+            self.native = False
         if self.collective and dist.get_backend(group) == "nccl":
             # scans on one side stream, RCCL all-gather + merge on another that waits for the batch's scan through an event:
             # no host synchronisation between the shard scan and the collective.  (Not torch's default stream: its handle
