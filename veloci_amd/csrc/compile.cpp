@@ -745,7 +745,6 @@ struct Compiler {
                 h.flags |= LIST_BITMAP;
                 h.d_bitmap = ps.bitmaps.as<uint32_t>() + ps.bm_start[e.tid];
                 h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[e.tid];
-                h.d_block_max = ps.block_max.as<uint16_t>() + ps.rd_start[e.tid];
             }
             if (!ps.td_start.empty() && ps.td_start[e.tid] >= 0) h.d_tile_dir = ps.tile_dir.as<uint32_t>() + ps.td_start[e.tid];
             uint32_t li = add_list(h);
@@ -1980,7 +1979,6 @@ struct Compiler {
                                 h.flags |= LIST_BITMAP;
                                 h.d_bitmap = same_ps->bitmaps.as<uint32_t>() + same_ps->bm_start[id];
                                 h.d_rank_dir = same_ps->rank_dir.as<uint32_t>() + same_ps->rd_start[id];
-                                h.d_block_max = same_ps->block_max.as<uint16_t>() + same_ps->rd_start[id];
                             }
                         } else {
                             h.d_docs = t2t.values.as<uint32_t>() + t2t.start[r];
@@ -2226,9 +2224,9 @@ struct Compiler {
             b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
         else if (wide) {
             for (uint32_t k = 0; k < cq.wide.n_leaves; ++k) b += ((cq.wide.bitmap_mask >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[cq.wide.leaf_list[k]].len;
-        } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's ids and scores and the operands' words are streamed with one rank entry and the block maxima (2 B per 512 docs) per tile
+        } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's ids and scores are streamed, the operands' tiles come with 32 rank entries
             for (uint32_t k = 0; k < cq.simple_n; ++k)
-                b += ((cq.simple_flags >> k) & 1u) ? visited * (tile_docs / 8 + 4 + 2 * (tile_docs >> kRankShift)) : 6ull * cq.lists[cq.ops[k].list_begin].len;
+                b += ((cq.simple_flags >> k) & 1u) ? visited * (tile_docs / 8 + 4 * (tile_docs >> kRankShift)) : 6ull * cq.lists[cq.ops[k].list_begin].len;
         } else if (simple) {
             std::vector<bool> seen(cq.lists.size(), false);
             const bool rich = (cq.simple_flags >> 18) & 1u;

@@ -24,10 +24,7 @@ constexpr int kMaxChildren = 16;    // children per AND/OR node (the query gener
 constexpr int kMaxLists = 64;       // lists per query in one launch
 constexpr int kMaxOps = 160;
 constexpr int kMaxSkipWhen = 4;
-#ifndef VQ_TILE_DIR_SHIFT
-#define VQ_TILE_DIR_SHIFT 14
-#endif
-constexpr uint32_t kTileDirShift = VQ_TILE_DIR_SHIFT;  // tile directory of an id list: one entry per 16384 docs (the tile of k_scan_probe)
+constexpr uint32_t kTileDirShift = 15;  // tile directory of an id list: one entry per 32768 docs (the tile of k_scan_probe)
 constexpr uint32_t kRankShift = 9;  // rank directory of a dense list: one entry per 512 docs (16 bitmap words = one 64-byte sector)
 
 enum ListFlags : uint32_t {
@@ -37,7 +34,7 @@ enum ListFlags : uint32_t {
     LIST_F32 = 8u,         // materialised leaf (k_union): scores are final f32 values, term_score is not applied
 };
 
-struct DList {  // 64 B
+struct DList {  // 56 B
     const uint32_t* docs;    // 16-byte aligned, padded to a multiple of 4 with 0xFFFFFFFF
     const uint16_t* scores;  // f16 bits, same indexing as docs (null for id-only lists)
     uint32_t len;
@@ -47,7 +44,6 @@ struct DList {  // 64 B
     uint16_t pad;
     const uint32_t* bitmap;    // LIST_BITMAP: bit (doc - bitmap_base) set for every doc of the list
     const uint32_t* rank_dir;  // LIST_BITMAP: entries of the list below doc bitmap_base + (k << kRankShift)
-    const uint16_t* block_max; // LIST_BITMAP: largest f16 score bits among the list's postings in docs [bitmap_base + (k << kRankShift), + 512) (0: none there) — block-max pruning
     const uint32_t* tile_dir;  // lists of at least 1/4096 of the shard's docs (null otherwise): entries below doc bitmap_base + (k << kTileDirShift)
 };
 

@@ -280,7 +280,6 @@ struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segment
     std::vector<int64_t> rd_start;      // entry offset of list t inside `rank_dir`, or -1
     DevBuf bitmaps;                     // u32 words; bit (doc - Index::bitmap_base)
     DevBuf rank_dir;                    // u32: entries below bitmap_base + (k << kRankShift)
-    DevBuf block_max;                   // u16, indexed like rank_dir: largest f16 score bits of the list's postings in block k (512 docs)
     // lists that hold at least 1/4096 of the shard's docs get a tile directory (k_scan_probe reads a tile's postings of
     // its cover list without searching or counting): entries below bitmap_base + (k << kTileDirShift)
     std::vector<int64_t> td_start;      // entry offset of list t inside `tile_dir`, or -1
@@ -502,7 +501,6 @@ struct HList {
     uint64_t global_len = 0;
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;
-    const uint16_t* d_block_max = nullptr;
     const uint32_t* d_tile_dir = nullptr;
     int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
     int inline_val_idx = -1;  // >= 0: f32 values come from inline_vals[inline_val_idx]

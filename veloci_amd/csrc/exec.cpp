@@ -176,7 +176,6 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
         d.max_raw = l.max_raw;
         d.bitmap = l.d_bitmap;
         d.rank_dir = l.d_rank_dir;
-        d.block_max = l.d_block_max;
         d.tile_dir = l.d_tile_dir;
         dl[i] = d;
     }

@@ -194,26 +194,22 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         ps.rd_start.assign(ps.num_tokens, -1);
         {
             const uint64_t range = uint64_t(hi) - lo;
-            const uint64_t words = idx->bitmap_words, blocks = words >> (kRankShift - 5);  // rank directory and block maxima: one entry per 512 docs (kRankShift)
+            const uint64_t words = idx->bitmap_words, blocks = words >> (kRankShift - 5);  // rank directory: one entry per 512 docs (kRankShift)
             std::vector<uint32_t> dense;
             for (uint32_t t = 0; t < ps.num_tokens; ++t)
                 if (range >= 65536 && uint64_t(ps.len[t]) * 64 >= range) dense.push_back(t);
             if (!dense.empty()) {
                 std::vector<uint32_t> bits(words * dense.size(), 0u);
                 std::vector<uint32_t> rdir((blocks + 1) * dense.size(), 0u);
-                std::vector<uint16_t> bmax((blocks + 1) * dense.size(), 0);  // block maxima of the scores (non-negative f16: bit order == value order)
                 for (size_t k = 0; k < dense.size(); ++k) {
                     const uint32_t t = dense[k];
                     uint32_t* bw = bits.data() + words * k;
                     uint32_t* rd = rdir.data() + (blocks + 1) * k;
                     const uint32_t* d = docs.data() + ps.start[t];
-                    const uint16_t* sc16 = scores.data() + ps.start[t];
-                    uint16_t* bm = bmax.data() + (blocks + 1) * k;
                     for (uint32_t i = 0; i < ps.len[t]; ++i) {
                         const uint32_t rel = d[i] - idx->bitmap_base;
                         bw[rel >> 5] |= 1u << (rel & 31u);
                         rd[(rel >> kRankShift) + 1] += 1;
-                        bm[rel >> kRankShift] = std::max(bm[rel >> kRankShift], sc16[i]);
                     }
                     for (uint64_t bl = 1; bl <= blocks; ++bl) rd[bl] += rd[bl - 1];
                     ps.bm_start[t] = int64_t(words * k);
@@ -223,9 +219,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
                 ps.bitmaps.upload(bits.data(), bits.size() * 4);
                 ps.rank_dir.alloc(rdir.size() * 4 + 16);
                 ps.rank_dir.upload(rdir.data(), rdir.size() * 4);
-                ps.block_max.alloc(bmax.size() * 2 + 16);
-                ps.block_max.upload(bmax.data(), bmax.size() * 2);
-                idx->device_bytes += ps.bitmaps.bytes + ps.rank_dir.bytes + ps.block_max.bytes;
+                idx->device_bytes += ps.bitmaps.bytes + ps.rank_dir.bytes;
             }
         }
         // ---- tile directories of the lists that hold at least 1/4096 of the shard's docs (dense ones included: one can be the cover of an AND)

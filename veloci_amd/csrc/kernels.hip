@@ -1772,8 +1772,6 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     const u32x4 kZero = u32x4{0u, 0u, 0u, 0u};
 
     while (true) {
-        // (a wave that is about to ask for its next tile goes first: the memory side idles while its loads wait behind other waves' arithmetic)
-        __builtin_amdgcn_s_setprio(3);
         uint32_t head = 0xFFFFFFFFu;
         if (seq) head = pos;
         else {
@@ -1811,7 +1809,6 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 }
             }
         }
-        if constexpr (!RICH) __builtin_amdgcn_s_setprio(0);
         // scatter the id lists (rounds of 64 x 16 B, counted with ballots; see k_tile_scan P2)
         if constexpr (RICH) {
             u32x4 sfirst[4];
@@ -1824,7 +1821,6 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
 #pragma unroll
                     for (uint32_t h = 0; h < NV; ++h) reinterpret_cast<u32x4*>(bml + sslot[s])[lane * NV + h] = kZero;
                 }
-            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (uint32_t s = 0; s < 4; ++s)
                 if (s < R.n_side) (void)simple_scatter_list(sdocs[s], slen[s], scur[s], snxt[s], bml + sslot[s], sfirst[s], false, tile_lo, tile_hi, lo_bound);
@@ -2040,7 +2036,6 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
             }
         }
     }
-    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (qlen) {
         uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;

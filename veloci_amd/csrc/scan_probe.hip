@@ -1,13 +1,13 @@
 // k_scan_probe — AND of 2..4 single-list posting leaves whose cover (the sparsest operand) is an id list and whose other operands are
 // dense lists with bitmap images: the headline shape (3-term AND, df 10 % / 3 % / 1 % of the docs).
 //
-// The doc space is walked in tiles of 16384 docs.  The cover's tile directory (DList::tile_dir) says which of its postings fall into a
+// The doc space is walked in tiles of 32768 docs.  The cover's tile directory (DList::tile_dir) says which of its postings fall into a
 // tile: their doc ids AND f16 scores are streamed (64 lanes x 16 B + 64 x 8 B per 256 postings) — no search, no counting, every lane
 // slot holds a posting of the tile.  The dense operands' bitmap words of the tile sit in LDS (coalesced 16 B/lane loads) and every
-// cover id tests its bit there.  Nothing is computed per bitmap word: the work per tile follows the COVER's postings (about 165 per
-// tile in the headline query), not the 512 words per operand.
+// cover id tests its bit there.  Nothing is computed per bitmap word: the work per tile follows the COVER's postings (about 330 per
+// tile in the headline query), not the 1024 words per operand.
 //
-// Loads are only ISSUED at the top of a tile — the next tile's words, rank entry and cover postings, the score gathers of the flush
+// Loads are only ISSUED at the top of a tile — the next tile's words, rank entries and cover postings, the score gathers of the flush
 // in flight, the query's shared threshold — and only consumed behind the top of the next one, which waits for everything in flight
 // once: nothing in the loop waits for a load it has just issued, and a whole tile of work hides the latency.
 //
@@ -17,11 +17,9 @@
 // above — f32 add and mul are monotone — and that bound is monotone in the cover's raw f16 score, so the test per posting is one
 // integer compare against `raw_min`, recomputed whenever the threshold moves.  Pruned hits are still counted (num_hits is exact).
 //
-// Hits that stay live need their index in every dense operand (the f16 score is scores[index]).  Only ONE rank directory entry per
-// tile and operand is read (the entries below the tile's first doc); while the tile's words pass through the registers on their way
-// to LDS, every lane counts the bits of its two 16-byte vectors and a wave scan turns the counts into the rank below each vector
-// (128 docs), kept in LDS next to the words.  A live hit's index is then that rank + the set bits of at most four words below the
-// doc.  Ranked hits are queued in a ring and scored 64 at a time by a pipeline that advances one stage per tile.
+// Hits that stay live need their index in every dense operand (the f16 score is scores[index]): rank directory entry of the doc's
+// 512-doc group (staged in LDS with the tile) + popcount of the group's words below the doc.  Ranked hits are queued and scored
+// 64 at a time, all score gathers of a flush in flight together.
 // Same results as k_scan_simple / k_tile_scan bit for bit (tests run every such query through all three).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -65,23 +63,20 @@ void debug_read_probe_stamps(unsigned long long* out, int reset) {
 
 __device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-constexpr uint32_t kPT = 1u << kTileDirShift;   // docs per tile (16384)
-constexpr uint32_t kPTW = kPT / 32;             // bitmap words per tile and dense operand (512)
-constexpr uint32_t kPNV = kPTW / 256;           // 16-byte vectors per lane, tile and dense operand (2)
-constexpr uint32_t kPBlk = kPT >> kRankShift;    // 512-doc blocks per tile: one block maximum per lane (32 or 64)
-static_assert(kPBlk <= 64, "a tile's block maxima ride in one register");
-constexpr uint32_t kPPre = kPTW / 4;             // ranks kept per tile and dense operand: entries of the list below each 16-byte vector (128 docs)
-static_assert(kPNV % 2 == 0, "the rank scan packs the counts of two of a lane's vectors into one word");
-constexpr uint32_t kPMaxR = (kPT * 3u / 200u + 255u) / 256u;  // rounds of 256 cover postings of a tile that are prefetched into registers — sized for a cover of 1.5 % of the docs (more: fetched on the spot)
+constexpr uint32_t kPT = 1u << kTileDirShift;   // docs per tile (32768)
+constexpr uint32_t kPTW = kPT / 32;             // bitmap words per tile and dense operand (1024)
+constexpr uint32_t kPNV = kPTW / 256;           // 16-byte vectors per lane, tile and dense operand (4)
+constexpr uint32_t kPRk = kPT >> kRankShift;    // rank directory entries per tile and dense operand (64: one per lane)
+constexpr uint32_t kPMaxR = 2;                  // rounds of 256 cover postings of a tile that are prefetched into registers (more: fetched on the spot)
 constexpr uint32_t kPU = 64 + kPMaxR * 256;     // unranked queue: live hits of the current tile, (doc - tile_lo) << 16 | raw f16 score of the cover
 constexpr uint32_t kPR = 128;                   // ranked queue
-// LDS map (u32): misc[8] | shape[32] | uq[kPU] | rdoc[kPR] rraw[kPR] ridx[ND][kPR] | tile[ND][kPTW] | pre[ND][kPPre] | cand[2 * cand_cap]
+// LDS map (u32): misc[8] | shape[32] | uq[kPU] | rdoc[kPR] rraw[kPR] ridx[ND][kPR] | tile[ND][kPTW] | rank[ND][kPRk] | cand[2 * cand_cap]
 // (the candidate buffer, the only part sized at run time, comes last: every other offset is a constant of the instantiation)
 constexpr uint32_t kPLdsShape = 8;
 constexpr uint32_t kPLdsU = kPLdsShape + 32;
 constexpr uint32_t kPLdsR = kPLdsU + kPU;
 __host__ __device__ constexpr uint32_t probe_lds_tile(uint32_t nd) { return kPLdsR + (2 + nd) * kPR; }
-__host__ __device__ constexpr uint32_t probe_lds_cand(uint32_t nd) { return probe_lds_tile(nd) + nd * (kPTW + kPPre); }
+__host__ __device__ constexpr uint32_t probe_lds_cand(uint32_t nd) { return probe_lds_tile(nd) + nd * (kPTW + kPRk); }
 // shape words (what only the rare paths need — scoring a flush, recomputing raw_min — lives in LDS, not in registers)
 constexpr uint32_t kShCts = 0, kShTs = 1, kShVmax = 4, kShSrc = 7, kShPrunable = 11, kShScores = 12;  // scores: 3 x u64
 
@@ -229,7 +224,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     uint32_t* rq = lds + kPLdsR;  // rdoc[kPR] rraw[kPR] ridx[ND][kPR]
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + probe_lds_cand(ND));
     uint32_t* tile = lds + probe_lds_tile(ND);  // [ND][kPTW]
-    uint32_t* pre = tile + ND * kPTW;           // [ND][kPPre]: entries of operand i below vector v of the tile (absolute)
+    uint32_t* rank = tile + ND * kPTW;          // [ND][kPRk]
     unsigned long long* const gthr = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr));
     CandState cs{cand, cand_n, thr, cand_cap, gthr};
     cs.upper = H->key_upper;
@@ -243,7 +238,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     uint32_t clen = 0;
     const uint32_t* d_bitmap[ND];
     const uint32_t* d_rank[ND];
-    const uint16_t* d_bmax[ND];
     {
         const uint32_t ck = (uint32_t)__ffs((int)((sflags >> 8) & 0xFu)) - 1u;
         uint32_t role_of[4] = {0u, 0u, 0u, 0u};  // leaf k -> 0 = cover, 1 + i = dense operand i
@@ -266,7 +260,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                     if (j == i) {
                         d_bitmap[j] = d.bitmap;
                         d_rank[j] = d.rank_dir;
-                        d_bmax[j] = d.block_max;
                         if (lane == 0) {
                             const uint16_t mr = d.max_raw;
                             sh[kShTs + j] = __float_as_uint(d.term_score);
@@ -320,9 +313,9 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     uint32_t dirv = load_dir();
     auto dir_at = [&](uint32_t tt) { return (uint32_t)__builtin_amdgcn_readlane((int)dirv, (int)(tt - dir_base)); };
 
-    // registers of the tile in flight: its words, the rank below its first doc, its cover postings (the first kPMaxR rounds)
+    // registers of the tile in flight: its words and rank entries, its cover postings (the first kPMaxR rounds)
     u32x4 wk[ND][kPNV];
-    uint32_t rk[ND], bmx[ND];  // (bmx: lane l holds the largest score of the operand in the tile's 512-doc block l)
+    uint32_t rk[ND];
     u32x4 nid[kPMaxR], cid[kPMaxR];
     u32x2 nsc[kPMaxR], csc[kPMaxR];
 #pragma unroll
@@ -340,8 +333,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(d_bitmap[i] + (size_t)tt * kPTW));
 #pragma unroll
                 for (uint32_t h = 0; h < kPNV; ++h) wk[i][h] = gb[h * 64u + lane];
-                rk[i] = as_global(d_rank[i])[tt * kPBlk];  // (one entry for the whole wave)
-                bmx[i] = as_global(d_bmax[i])[tt * kPBlk + (lane & (kPBlk - 1u))];
+                rk[i] = as_global(d_rank[i])[tt * kPRk + lane];
             }
 #pragma unroll
             for (uint32_t r = 0; r < kPMaxR; ++r) {
@@ -361,9 +353,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     // stage per tile.  Stage i has the gather of dense operand i's scores in flight; when it is consumed — a tile later, the data has
     // long arrived — the bound is taken again with the value now known, hits that can no longer reach the threshold drop out, and the
     // next operand's gather is issued.  After the last operand the scores are final and the keys go to the candidate buffer.
-    uint32_t bmc[ND];      // the CURRENT tile's block maxima (see bmx)
-#pragma unroll
-    for (uint32_t i = 0; i < ND; ++i) bmc[i] = 0u;
     uint32_t f_stage = 0;  // 0: idle; i + 1: operand i's gather is in flight
     uint32_t f_doc = 0, f_idx[ND];
     float f_vc = 0.0f, f_vd[ND];
@@ -466,8 +455,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     auto flush_sync = [&]() {
         const ProbeShape<ND> S = probe_shape<ND>(sh);
         probe_lds_fence();
-        const uint32_t count = rn < 64u ? rn : 64u;
-        const bool on = lane < count;
         const uint32_t slot = (rhead + lane) & (kPR - 1u);
         const uint32_t doc = rq[slot];
         const float vc = posting_value(S.cts, (uint16_t)rq[kPR + slot]);
@@ -475,59 +462,70 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
             const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[i]);
-            vd[i] = posting_value(S.ts[i], as_global(sp)[on ? rq[(2u + i) * kPR + slot] : 0u]);
+            vd[i] = posting_value(S.ts[i], as_global(sp)[rq[(2u + i) * kPR + slot]]);
         }
-        if (stat && lane == 0) *stat += 2u * ND * count;
+        if (stat && lane == 0) *stat += 2u * ND * 64u;
         const float score = probe_sum<ND>(S, vc, vd);
         const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
-        rhead = (rhead + count) & (kPR - 1u);
-        rn -= count;
-        push_keys(key, on && key > *thr && key < cs.upper, false);
+        rhead = (rhead + 64u) & (kPR - 1u);
+        rn -= 64u;
+        push_keys(key, key > *thr && key < cs.upper, false);
     };
     // Rank the first `cnt` (<= 64) entries of the unranked queue — live hits of the CURRENT tile, whose words are in LDS — into the ranked
-    // queue: index in dense operand i = entries below the doc's 16-byte vector (pre) + set bits of the vector's words below the doc.  The
-    // rest of the unranked queue moves to the front.
+    // queue: index in dense operand i = rank directory entry of the doc's 512-doc group + set bits of the group below the doc.  The rest
+    // of the unranked queue moves to the front.
     auto rank_some = [&](const uint32_t cnt) {
+        while (rn + cnt > kPR) flush_sync();  // uniform, warm-up only
         probe_lds_fence();
-        // ---- block-max pruning: what the hit can reach with every dense operand at the largest score of the doc's 512-doc block (streamed
-        // with the tile: 2 B per block and operand) instead of the whole list's.  Few live hits survive it — only those are ranked and scored.
-        const uint32_t e = lane < cnt ? uq[lane] : 0u;
-        const uint32_t rel = e >> 16;  // doc - tile_lo
-        bool keep = lane < cnt;
-        {
-            const ProbeShape<ND> S = probe_shape<ND>(sh);
-            const float thr_f = __uint_as_float(unorder_f32((uint32_t)(*thr >> 32)));  // NaN while there is no threshold: nothing is dropped
-            const float vc = posting_value_fast(S.cts, (uint16_t)(e & 0xFFFFu));
-            float vb[ND];
+        if (ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
+            const uint32_t el = lane & 31u, role = lane >> 5;
+            if (el < cnt) {
+                const uint32_t e = uq[el];
+                const uint32_t rel = e >> 16;  // doc - tile_lo
+                const uint32_t slot = (rhead + rn + el) & (kPR - 1u);
+                if (role == 0u) {
+                    rq[slot] = tile_lo + rel;
+                    rq[kPR + slot] = e & 0xFFFFu;
+                }
+                const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
+                const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
+                const uint32_t* tl = tile + role * kPTW;
+                uint32_t acc = rank[role * kPRk + g] + (uint32_t)__popc(tl[rel >> 5] & below);
+                const u32x4* gw = reinterpret_cast<const u32x4*>(tl + g * 16u);
+#pragma unroll
+                for (uint32_t v4 = 0; v4 < 4; ++v4) {
+                    const u32x4 x = gw[v4];
+                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
+                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
+                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
+                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
+                }
+                rq[(2u + role) * kPR + slot] = acc;
+            }
+        } else if (lane < cnt) {
+            const uint32_t e = uq[lane];
+            const uint32_t rel = e >> 16;  // doc - tile_lo
+            const uint32_t slot = (rhead + rn + lane) & (kPR - 1u);
+            rq[slot] = tile_lo + rel;
+            rq[kPR + slot] = e & 0xFFFFu;
+            const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
+            const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
 #pragma unroll
             for (uint32_t i = 0; i < ND; ++i) {
-                const uint32_t braw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel >> kRankShift) << 2), (int)bmc[i]) & 0xFFFFu;  // (every lane takes part)
-                vb[i] = (braw < 0x7C00u && S.vmax[i] < __uint_as_float(0x7F800000u)) ? posting_value_fast(S.ts[i], (uint16_t)braw) : S.vmax[i];  // (+inf: no bound for this operand)
-            }
-            keep = keep && !(probe_sum<ND>(S, vc, vb) < thr_f);
-        }
-        const unsigned long long km = wballot(keep);
-        const uint32_t nk = (uint32_t)__popcll(km);
-        if (nk) {  // uniform
-            while (rn + nk > kPR) flush_sync();  // uniform, warm-up only
-            if (keep) {
-                const uint32_t slot = (rhead + rn + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) & (kPR - 1u);
-                rq[slot] = tile_lo + rel;
-                rq[kPR + slot] = e & 0xFFFFu;
-                const uint32_t v = rel >> 7, wi = (rel >> 5) & 3u, below = (1u << (rel & 31u)) - 1u;
-                const int full = (int)((1u << wi) - 1u), eq = (int)(1u << wi);  // bit j: word j of the vector lies entirely below the doc / holds it
-                const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe(full, 0u, 1u) | ((uint32_t)__builtin_amdgcn_sbfe(eq, 0u, 1u) & below);
-                const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe(full, 1u, 1u) | ((uint32_t)__builtin_amdgcn_sbfe(eq, 1u, 1u) & below);
-                const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe(full, 2u, 1u) | ((uint32_t)__builtin_amdgcn_sbfe(eq, 2u, 1u) & below);
-                const uint32_t m3 = (uint32_t)__builtin_amdgcn_sbfe(eq, 3u, 1u) & below;
+                uint32_t acc = rank[i * kPRk + g] + (uint32_t)__popc(tile[i * kPTW + (rel >> 5)] & below);
+                const u32x4* gw = reinterpret_cast<const u32x4*>(tile + i * kPTW + g * 16u);
 #pragma unroll
-                for (uint32_t i = 0; i < ND; ++i) {
-                    const u32x4 x = reinterpret_cast<const u32x4*>(tile + i * kPTW)[v];
-                    rq[(2u + i) * kPR + slot] = pre[i * kPPre + v] + (uint32_t)(__popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3));
+                for (uint32_t v4 = 0; v4 < 4; ++v4) {
+                    const u32x4 x = gw[v4];
+                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
+                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
+                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
+                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
                 }
+                rq[(2u + i) * kPR + slot] = acc;
             }
-            rn += nk;
         }
+        rn += cnt;
         if (un > cnt) {  // uniform
             const uint32_t rem = un - cnt;
             constexpr uint32_t kMove = kPU / 64u;
@@ -591,26 +589,15 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         PS_COUNT(8)
         // ---- top of the tile: everything in flight lands here — one wait for all of it (vmcnt(0); the compiler's own bookkeeping sees the
         // instruction and knows of nothing in flight behind it, so none of ITS waits can fall behind the next tile's loads)
-        asm volatile("; probe: tile top");
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_setprio(3);  // a wave whose data has landed goes first until its next loads are out: the memory side idles while loads wait behind other waves' arithmetic
+        __builtin_amdgcn_s_setprio(3);  // a wave whose data has landed goes first until its next loads are out (nothing it does in between should queue behind other waves' arithmetic)
         const uint32_t rounds = pf_rounds, v0 = pf_v0;
-        uint32_t pc[ND][kPNV / 2], rkc[ND];
-        // set bits of the lane's vectors (two packed into a word), the operand's rank below the tile
-        if (rounds) {  // uniform: the tile's words go to LDS; what the next loads will overwrite is taken out of their registers
+        if (rounds) {  // uniform
 #pragma unroll
             for (uint32_t i = 0; i < ND; ++i) {
 #pragma unroll
                 for (uint32_t h = 0; h < kPNV; ++h) reinterpret_cast<u32x4*>(tile + i * kPTW)[h * 64u + lane] = wk[i][h];
-#pragma unroll
-                for (uint32_t j = 0; j < kPNV / 2; ++j) {
-                    const u32x4 a = wk[i][2 * j], b = wk[i][2 * j + 1];
-                    const uint32_t c0 = (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
-                    const uint32_t c1 = (uint32_t)(__popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
-                    pc[i][j] = c0 | (c1 << 16);  // (at most 8192 per half: no carry between the halves in the scan below)
-                }
-                rkc[i] = rk[i];
-                bmc[i] = bmx[i];
+                rank[i * kPRk + lane] = rk[i];
             }
 #pragma unroll
             for (uint32_t r = 0; r < kPMaxR; ++r) {
@@ -621,6 +608,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 asm volatile("" : "+v"(cid[r]), "+v"(csc[r]));
             }
         }
+        // ---- first everything that CONSUMES a load of the last period (the flush in flight, the shared threshold word) ...
         {  // (every register a load of the last period wrote is touched here, where all of them have landed: behind this point the compiler
            //  knows of nothing in flight, and none of its waits can fall behind the next tile's loads)
             uint32_t fr = f_r, glo = (uint32_t)g_prev, ghi = (uint32_t)(g_prev >> 32);
@@ -640,31 +628,14 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             ne0 = dir_at(t + 1u);
             ne1 = dir_at(t + 2u);
         }
-        // ---- the NEXT tile's loads go out as early as possible: a wave has nothing in flight between the wait above and this point, and
-        // the memory side only stays busy while enough waves have.  Everything below works on what has landed, with those loads in flight.
-        asm volatile("; probe: issue tile");
+        if (f_stage || rn >= 64u) PS_COUNT(11)
+        flush_service(false);  // takes the gather issued a tile ago, issues the next one (the LAST consumer of an old load: behind it only new ones go out)
+        PS_AT(4)
+        // ---- ... then everything the NEXT tile needs is asked for, and nothing below waits for any of it
         if (more) issue_tile(t + 1u, ne0, ne1);  // uniform
         else pf_rounds = 0;
         if (lane == 0) g_prev = __hip_atomic_load(gthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
-        PS_AT(5)
-        if (rounds) {  // uniform: ranks below the lane's vectors (vector h * 64 + l: words 256 h + 4 l ..): two vectors' counts ride one scan
-#pragma unroll
-            for (uint32_t i = 0; i < ND; ++i) {
-                uint32_t base = rkc[i];
-#pragma unroll
-                for (uint32_t j = 0; j < kPNV / 2; ++j) {
-                    uint32_t total;
-                    const uint32_t ex = wave_excl_scan_u32(pc[i][j], &total);
-                    pre[i * kPPre + (2 * j) * 64u + lane] = base + (ex & 0xFFFFu);
-                    pre[i * kPPre + (2 * j + 1) * 64u + lane] = base + (total & 0xFFFFu) + (ex >> 16);
-                    base += (total & 0xFFFFu) + (total >> 16);
-                }
-            }
-        }
-        if (f_stage || rn >= 64u) PS_COUNT(11)
-        asm volatile("; probe: flush service");
-        flush_service(false);  // takes the gather issued a tile ago, issues the next one
         probe_lds_fence();
         {
             const unsigned long long tn = *thr;
@@ -672,9 +643,9 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             thr_seen = tn;
             ++tiles_since_merge;
         }
-        PS_AT(4)
+        PS_AT(5)
 #ifdef VQ_PROBE_STREAM_ONLY  // diagnostic build: the loads and the LDS fill only (what the memory side alone takes)
-        hits += (unsigned long long)__popcll(wballot((cid[0].x ^ csc[0].x ^ cid[kPMaxR - 1].y ^ csc[kPMaxR - 1].y) == 0x12345u));  // (keeps the cover loads alive)
+        hits += (unsigned long long)__popcll(wballot((cid[0].x ^ csc[0].x ^ cid[1].y ^ csc[1].y) == 0x12345u));  // (keeps the cover loads alive)
         if (rounds && span == 0xFFFFFFFFu) {
 #else
         if (rounds) {  // uniform
@@ -684,7 +655,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
             lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
             width = tile_hi - lo_bound;
-            asm volatile("; probe: rounds");
             {  // the register rounds: every LDS read of the tile's postings goes out first, then the few hits are picked up
                 ProbeWords pw[kPMaxR];
 #pragma unroll
@@ -717,7 +687,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             }
             PS_AT(3)
         }
-        asm volatile("; probe: tile end");
         ++t;
         tile_lo += kPT;
     }
@@ -735,7 +704,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     PS_FLUSH
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kTileDirShift >= 15 ? 3 : 4, 8))) void k_scan_probe(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_scan_probe(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                                                                const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                                                                uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
                                                                                                unsigned long long* __restrict__ num_hits) {
