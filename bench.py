@@ -292,7 +292,7 @@ def roofline_object(table, docs, triples, batch, workload, world):
                     "2-4 B per gathered score / value as counted by the kernel, 8 B per key) / mean launch time from HIP events inside the timed region"}
     # HBM traffic from PMC passes is taken offline (rocprofv3 cannot wrap a region of this process): reported only when a committed
     # profile was taken on exactly this configuration, and labelled as such
-    for fn in ("r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 tr = json.load(f)
