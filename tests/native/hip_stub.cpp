@@ -82,11 +82,20 @@ hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 }
 
 namespace vq {
-[[noreturn]] static void no_device(const char* what) { throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("device layer stubbed: ") + what); }
+// VQ_STUB_NOOP_LAUNCH=1 (tools/host_step_profile.py only): launches do nothing instead of throwing, so that the host side of a whole step
+// (compile, pack, launch calls, result assembly — over garbage "results") can be timed on a machine without a GPU
+static void no_device(const char* what) {
+    static const bool noop = std::getenv("VQ_STUB_NOOP_LAUNCH") != nullptr;
+    if (noop) return;
+    throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("device layer stubbed: ") + what);
+}
 size_t tile_scan_lds_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool, uint32_t) { return 0; }
 size_t scan_simple_lds_bytes(uint32_t, uint32_t, uint32_t, bool) { return 0; }
 size_t scan_wide_lds_bytes(uint32_t, uint32_t, uint32_t) { return 0; }
-uint32_t debug_div100_mismatches() { no_device("debug_div100_mismatches"); }
+uint32_t debug_div100_mismatches() {
+    no_device("debug_div100_mismatches");
+    return 0;
+}
 void launch_tile_scan(hipStream_t, uint32_t, size_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t, unsigned long long*,
                       unsigned long long*, uint32_t*, bool, uint32_t, bool) { no_device("k_tile_scan"); }
 void launch_scan_leaf_f32(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*, uint32_t*) {

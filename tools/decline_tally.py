@@ -19,6 +19,7 @@ for i in range(600):
         key = (e.kind, str(e)[:110])
         why[key] += 1
         ex.setdefault(key, json.dumps(req)[:400])
+print(f"600 random requests (the generator of test_random_requests_on_reference_corpus_match_the_oracle, seed 20241003): {sum(why.values())} declined")
 for k, v in why.most_common():
     print(v, k)
     print("    e.g.", ex[k])

@@ -543,6 +543,7 @@ struct ExplainPlan {
 };
 
 struct CompiledQuery {
+    size_t blob_bytes = 0, desc_bytes = 0;  // size of the packed blob / of its descriptor part, taken right after compilation on the compiling thread (0: not taken)
     int status = 0;
     std::shared_ptr<const ExplainPlan> explain_plan;  // request.explain: what complete_explain_requests needs for the returned hits
     std::string error;

@@ -873,6 +873,14 @@ static void run_count_queries(const Index& idx, Workspace& ws, const std::vector
 }
 
 
+// blob and descriptor size of a compiled query (a dry run of pack_blob), kept with it: the serial part of a step does not walk every query three times
+static void size_blob(CompiledQuery& cq, const Index& idx) {
+    if (cq.status != 0) return;
+    size_t d = 0;
+    cq.blob_bytes = pack_blob(cq, idx, nullptr, nullptr, 0, 0, {}, {}, &d);
+    cq.desc_bytes = d;
+}
+
 std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request* const* reqs, size_t n, int slot, int64_t arena_offset) {
     const double t_start = now_ms();
     auto pb = std::make_unique<PartialBatch>();
@@ -926,7 +934,10 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             if (!reqs[i]) {
                 pb->queries[i].status = ERR_INVALID_ARGUMENT;
                 pb->queries[i].error = "null request";
-            } else pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy, nullptr, nullptr, nullptr, &boost_cache);
+            } else {
+                pb->queries[i] = compile_query(idx, *reqs[i], fuzzy.empty() ? nullptr : &fuzzy, nullptr, nullptr, nullptr, &boost_cache);
+                size_blob(pb->queries[i], idx);
+            }
         }
     };
     if (n >= 64) {  // query compilation is independent per request: fan out over the index's host threads
@@ -1000,6 +1011,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                         q.status = ERR_UNSUPPORTED;
                         q.error = "unsupported on the MI355X query path: leaf expansion changed between compilation passes (internal)";
                     }
+                    size_blob(q, idx);
                 }
             };
             if (again.size() >= 8 && host_threads() > 1) {
@@ -1121,7 +1133,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         }
         hist_offs.push_back(std::move(ho));
         fac_out_offs.push_back(std::move(fo));
-        blob_bytes += pack_blob(cq, idx, nullptr, nullptr, 0, 0, {}, {});
+        if (!cq.blob_bytes) size_blob(cq, idx);  // (normally taken on the compiling thread)
+        blob_bytes += cq.blob_bytes;
         max_lists = std::max<uint32_t>(max_lists, uint32_t(cq.lists.size()));
         max_ww = std::max(max_ww, cq.tile_words);
         stack_depth = std::max(stack_depth, cq.stack_depth);
@@ -1134,6 +1147,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     pb->n_facet_jobs = uint32_t(jobs.size());
     pb->total_facet_out = fac_out_total;
     pb->facet_jobs = jobs;
+    const double t_layout = now_ms();
 
     PartialLayout& lay = pb->layout;
     lay.nq = nq;
@@ -1189,8 +1203,10 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
             CompiledQuery& cq = pb->queries[i];
             if (cq.status != 0) continue;
             hbo[qi] = uint32_t(off);
-            off += pack_blob(cq, idx, hup + off, dup + off, keys_base[qi], part_keys_off[qi], hist_offs[qi], fac_out_offs[qi], nullptr,
-                             pb->profiled ? uint32_t((lay.off_stats - lay.off_hits) / 8 + qi) : 0u);  // 0: the kernels count nothing
+            const size_t packed = pack_blob(cq, idx, hup + off, dup + off, keys_base[qi], part_keys_off[qi], hist_offs[qi], fac_out_offs[qi], nullptr,
+                                            pb->profiled ? uint32_t((lay.off_stats - lay.off_hits) / 8 + qi) : 0u);  // 0: the kernels count nothing
+            if (packed != cq.blob_bytes) throw VelociError(ERR_DEVICE, "query blob changed size between compilation and packing (internal)");
+            off += packed;
             ++qi;
         }
         hbo[nq] = uint32_t(off);
@@ -1303,6 +1319,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     pb->d_facet_jobs = reinterpret_cast<const FacetJob*>(dup + up_jobs);
     if (nq == 0) return pb;
 
+    const double t_packed = now_ms();
     VQ_HIP(hipMemcpyAsync(dup, hup, up_bytes, hipMemcpyHostToDevice, st));
     ws.d_span_keys.ensure(size_t(total_span_keys) * 8 + 16);
     if (arena_offset >= 0) {  // a chunk of a sharded step with one collective: its partial lives in the index's arena
@@ -1323,9 +1340,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t desc_cap = 0;  // bytes of the largest query descriptor (staged into LDS by every workgroup)
     for (size_t i = 0; i < n; ++i)
         if (pb->queries[i].status == 0) {
-            size_t d = 0;
-            pack_blob(pb->queries[i], idx, nullptr, nullptr, 0, 0, {}, {}, &d);
-            desc_cap = std::max(desc_cap, uint32_t(d));
+            desc_cap = std::max(desc_cap, uint32_t(pb->queries[i].desc_bytes));
         }
     desc_cap = uint32_t(align_up(desc_cap, 16));
     bool facets_generic = false;  // k_tile_scan queries with facets: room for the LDS counter cache behind the descriptor
@@ -1403,6 +1418,8 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         std::fprintf(stderr, "[vq timing] n=%zu compile %.3f ms (dictionary scans %.3f [%zu probes], pass 1 %.3f, unions %.3f [%zu jobs], pass 2 %.3f), range jobs %.3f [%zu], spans generic/simple/and/rich/union %u/%u/%u/%u/%u, pack+launch %.3f ms\n", n,
                      t_compiled - t_start, t_probes - t_start, fuzzy.size(), t_pass1 - t_probes, t_unions - t_pass1, unions.size(), t_compiled - t_ranges,
                      t_ranges - t_unions, ranges.size(), spans_generic, spans_simple, spans_wide, spans_rich, spans_dense + spans_leaf, now_ms() - t_compiled);
+    if (timing_enabled())
+        std::fprintf(stderr, "[vq timing] pack+launch: span sizing + layout %.3f, blobs + tables %.3f, upload + launches %.3f ms\n", t_layout - t_compiled, t_packed - t_layout, now_ms() - t_packed);
     if (timing_enabled()) {  // thread-time inside compile_query since the last batch (all passes, all threads)
         uint64_t v[16];
         for (int k = 0; k < 16; ++k) v[k] = g_compile_ns[k].exchange(0);
