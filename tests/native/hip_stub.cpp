@@ -148,8 +148,14 @@ void launch_dict_scan(hipStream_t, const DictProbe* probes, uint32_t probe_base,
 void launch_loc_gather(hipStream_t, const LocRow*, uint32_t, const uint32_t*, uint32_t*) { no_device("k_loc_gather"); }
 void launch_loc_expand(hipStream_t, bool, const LocJob*, uint32_t, const uint32_t*, uint32_t, uint32_t*, unsigned long long*) { no_device("k_loc_expand"); }
 void launch_loc_compact(hipStream_t, const LocJob*, uint32_t, const unsigned long long*, uint32_t*, float*, uint32_t*) { no_device("k_loc_compact"); }
-size_t seg_sort_u32(void*, size_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) { no_device("seg_sort_u32"); }
-size_t seg_sort_u64(void*, size_t, const unsigned long long*, unsigned long long*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) { no_device("seg_sort_u64"); }
+size_t seg_sort_u32(void*, size_t, const uint32_t*, uint32_t*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) {
+    no_device("seg_sort_u32");
+    return 0;
+}
+size_t seg_sort_u64(void*, size_t, const unsigned long long*, unsigned long long*, uint32_t, uint32_t, const uint32_t*, const uint32_t*, hipStream_t) {
+    no_device("seg_sort_u64");
+    return 0;
+}
 void launch_b1n_map(hipStream_t, const B1nJob*, uint32_t, const uint32_t*, uint32_t*, float*, B1nResult*) { no_device("k_b1n_map"); }
 void launch_explain(hipStream_t, uint32_t, const ExQuery*, const uint32_t*, const uint32_t*, const ExOp*, const uint16_t*, const ExList*, const DColBoost*, uint32_t*) { no_device("k_explain"); }
 }  // namespace vq

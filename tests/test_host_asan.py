@@ -25,4 +25,10 @@ def test_host_side_under_asan_and_ubsan():
     assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, tail
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail
     stats = json.loads(r.stdout.split("ASAN_DRIVER_OK ", 1)[1])
+    # whole pipelined steps over a "device" whose launches do nothing (compile, pack, launch calls, result assembly, the background reaper)
+    r2 = subprocess.run([sys.executable, os.path.join(HERE, "native", "asan_step_driver.py")], capture_output=True, text=True, timeout=900, env=dict(env, VQ_STUB_NOOP_LAUNCH="1"))
+    tail2 = r2.stdout[-1500:] + r2.stderr[-6000:]
+    assert r2.returncode == 0 and "ASAN_STEP_DRIVER_OK" in r2.stdout, tail2
+    assert "ERROR: AddressSanitizer" not in r2.stderr and "runtime error:" not in r2.stderr, tail2
+    assert json.loads(r2.stdout.split("ASAN_STEP_DRIVER_OK ", 1)[1])["steps"] >= 4
     assert stats["parsed"] > 100 and stats["compiled"] > 70 and stats["ready"] > 30 and stats["device_errors"] > 10 and stats["highlighted"] > 80 and stats["highlight_errors"] > 5, stats
