@@ -1,7 +1,7 @@
 """Second driver of the CPU sanitizer build (tests/test_host_asan.py, with VQ_STUB_NOOP_LAUNCH=1: the stubbed launchers return instead of throwing):
 the host side of whole pipelined steps — vq_shard_step_begin / _end with two steps in flight, with and without facets, through the custom exchange of
 two shards in one process — runs to the end over whatever the stubbed "device" memory holds: compile, pack, the launch calls, merge bookkeeping,
-result assembly, copy-out and the background thread that frees a finished step.  Results are garbage; any sanitizer report aborts the process."""
+result assembly and copy-out.  Results are garbage; any sanitizer report aborts the process."""
 import json
 import os
 import sys

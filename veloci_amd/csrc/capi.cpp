@@ -5,12 +5,7 @@
 #include <cstring>
 
 #include "../../include/veloci_amd.h"
-#include <condition_variable>
 #include <functional>
-#include <memory>
-#include <mutex>
-#include <thread>
-#include <type_traits>
 #include <future>
 
 #include <dlfcn.h>
@@ -223,54 +218,6 @@ void dump_parts(std::string& s, const std::optional<std::vector<vqreq::RequestSe
         dump_part(s, (*v)[i]);
     }
     s += ']';
-}
-}  // namespace
-
-// What a finished step leaves behind — 1024 compiled queries, 1024 result objects: tens of thousands of small frees — is handed to one background
-// thread instead of being destroyed on the caller's: on a small shard the step's host time IS the step time (0.25 ms of a 1.1 ms step).
-namespace {
-class Reaper {
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::vector<std::shared_ptr<void>> q_;
-    bool stop_ = false;
-    std::thread th_;
-    void run() {
-        for (;;) {
-            std::vector<std::shared_ptr<void>> take;
-            {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [&] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return;  // (stop_)
-                take.swap(q_);
-            }
-            take.clear();  // the destructors run here
-        }
-    }
-
-public:
-    Reaper() : th_([this] { run(); }) {}
-    ~Reaper() {
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            stop_ = true;
-        }
-        cv_.notify_one();
-        th_.join();
-    }
-    template <class T>
-    void give(T&& x) {
-        std::shared_ptr<void> p(new typename std::decay<T>::type(std::move(x)), [](void* v) { delete static_cast<typename std::decay<T>::type*>(v); });
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            q_.push_back(std::move(p));
-        }
-        cv_.notify_one();
-    }
-};
-Reaper& reaper() {
-    static Reaper r;
-    return r;
 }
 }  // namespace
 
@@ -1273,8 +1220,8 @@ int vq_shard_step_end(vq_shard_step* step_raw, size_t stride, uint64_t* num_hits
             decline_deep(results, st, errs);
             decline_explain(results, st, errs, "the sharded step");
             copy_flat(results, st, errs, step->first[k], stride, num_hits, counts, ids, scores, status);
-            reaper().give(std::move(step->pbs[k]));  // (finished: its destructor only frees host memory)
-            reaper().give(std::move(results));
+            step->pbs[k].reset();  // (destroyed here, by the thread that uses these allocations next: handing the frees to a background thread was tried and
+                                   //  cost more than it saved — it frees into the arenas the compile threads are allocating from)
         }
         if (timing) std::fprintf(stderr, "[vq timing] shard step end total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count());
     });

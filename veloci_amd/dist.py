@@ -113,19 +113,23 @@ class ShardedSearcher:
             L = _lib.lib()
             rank = dist.get_rank(group)
             failed = 0
+            ident = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8)  # the id + one byte: rank 0 has no id to give (nobody may wait for it in the init)
             try:
-                ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
                 if rank == 0:
                     buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
                     _lib.check(L.vq_comm_unique_id(buf))
-                    ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+                    ident[:_lib.COMM_ID_BYTES] = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
             except Exception as e:  # noqa: BLE001 — e.g. no RCCL library to load: every rank must learn of it (below)
                 failed, err = 1, e
+                ident[_lib.COMM_ID_BYTES] = 1
             ident = ident.cuda()
             dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = ident.cpu()
+            if not failed and int(ident[_lib.COMM_ID_BYTES]) != 0:
+                failed, err = 1, RuntimeError("rank 0 could not create a communicator id")
             if not failed:
                 try:
-                    _lib.check(L.vq_comm_init(index.h, self.world, rank, bytes(ident.cpu().numpy().tobytes())))
+                    _lib.check(L.vq_comm_init(index.h, self.world, rank, bytes(ident[:_lib.COMM_ID_BYTES].numpy().tobytes())))
                 except Exception as e:  # noqa: BLE001
                     failed, err = 1, e
             # the ranks agree on the path: one rank on the library's exchange and another on this module's would never meet in a collective
