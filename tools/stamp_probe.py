@@ -32,5 +32,7 @@ tiles = max(v[8], 1)
 print(f"batch of 1024: {dt * 1e3:.2f} ms; waves' time by phase (s_memtime ticks = shader cycles), {tiles} tiles:")
 for k, n in names.items():
     print(f"  {n:60s} {v[k] / tot * 100:6.2f}%   {v[k] / tiles:9.0f} cycles/tile")
+if v[15]:
+    print(f"  shader clock while the spans ran: {v[14] / v[15] * 100:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick)")
 print(f"  total {tot / tiles:.0f} cycles per tile and wave; rounds/tile {v[9] / tiles:.2f}, rank steps/tile {v[10] / tiles:.3f}, flush services/tile {v[11] / tiles:.3f}, "
       f"final stages/tile {v[12] / tiles:.3f}, pool merges/tile {v[13] / tiles:.3f}")

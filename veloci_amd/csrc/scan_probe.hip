@@ -33,8 +33,10 @@ namespace vq {
 // Diagnostic build only (make stamp): time shares of the kernel's phases, summed over all waves (s_memtime ticks), and event counts.
 #ifdef VQ_STAMP
 __device__ unsigned long long g_probe_stamp[16];
-#define PS_INIT                                             \
-    unsigned long long _st0 = __builtin_amdgcn_s_memtime(); \
+#define PS_INIT                                                      \
+    unsigned long long _st0 = __builtin_amdgcn_s_memtime();          \
+    const unsigned long long _t0 = _st0;                             \
+    const unsigned long long _r0 = __builtin_amdgcn_s_memrealtime(); \
     unsigned long long _acc[16] = {0};
 #define PS_AT(k)                                                \
     {                                                           \
@@ -44,6 +46,8 @@ __device__ unsigned long long g_probe_stamp[16];
     }
 #define PS_COUNT(k) _acc[k] += 1ull;
 #define PS_FLUSH                                                                                             \
+    _acc[14] = __builtin_amdgcn_s_memtime() - _t0;     /* shader-clock ticks of the span */                   \
+    _acc[15] = __builtin_amdgcn_s_memrealtime() - _r0; /* constant 100 MHz ticks of the span */               \
     if (threadIdx.x == 0) {                                                                                  \
         _Pragma("unroll") for (int _k = 0; _k < 16; ++_k) if (_acc[_k]) atomicAdd(&g_probe_stamp[_k], _acc[_k]); \
     }
