@@ -1,5 +1,5 @@
-# Round-3 counter evidence for the dominant kernels of configs #3 and #4 (k_scan_simple<2,rich>, k_dict_scan, k_scan_union, k_union): rocprofv3 kernel
-# stats, FETCH_SIZE / WRITE_SIZE and the SQ instruction / cycle sets, one pass each.  usage: bash tools/profile_r03_configs.sh
+# Round-3 counter evidence for the dominant kernels of configs #2, #3 and #4 (k_scan_union, k_scan_simple<2,rich>, k_dict_scan, k_union): rocprofv3 kernel
+# stats, FETCH_SIZE / WRITE_SIZE and the SQ instruction / cycle sets, one pass each.  usage: bash tools/profile_r03_configs.sh [config2|config3|config4 ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03_configs; mkdir -p $O
 prof() {  # tag, bench args...
@@ -16,5 +16,12 @@ prof() {  # tag, bench args...
         [ -f $S/sum.csv ] && { head -1 $S/sum.csv > $O/${tag}_pmc_$name.csv; grep "vq::" $S/sum.csv >> $O/${tag}_pmc_$name.csv; }
     done
 }
-prof config3 --workload config3 --docs 10000000 --terms 1000000 --triples 32 && prof config4 --workload config4 --docs 10000000 --terms 1000000 --triples 32
-ls $O; head -5 $O/config3_kernel_stats.csv | cut -c1-150
+[ $# -eq 0 ] && set -- config3 config4
+for c in "$@"; do
+    case $c in
+        config2) prof config2 --workload single --docs 100000000 || exit 1;;  # (the default run's config2_100m_docs leg: single-term scans over the 256 triples' lists)
+        config3) prof config3 --workload config3 --docs 10000000 --terms 1000000 --triples 32 || exit 1;;
+        config4) prof config4 --workload config4 --docs 10000000 --terms 1000000 --triples 32 || exit 1;;
+    esac
+done
+ls $O
