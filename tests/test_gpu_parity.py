@@ -1479,6 +1479,48 @@ def test_sharded_step_inside_the_library_over_rccl_with_one_rank(corpus):
     _lib.check(L.vq_comm_destroy(idx.h))
 
 
+def test_sharded_step_error_paths_leave_the_index_usable(corpus):
+    """What a caller can get wrong with the step functions: a third step begun while two are in flight, a stride smaller than a request's top,
+    a step given up without its end (vq_shard_step_free), a step of zero requests, requests the path declines inside a step — each answered with
+    its error (or status), none of them leaving a workspace locked or a merge pending: the next steps still equal the oracle."""
+    import ctypes as C
+    import veloci_amd
+    from veloci_amd import _lib, synth
+    from veloci_amd.dist import shard_step_begin, shard_step_end
+    data, meta, idx0, ora = corpus
+    idx = veloci_amd.Index(data, device=0)
+    L = _lib.lib()
+    a = list(meta.triples[0])
+    reqs = [synth.req_and(a), synth.req_or(a, top=30), synth.req_single(meta.extra_probes[0])] * 40
+    batch = veloci_amd.RequestBatch(reqs)
+    cache = {}
+    s1 = shard_step_begin(idx, batch)
+    s2 = shard_step_begin(idx, batch)
+    with pytest.raises(veloci_amd.VelociError) as e:
+        shard_step_begin(idx, batch)
+    assert e.value.kind == "InvalidArgument" and "two steps are in flight" in str(e.value)
+    with pytest.raises(veloci_amd.VelociError) as e:  # top 30 does not fit a stride of 10: the step is consumed by the failed end
+        shard_step_end(s1, 10)
+    assert "stride" in str(e.value)
+    _check_flat_rows(reqs, shard_step_end(s2, 32), ora, cache)
+    s3 = shard_step_begin(idx, batch)  # given up without an end: its scans are waited for, its workspace is handed on
+    L.vq_shard_step_free(s3[0])
+    empty = veloci_amd.RequestBatch([])
+    out = shard_step_end(shard_step_begin(idx, empty), 10)
+    assert len(out[0]) == 0
+    # a request the path declines (select) and one that fails to compile (unknown field) ride along: statuses, not a failed step
+    mixed = reqs[:6] + [dict(synth.req_single(meta.extra_probes[0]), select=["body"]), {"search_req": {"search": {"terms": ["x"], "path": "nosuchfield"}}}]
+    mb = veloci_amd.RequestBatch(mixed)
+    res = shard_step_end(shard_step_begin(idx, mb), 32)
+    assert list(res[4][:6]) == [0] * 6 and res[4][6] != 0 and res[4][7] != 0
+    _check_flat_rows(mixed[:6], tuple(x[:6] for x in res), ora, cache)
+    for _ in range(2):  # and the pipeline still runs
+        s4 = shard_step_begin(idx, batch)
+        s5 = shard_step_begin(idx, batch)
+        _check_flat_rows(reqs, shard_step_end(s4, 32), ora, cache)
+        _check_flat_rows(reqs, shard_step_end(s5, 32), ora, cache)
+
+
 def test_rccl_collective_path_with_one_rank(corpus, monkeypatch):
     """dist.ShardedSearcher on the `nccl` (= RCCL) backend with a single rank.  First the module's own exchange (VQ_PY_COLLECTIVE=1): the
     scans run on a torch side stream handed to the index (vq_index_set_stream), the packed partial is all-gathered by RCCL as a zero-copy
