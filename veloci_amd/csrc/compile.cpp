@@ -2163,7 +2163,10 @@ struct Compiler {
         const bool probe_like = (cq.simple_flags >> 25) & 1u;  // k_scan_probe prunes by the query's shared threshold: long spans warm up once (launches of 512: 4.29 ms at 128 Ki, 3.77 ms at 1 Mi)
         // (on a small shard the same number of spans per query is kept — a 1/8 shard with 1 Mi-posting spans would leave half the chip without a wave)
         const uint64_t probe_span = std::min<uint64_t>(std::max<uint64_t>(range / 96, 131072), 1048576);
-        const uint64_t span_postings = span_env ? span_env : (probe_like ? probe_span : and_like ? 131072 : wide_like ? 589824 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
+        // a plain simple OR prunes by its threshold too: on a large shard longer spans warm up once (3-term OR on 100 M docs, launches of 1024: 9.99 ms at 256 Ki,
+        // 9.57 at 512 Ki, 9.64 at 1 Mi, 10.86 at 2 Mi); a small shard keeps the span count that fills the chip
+        const bool or_like = cq.simple_flags && !((cq.simple_flags >> 18) & 1u) && !wide_like && !probe_like && cq.simple_n > 1 && cq.ops.back().kind == OP_OR;
+        const uint64_t span_postings = span_env ? span_env : (probe_like ? probe_span : and_like ? 131072 : wide_like ? 589824 : (or_like && range >= 50'000'000ull) ? 524288 : 262144);  // (wide, launches of 512: 29.7-29.8 k requests/s at 512 Ki, 29.8-30.1 k at 576 Ki, 29.8 k at 608 Ki; AND of two 4-term ORs 30.7 -> 31.3 k)
         uint32_t ww = ww_max;  // W = 32 * ww docs
         const size_t TL = size_t(L) + cq.n_temps;
         while (ww > 64 && (size_t(ww) + TL * ww + size_t(L) * ww / 2) * 4 > var_budget) ww >>= 1;
