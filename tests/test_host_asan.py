@@ -25,7 +25,7 @@ def test_host_side_under_asan_and_ubsan():
     assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, tail
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail
     stats = json.loads(r.stdout.split("ASAN_DRIVER_OK ", 1)[1])
-    # whole pipelined steps over a "device" whose launches do nothing (compile, pack, launch calls, result assembly, the background reaper)
+    # whole pipelined steps over a "device" whose launches do nothing (compile, pack, launch calls, result assembly, copy-out)
     r2 = subprocess.run([sys.executable, os.path.join(HERE, "native", "asan_step_driver.py")], capture_output=True, text=True, timeout=900, env=dict(env, VQ_STUB_NOOP_LAUNCH="1"))
     tail2 = r2.stdout[-1500:] + r2.stderr[-6000:]
     assert r2.returncode == 0 and "ASAN_STEP_DRIVER_OK" in r2.stdout, tail2
