@@ -109,6 +109,13 @@ void launch_scan_probe(hipStream_t, uint32_t, uint32_t, const uint8_t*, const ui
     no_device("k_scan_probe");
 }
 size_t scan_probe_lds_bytes(uint32_t, uint32_t) { return 0; }
+void launch_scan_ring(hipStream_t, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t*, unsigned long long*,
+                      unsigned long long*) {
+    no_device("k_scan_ring");
+}
+uint32_t scan_ring_consumers(uint32_t) { return 10; }
+uint32_t scan_ring_slots(uint32_t, uint32_t) { return 3; }
+size_t scan_ring_lds_bytes(uint32_t, uint32_t, uint32_t) { return 0; }
 void launch_merge_spans(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const unsigned long long*, unsigned long long*) { no_device("k_merge_spans"); }
 void launch_finalize(hipStream_t, uint32_t, const uint8_t*, const uint32_t*, const uint8_t*, uint32_t, size_t, const PartialLayout&, uint32_t*, float*, uint32_t*, unsigned long long*) {
     no_device("k_finalize");

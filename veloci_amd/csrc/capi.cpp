@@ -1289,6 +1289,7 @@ const char* vq_profile_json(const vq_index* i, int reset) {
 #ifdef VQ_STAMP
 void vq_debug_stamps(unsigned long long* out, int reset) { vq::debug_read_stamps(out, reset); }
 void vq_debug_probe_stamps(unsigned long long* out, int reset) { vq::debug_read_probe_stamps(out, reset); }
+void vq_debug_ring_stamps(unsigned long long* out, int reset) { vq::debug_read_ring_stamps(out, reset); }
 #endif
 
 }  // extern "C"

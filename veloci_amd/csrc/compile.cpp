@@ -2105,6 +2105,10 @@ struct Compiler {
                 }
                 if (seq) f |= 1u << 16;
                 if (probe) f |= 1u << 25;
+                // ... and with top + skip <= 32 (the candidate buffer is one key per lane, the query has a shared pool) the persistent form of that
+                // kernel, k_scan_ring: loader waves stream the tiles into LDS rings, consumer waves probe (VQ_NO_RING=1: k_scan_probe)
+                static const bool no_ring = std::getenv("VQ_NO_RING") != nullptr;
+                if (probe && !no_ring && cq.top_k >= 1 && cq.top_k <= kPoolMaxK) f |= 1u << 26;
                 for (uint32_t k = 0; k < cq.simple_n; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
                     const bool cover = l.flags & LIST_COVER;
@@ -2197,6 +2201,16 @@ struct Compiler {
             if (!cq.simple_flags && cq.total_len / visited < 1024) spans = std::max<uint64_t>(spans, visited / 16);
             if (((cq.simple_flags >> 18) & 1u) && cq.total_len / visited < 1024) spans = std::max<uint64_t>(spans, visited / 64);  // rich: 16384-doc tiles, cheaper each
         }
+        if ((cq.simple_flags >> 26) & 1u) {
+            // k_scan_ring: a persistent grid draws (query, span) items from a counter, span 0 of every query first: a span needs no length to
+            // warm its threshold up (the query's pool is warm after the first round) — short spans even out the end of the launch
+            static const uint64_t ring_tiles = [] {
+                const char* e = std::getenv("VQ_RING_SPAN_TILES");
+                return uint64_t(e ? std::max(1, std::atoi(e)) : 128);
+            }();
+            const uint64_t ptiles = std::max<uint64_t>((range + (1u << kTileDirShift) - 1) >> kTileDirShift, 1);
+            spans = (ptiles + ring_tiles - 1) / ring_tiles;
+        }
         spans = std::min<uint64_t>(spans, tiles);
         spans = std::min<uint64_t>(std::max<uint64_t>(spans, 1), 4096);
         cq.n_spans = uint32_t(spans);
@@ -2216,7 +2230,7 @@ struct Compiler {
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
         const bool simple = cq.simple_flags != 0;
         const bool wide = (cq.simple_flags >> 24) & 1u;
-        const uint64_t tile_docs = wide ? 8192 : ((cq.simple_flags >> 25) & 1u) ? (1u << kTileDirShift) : simple ? 16384 : uint64_t(cq.tile_words) << 5;
+        const uint64_t tile_docs = wide ? 8192 : ((cq.simple_flags >> 26) & 1u) ? (1u << kTileDirShift) : ((cq.simple_flags >> 25) & 1u) ? (1u << kProbeTileShift) : simple ? 16384 : uint64_t(cq.tile_words) << 5;
         const uint64_t tiles = std::max<uint64_t>((range + tile_docs - 1) / tile_docs, 1);
         const bool seq = wide ? cq.wide.seq != 0 : simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
         const uint64_t visited = seq ? tiles : std::min<uint64_t>(std::max<uint64_t>(cover_len, 1), tiles);

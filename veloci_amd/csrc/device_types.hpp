@@ -24,7 +24,8 @@ constexpr int kMaxChildren = 16;    // children per AND/OR node (the query gener
 constexpr int kMaxLists = 64;       // lists per query in one launch
 constexpr int kMaxOps = 160;
 constexpr int kMaxSkipWhen = 4;
-constexpr uint32_t kTileDirShift = 15;  // tile directory of an id list: one entry per 32768 docs (the tile of k_scan_probe)
+constexpr uint32_t kTileDirShift = 14;  // tile directory of an id list: one entry per 16384 docs (the tile of k_scan_ring)
+constexpr uint32_t kProbeTileShift = 15;  // the tile of k_scan_probe: 32768 docs = every second directory entry
 constexpr uint32_t kRankShift = 9;  // rank directory of a dense list: one entry per 512 docs (16 bitmap words = one 64-byte sector)
 
 enum ListFlags : uint32_t {
@@ -193,7 +194,7 @@ struct QHeader {
                              // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
                              // bit 18: rich simple query (DSimple2); bit 19: one materialised leaf (k_scan_leaf_f32); bits 20-23: leaf k has enough
                              // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide); bit 25: AND whose
-                             // cover is ONE id list and whose other leaves are bitmap images (k_scan_probe)
+                             // cover is ONE id list and whose other leaves are bitmap images (k_scan_probe); bit 26: ... and top_k <= 32: k_scan_ring
 };
 
 // The best top_k keys any span of the query has scored so far (k_scan_probe, top_k <= kPoolMaxK): a span merges its own best keys in under

@@ -364,7 +364,7 @@ constexpr int kWorkspaces = 4;  // batches in flight per index (host compile of 
 
 // Kernels the profiler accounts separately (vq_profile_json): the pre-passes, one entry per scan class, the merges.
 enum KernelId : int {
-    K_DICT_SCAN = 0, K_UNION_COUNT, K_UNION_WRITE, K_RANGE_HITS, K_COUNT_PREPASS, K_SCAN_LEAF_F32, K_SCAN_RICH, K_SCAN_PROBE, K_SCAN_AND, K_SCAN_SIMPLE, K_SCAN_UNION,
+    K_DICT_SCAN = 0, K_UNION_COUNT, K_UNION_WRITE, K_RANGE_HITS, K_COUNT_PREPASS, K_SCAN_LEAF_F32, K_SCAN_RICH, K_SCAN_RING, K_SCAN_PROBE, K_SCAN_AND, K_SCAN_SIMPLE, K_SCAN_UNION,
     K_SCAN_WIDE, K_TILE_SCAN, K_MERGE_SPANS, K_FINALIZE, K_FACET_SELECT, K_LOCALITY, K_BOOST1N, K_COUNT_
 };
 extern const char* const kKernelNames[K_COUNT_];

@@ -40,7 +40,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 const char* const kKernelNames[K_COUNT_] = {"k_dict_scan", "k_union<count>", "k_union<write>", "k_range_hits", "k_tile_scan<count pre-pass>", "k_scan_leaf_f32",
-                                            "k_scan_simple<2,rich>", "k_scan_probe (AND)", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
+                                            "k_scan_simple<2,rich>", "k_scan_ring (AND)", "k_scan_probe (AND)", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
                                             "k_merge_spans", "k_finalize", "k_facet_select", "k_locality", "k_boost1n"};
 
 LaunchTimer::LaunchTimer(bool on, Workspace& w, hipStream_t s, int kernel, uint64_t layout_bytes, uint64_t algorithmic_bytes, uint64_t queries) {
@@ -1180,7 +1180,13 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const size_t up_qmap_x = up_span_x + tbl;
     const size_t up_span_p = up_qmap_x + tbl;   // ANDs of one id-list cover and bitmap operands: k_scan_probe
     const size_t up_qmap_p = up_span_p + tbl;
-    const size_t up_jobs = up_qmap_p + tbl;
+    const size_t up_qmap_n = up_qmap_p + tbl;   // ... with top + skip <= 32: k_scan_ring (a persistent grid: no span table, (query, span) items instead)
+    const size_t up_work_n = up_qmap_n + tbl;   // its item counter and error word (zeroed with every upload)
+    size_t ring_items_max = 0;                  // its item table: only when the launch's queries differ in their span counts
+    for (size_t i = 0; i < n; ++i)
+        if (pb->queries[i].status == 0 && ((pb->queries[i].simple_flags >> 26) & 1u)) ring_items_max += pb->queries[i].n_spans;
+    const size_t up_items_n = up_work_n + 256;
+    const size_t up_jobs = up_items_n + align_up(ring_items_max * 4, 256);
     const size_t up_bytes = up_jobs + align_up(jobs.size() * sizeof(FacetJob), 256) + 256;
     ws.h_up.ensure(up_bytes);
     ws.d_up.ensure(up_bytes);
@@ -1194,6 +1200,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t n_leaf = 0, spans_leaf = 0;
     uint32_t n_xwide = 0, spans_xwide = 0, leaves_xwide = 0, scatter_xwide = 0;
     uint32_t n_probe = 0, spans_probe = 0, nd_probe = 1;
+    uint32_t n_ring = 0, items_ring = 0, nd_ring = 1, ring_spans_each = 0;
     uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
     {
         size_t off = 0;
@@ -1228,6 +1235,11 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         uint32_t accg = 0, accs = 0, accd = 0, accw = 0, accr = 0, accp = 0;
         uint32_t* sp = reinterpret_cast<uint32_t*>(hup + up_span_p);
         uint32_t* mp = reinterpret_cast<uint32_t*>(hup + up_qmap_p);
+        uint32_t* mn = reinterpret_cast<uint32_t*>(hup + up_qmap_n);
+        uint32_t ring_max_spans = 0;
+        std::vector<uint32_t> ring_ns;  // spans of k_scan_ring's queries
+        bool ring_uniform = true;
+        std::memset(hup + up_work_n, 0, 256);
         qi = 0;
         for (size_t i = 0; i < n; ++i) {
             const CompiledQuery& cq = pb->queries[i];
@@ -1265,6 +1277,14 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 sd[n_dense] = accd;
                 md[n_dense++] = qi;
                 accd += cq.n_spans;
+            } else if ((cq.simple_flags >> 26) & 1u) {
+                kclass = K_SCAN_RING;
+                nd_ring = std::max<uint32_t>(nd_ring, cq.simple_n - 1);
+                ring_uniform = ring_uniform && (n_ring == 0 || cq.n_spans == ring_max_spans);
+                ring_max_spans = std::max(ring_max_spans, cq.n_spans);
+                mn[n_ring++] = qi;
+                ring_ns.push_back(cq.n_spans);
+                items_ring += cq.n_spans;
             } else if ((cq.simple_flags >> 25) & 1u) {
                 kclass = K_SCAN_PROBE;
                 nd_probe = std::max<uint32_t>(nd_probe, cq.simple_n - 1);
@@ -1307,6 +1327,16 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
         spans_xwide = accx;
         sp[n_probe] = accp;
         spans_probe = accp;
+        if (n_ring) {  // k_scan_ring's items in round-major order: span 0 of every query, then span 1, ... (a query's pool is warm after its first span)
+            if (ring_uniform) ring_spans_each = ring_max_spans;
+            else {
+                uint32_t* it = reinterpret_cast<uint32_t*>(hup + up_items_n);
+                uint32_t k = 0;
+                for (uint32_t r = 0; r < ring_max_spans; ++r)
+                    for (uint32_t j = 0; j < n_ring; ++j)
+                        if (r < ring_ns[j]) it[k++] = (j << 12) | r;
+            }
+        }
         sd[n_dense] = accd;
         spans_generic = accg;
         spans_simple = accs;
@@ -1373,6 +1403,17 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     if (spans_rich) {
         LaunchTimer t(prof, ws, st, K_SCAN_RICH, cls_layout[K_SCAN_RICH], cls_algo[K_SCAN_RICH], cls_q[K_SCAN_RICH]);
         launch_scan_simple(st, true, scatter_rich, spans_rich, pb->d_blobs, pb->d_blob_off, tab(up_span_r), tab(up_qmap_r), n_rich, cand_cap, keys_ptr, hits_ptr, hist_ptr, facets_rich);
+    }
+    VQ_HIP(hipGetLastError());
+    if (items_ring) {
+        static const uint32_t cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            return uint32_t(v);
+        }();
+        LaunchTimer t(prof, ws, st, K_SCAN_RING, cls_layout[K_SCAN_RING], cls_algo[K_SCAN_RING], cls_q[K_SCAN_RING]);
+        launch_scan_ring(st, nd_ring, cus, pb->d_blobs, pb->d_blob_off, tab(up_qmap_n), n_ring, ring_spans_each, tab(up_items_n), items_ring,
+                         reinterpret_cast<uint32_t*>(dup + up_work_n), keys_ptr, hits_ptr);
     }
     VQ_HIP(hipGetLastError());
     if (spans_probe) {

@@ -226,7 +226,7 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         ps.td_start.assign(ps.num_tokens, -1);
         {
             const uint64_t range = uint64_t(hi) - lo;
-            const uint64_t tiles = (idx->bitmap_words >> (kTileDirShift - 5)) + 1;
+            const uint64_t tiles = (idx->bitmap_words >> (kTileDirShift - 5)) + 3;  // (k_scan_probe reads every second entry, up to one behind its last 32768-doc tile)
             std::vector<uint32_t> tdir;
             for (uint32_t t = 0; t < ps.num_tokens; ++t) {
                 if (range < 65536 || uint64_t(ps.len[t]) * 4096 < range) continue;

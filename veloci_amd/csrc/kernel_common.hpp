@@ -71,7 +71,7 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, uin
 // All threads of the workgroup call this together.  Without `force` a buffer that already holds <= k keys
 // is left as it is (the caller only needs the SET of the best k); with `force` the keys end up sorted
 // descending.  On return *cs.n <= k.
-static __device__ void cand_prune(const CandState& cs, uint32_t k, bool force = false) {
+__attribute__((unused)) static __device__ void cand_prune(const CandState& cs, uint32_t k, bool force = false) {
     __syncthreads();
     uint32_t n = *cs.n;
     if (n > cs.cap) n = cs.cap;

@@ -54,6 +54,12 @@ void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t 
 size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd);
 void launch_scan_probe(hipStream_t st, uint32_t max_nd, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
                        uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
+// k_scan_ring (scan_ring.hip): persistent loader / consumer form of k_scan_probe.  `work`: two zeroed u32 (item counter, error word)
+uint32_t scan_ring_consumers(uint32_t max_nd);
+uint32_t scan_ring_slots(uint32_t maxnd, uint32_t consumers);
+size_t scan_ring_lds_bytes(uint32_t maxnd, uint32_t consumers, uint32_t slots);
+void launch_scan_ring(hipStream_t st, uint32_t max_nd, uint32_t grid, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* qmap, uint32_t nq, uint32_t spans_each,
+                      const uint32_t* items, uint32_t total_items, uint32_t* work, unsigned long long* span_keys, unsigned long long* num_hits);
 size_t scan_wide_lds_bytes(uint32_t cand_cap, uint32_t n_leaves, uint32_t n_scatter);
 void launch_scan_wide(hipStream_t st, uint32_t max_leaves, uint32_t max_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                       const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
@@ -137,6 +143,7 @@ void launch_explain(hipStream_t st, uint32_t n_docs, const ExQuery* queries, con
 #ifdef VQ_STAMP
 void debug_read_stamps(unsigned long long* out, int reset);
 void debug_read_probe_stamps(unsigned long long* out, int reset);
+void debug_read_ring_stamps(unsigned long long* out, int reset);
 #endif
 
 }  // namespace vq
