@@ -150,6 +150,9 @@ void vq_request_free(vq_request*);
  * facet_request.rs:2-11) in declaration order, absent Options as null, `select` / `snippet_info` as "present" booleans, f32 values as their bit
  * patterns (u32).  Pinned by tests/golden/request_parse.json against an independent restatement of serde's rules.  Thread-local string. */
 const char* vq_request_to_json(const vq_request*);
+/* 1 when the request asks for facets (Request::facets, src/search/request/mod.rs:39, is a non-empty list), else 0: what decides whether a sharded
+ * step exchanges histograms — taken from the PARSED request, the same on every rank. */
+int vq_request_has_facets(const vq_request*);
 /* str::to_lowercase as the dictionary side applies it (src/search/search_field.rs:284,312).  Returns the byte length written to `out`, or
  * (size_t)-1 when `cap` is too small.  Diagnostic: swept over every code point by tests/test_request_parse.py. */
 size_t vq_debug_to_lowercase(const char* utf8, size_t len, char* out, size_t cap);

@@ -78,6 +78,14 @@ hipError_t hipGetDeviceCount(int* n) {
     return hipSuccess;
 }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) {
+    *d = 0;
+    return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+    *v = 256;
+    return hipSuccess;
+}
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 }
 

@@ -374,6 +374,7 @@ int vq_request_parse(const char* json, size_t len, vq_request** out) {
         *out = r;
     });
 }
+int vq_request_has_facets(const vq_request* r) { return r && r->req.facets && !r->req.facets->empty() ? 1 : 0; }
 const char* vq_request_to_json(const vq_request* r) {
     thread_local std::string s;
     s.clear();
@@ -1095,8 +1096,12 @@ struct vq_shard_step {
     bool merge_queued = false;
     bool counted = false;
     ~vq_shard_step() {
+        pbs.clear();  // (the workspaces first: a parity is free once nothing of the step holds them)
         if (idx && idx->comm && idx->comm->unmerged == this) idx->comm->unmerged = nullptr;
-        if (counted && idx && idx->comm) idx->comm->live -= 1;
+        if (counted && idx && idx->comm) {
+            idx->comm->live -= 1;
+            idx->comm->busy[parity] = false;
+        }
     }
 };
 namespace {
@@ -1145,7 +1150,15 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
         step->counted = true;
         c.live += 1;
         step->n = n;
-        step->parity = int(c.seq++ & 1u);
+        // the parity (workspace pair, gather buffer, events) no live step holds — not a running count: steps may end in any order, and a
+        // begin that throws (a pre-pass out of memory) is retried while the other step is still in flight
+        step->parity = c.busy[0] ? 1 : 0;
+        if (c.busy[step->parity]) {
+            step->counted = false;
+            c.live -= 1;
+            throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: both step slots are held (end a step first)");
+        }
+        c.busy[step->parity] = true;
         // One launch per step: with two steps in flight the compilation of step i + 1 already overlaps the scans of step i, and one launch of
         // 1024 requests fills the chip more evenly than two of 512 (100 M docs: 7.25 against 7.41 ms per step).  VQ_SHARD_CHUNKS=2 cuts a step in two.
         static const size_t chunks_env = [] {

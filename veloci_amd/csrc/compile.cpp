@@ -2206,9 +2206,9 @@ struct Compiler {
             // warm its threshold up (the query's pool is warm after the first round) — short spans even out the end of the launch
             static const uint64_t ring_tiles = [] {
                 const char* e = std::getenv("VQ_RING_SPAN_TILES");
-                return uint64_t(e ? std::max(1, std::atoi(e)) : 128);
+                return uint64_t(e ? std::max(1, std::atoi(e)) : 64);
             }();
-            const uint64_t ptiles = std::max<uint64_t>((range + (1u << kTileDirShift) - 1) >> kTileDirShift, 1);
+            const uint64_t ptiles = std::max<uint64_t>((range + (1u << kProbeTileShift) - 1) >> kProbeTileShift, 1);
             spans = (ptiles + ring_tiles - 1) / ring_tiles;
         }
         spans = std::min<uint64_t>(spans, tiles);
@@ -2230,7 +2230,7 @@ struct Compiler {
         const uint64_t range = uint64_t(idx.doc_hi) - idx.doc_lo;
         const bool simple = cq.simple_flags != 0;
         const bool wide = (cq.simple_flags >> 24) & 1u;
-        const uint64_t tile_docs = wide ? 8192 : ((cq.simple_flags >> 26) & 1u) ? (1u << kTileDirShift) : ((cq.simple_flags >> 25) & 1u) ? (1u << kProbeTileShift) : simple ? 16384 : uint64_t(cq.tile_words) << 5;
+        const uint64_t tile_docs = wide ? 8192 : ((cq.simple_flags >> 25) & 1u) ? (1u << kProbeTileShift) : simple ? 16384 : uint64_t(cq.tile_words) << 5;
         const uint64_t tiles = std::max<uint64_t>((range + tile_docs - 1) / tile_docs, 1);
         const bool seq = wide ? cq.wide.seq != 0 : simple ? ((cq.simple_flags >> 16) & 1u) : cq.seq_tiles != 0;
         const uint64_t visited = seq ? tiles : std::min<uint64_t>(std::max<uint64_t>(cover_len, 1), tiles);

@@ -377,6 +377,7 @@ struct TimedLaunch {  // one profiled launch of a batch: events [begin, end] on 
 
 struct Workspace {  // scratch of one in-flight batch
     std::mutex mu;
+    std::atomic<bool> pinned{false};  // held by a batch that named this workspace (the chunks of a sharded step): callers that take any free one skip it
     std::vector<hipEvent_t> ev_pool;          // profiling: created on first use
     uint32_t ev_used = 0;
     std::vector<TimedLaunch> timed;           // launches of the batch in flight (profiling)
@@ -435,7 +436,7 @@ struct ShardComm {
     int live = 0;              // steps begun and not yet ended / freed (at most two: each holds workspaces of its own)
     DevBuf gathered[2];
     DevBuf red;  // scratch of the sums-over-shards hook (u64)
-    uint32_t seq = 0;
+    bool busy[2] = {false, false};  // parity (workspace pair, gather buffer, events) held by a live step
     std::mutex mu;  // the hook may be called from compile threads of two steps
     ~ShardComm();
 };
@@ -629,6 +630,7 @@ struct PartialBatch {
     const Index* index = nullptr;
     Workspace* ws = nullptr;
     std::unique_lock<std::mutex> lock;    // holds the workspace until the batch is finished
+    bool pinned_ws = false;               // ... a workspace the caller named (Workspace::pinned is ours to clear)
     std::vector<CompiledQuery> queries;   // status != 0: failed at compile time
     std::vector<uint32_t> slot;           // slot[i]: position of request i among the device queries, or UINT32_MAX
     std::vector<uint8_t> qclass;          // profiling: KernelId of the scan that serves device query q

@@ -886,9 +886,36 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     auto pb = std::make_unique<PartialBatch>();
     pb->index = &idx;
     pb->t0 = std::chrono::steady_clock::now();
-    if (slot < 0) slot = int(idx.next_ws.fetch_add(1) % kWorkspaces);
-    pb->ws = &idx.ws[slot % kWorkspaces];
-    pb->lock = std::unique_lock<std::mutex>(pb->ws->mu);
+    if (slot < 0) {
+        // any workspace: the first free one from the round-robin position on, never one that a batch holds by name (the chunks of a sharded step
+        // in flight: waiting for one of those on the thread that has to end the step would never return)
+        const uint32_t start = idx.next_ws.fetch_add(1);
+        int fallback = -1;
+        for (uint32_t k = 0; k < uint32_t(kWorkspaces) && !pb->lock.owns_lock(); ++k) {
+            Workspace& w = idx.ws[(start + k) % kWorkspaces];
+            if (w.pinned.load(std::memory_order_acquire)) continue;
+            if (fallback < 0) fallback = int((start + k) % kWorkspaces);
+            std::unique_lock<std::mutex> l(w.mu, std::try_to_lock);
+            if (l.owns_lock() && !w.pinned.load(std::memory_order_acquire)) {
+                pb->ws = &w;
+                pb->lock = std::move(l);
+            }
+        }
+        if (!pb->lock.owns_lock()) {
+            if (fallback < 0) throw vqreq::VelociError(vqreq::ERR_INVALID_ARGUMENT, "every workspace of the index is held by a sharded step in flight: end a step first");
+            pb->ws = &idx.ws[fallback];  // held by another thread's batch: it will be handed on
+            pb->lock = std::unique_lock<std::mutex>(pb->ws->mu);
+        }
+    } else {
+        pb->ws = &idx.ws[slot % kWorkspaces];
+        pb->lock = std::unique_lock<std::mutex>(pb->ws->mu, std::try_to_lock);
+        if (!pb->lock.owns_lock()) {
+            if (pb->ws->pinned.load(std::memory_order_acquire)) throw vqreq::VelociError(vqreq::ERR_INVALID_ARGUMENT, "the workspace named for this batch is held by a step in flight");
+            pb->lock = std::unique_lock<std::mutex>(pb->ws->mu);
+        }
+        pb->ws->pinned.store(true, std::memory_order_release);
+        pb->pinned_ws = true;
+    }
     VQ_HIP(hipSetDevice(idx.device));
     Workspace& ws = *pb->ws;
     hipStream_t st = idx.stream;
@@ -1808,6 +1835,7 @@ void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Res
 
 PartialBatch::~PartialBatch() {
     if (ws && launched && !finished && ws->ev_done) (void)hipEventSynchronize(ws->ev_done);
+    if (ws && pinned_ws && lock.owns_lock()) ws->pinned.store(false, std::memory_order_release);
 }
 
 namespace {

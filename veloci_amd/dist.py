@@ -226,13 +226,25 @@ class ShardedSearcher:
         if any(sb.has_facets for sb in subs):
             return False
         pbs, arena_off = [], 0
-        for c, sb in enumerate(subs):
-            pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)
-            if c == 0:
-                self._free_finished()
-            pbs.append(pb)
-            arena_off += (pb.total_nbytes + 255) // 256 * 256
-        assert not any(pb.hist_nbytes for pb in pbs)
+        try:
+            for c, sb in enumerate(subs):
+                pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)
+                pbs.append(pb)
+                if c == 0:
+                    self._free_finished()
+                arena_off += (pb.total_nbytes + 255) // 256 * 256
+            if any(pb.hist_nbytes for pb in pbs):  # (has_facets comes from the parsed requests: this cannot happen — and must not pass silently)
+                raise RuntimeError("a chunk of a one-collective step carries facet histograms")
+        except Exception as ex:
+            # nothing of the step may stay behind: every queued chunk holds a workspace (and scans in flight) until it is closed
+            for pb in pbs:
+                pb.close()
+            from .search import VelociError
+            if isinstance(ex, VelociError) and "partial arena" in str(ex):
+                # the arena is too small for this step's partials: a fact of the layout, identical on every rank (the requests and the
+                # partial layout are) — every rank takes the per-chunk path, nothing was exchanged yet
+                return False
+            raise
         self._ev = (self._ev + 1) % len(self._events)
         scanned = self._events[self._ev]
         scanned.record(self.stream)

@@ -55,7 +55,7 @@ class Request:
         h = C.c_void_p()
         _lib.check(self.L.vq_request_parse(request, len(request), C.byref(h)))
         self.h = h
-        self.has_facets = b'"facets"' in request  # (a hint for schedulers: a false positive only costs the slower path)
+        self.has_facets = bool(self.L.vq_request_has_facets(self.h))  # from the PARSED request: decides the exchange path of a sharded step on every rank alike
 
     def __del__(self):
         if getattr(self, "h", None):
