@@ -747,6 +747,11 @@ struct Compiler {
                 h.d_rank_dir = ps.rank_dir.as<uint32_t>() + ps.rd_start[e.tid];
             }
             if (!ps.td_start.empty() && ps.td_start[e.tid] >= 0) h.d_tile_dir = ps.tile_dir.as<uint32_t>() + ps.td_start[e.tid];
+            if (!ps.pk_start.empty() && ps.pk_start[e.tid] >= 0) {
+                h.d_cov32 = ps.cov32.as<uint32_t>() + uint64_t(ps.pk_start[e.tid]) * 8;
+                h.d_gdir = ps.gdir.as<uint32_t>() + ps.gd_start[e.tid];
+                if (ps.ak_start[e.tid] >= 0) h.d_arr16 = ps.arr16.as<uint16_t>() + uint64_t(ps.ak_start[e.tid]) * 8;
+            }
             uint32_t li = add_list(h);
             info.cover.push_back(li);
             info.cover_len += h.len;
@@ -2087,14 +2092,20 @@ struct Compiler {
                 static const bool no_probe = std::getenv("VQ_NO_PROBE") != nullptr;
                 static const uint64_t probe_min_docs = std::getenv("VQ_PROBE_MIN_DOCS") ? uint64_t(std::atoll(std::getenv("VQ_PROBE_MIN_DOCS"))) : 40'000'000ull;
                 bool probe = !no_probe && cq.simple_n >= 2 && cq.ops[cq.simple_n].kind == OP_AND && uint64_t(idx.doc_hi) - idx.doc_lo >= probe_min_docs;
+                uint32_t arr_mask = 0;  // operands probed as 16-bit arrays (2 B per posting) instead of bitmap words (a bit per doc): the fewer bytes win
                 if (probe) {
+                    static const bool no_arr = std::getenv("VQ_PROBE_NO_ARR") != nullptr;
                     uint32_t covers = 0;
                     for (uint32_t k = 0; k < cq.simple_n; ++k) {
                         const HList& l = cq.lists[cq.ops[k].list_begin];
                         if (l.flags & LIST_COVER) {
                             ++covers;
-                            probe = probe && l.d_tile_dir;
-                        } else probe = probe && (l.flags & LIST_BITMAP);
+                            probe = probe && l.d_cov32;
+                        } else {
+                            const bool arr = l.d_arr16 && !no_arr && (!(l.flags & LIST_BITMAP) || uint64_t(l.len) * 16 < uint64_t(idx.doc_hi) - idx.doc_lo);
+                            if (arr) arr_mask |= 1u << k;
+                            probe = probe && (arr || (l.flags & LIST_BITMAP));
+                        }
                     }
                     probe = probe && covers == 1;
                 }
@@ -2104,18 +2115,25 @@ struct Compiler {
                     if ((l.flags & LIST_COVER) && (l.flags & LIST_BITMAP)) seq = true;
                 }
                 if (seq) f |= 1u << 16;
-                if (probe) f |= 1u << 25;
+                if (probe) {
+                    f |= 1u << 25 | arr_mask << 12;
+                    cq.probe = DProbe{};
+                    for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                        const HList& l = cq.lists[cq.ops[k].list_begin];
+                        cq.probe.leaf[k] = DProbeLeaf{l.d_cov32, l.d_arr16, l.d_gdir};
+                    }
+                }
                 // ... and with top + skip <= 32 (the candidate buffer is one key per lane, the query has a shared pool) the persistent form of that
                 // kernel, k_scan_ring: loader waves stream the tiles into LDS rings, consumer waves probe (opt-in)
                 // Measured on launches that read no list twice (256 distinct queries per launch, 100 M docs): 1.95 ms against k_scan_probe's 1.94 —
                 // the stream side reaches 5.9 TB/s alone, the consumer waves do not keep up: opt-in, VQ_RING=1
                 static const bool ring = std::getenv("VQ_RING") != nullptr && std::atoi(std::getenv("VQ_RING")) != 0;
-                if (probe && ring && cq.top_k >= 1 && cq.top_k <= kPoolMaxK) f |= 1u << 26;
+                if (probe && ring && !arr_mask && cq.top_k >= 1 && cq.top_k <= kPoolMaxK) f |= 1u << 26;
                 for (uint32_t k = 0; k < cq.simple_n; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
                     const bool cover = l.flags & LIST_COVER;
                     if (cover) f |= 1u << (8 + k);
-                    if ((l.flags & LIST_BITMAP) && (seq || !cover)) f |= 1u << k;
+                    if ((l.flags & LIST_BITMAP) && (seq || !cover) && !((arr_mask >> k) & 1u)) f |= 1u << k;
                     if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);
                 }
                 cq.simple_flags = f;
@@ -2243,9 +2261,11 @@ struct Compiler {
             b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
         else if (wide) {
             for (uint32_t k = 0; k < cq.wide.n_leaves; ++k) b += ((cq.wide.bitmap_mask >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[cq.wide.leaf_list[k]].len;
-        } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's ids and scores are streamed, the operands' tiles come with 32 rank entries
-            for (uint32_t k = 0; k < cq.simple_n; ++k)
-                b += ((cq.simple_flags >> k) & 1u) ? visited * (tile_docs / 8 + 4 * (tile_docs >> kRankShift)) : 6ull * cq.lists[cq.ops[k].list_begin].len;
+        } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's tile-packed (id, score) words are streamed, a bitmap operand's tiles come with 64 rank entries, an array operand costs 2 B per posting
+            for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                const uint64_t len = cq.lists[cq.ops[k].list_begin].len;
+                b += ((cq.simple_flags >> k) & 1u) ? visited * (tile_docs / 8 + 4 * (tile_docs >> kRankShift)) : ((cq.simple_flags >> (12 + k)) & 1u) ? 2ull * len : 4ull * len;
+            }
         } else if (simple) {
             std::vector<bool> seen(cq.lists.size(), false);
             const bool rich = (cq.simple_flags >> 18) & 1u;

@@ -194,7 +194,19 @@ struct QHeader {
                              // visited sequentially (a dense list is in the cover); bit 17: eligible for k_scan_simple;
                              // bit 18: rich simple query (DSimple2); bit 19: one materialised leaf (k_scan_leaf_f32); bits 20-23: leaf k has enough
                              // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide); bit 25: AND whose
-                             // cover is ONE id list and whose other leaves are bitmap images (k_scan_probe); bit 26: ... and top_k <= 32: k_scan_ring
+                             // cover is ONE id list and whose other leaves are bitmap images or 16-bit arrays per tile (k_scan_probe, DProbe);
+                             // bits 12-15: leaf k is probed as a 16-bit array; bit 26: all operands bitmaps, top_k <= 32, opted in: k_scan_ring
+};
+
+// k_scan_probe's view of a leaf (simple_flags bit 25; at QHeader::off_simple2): the tile-packed image of its posting list — the list's
+// postings grouped by 32768-doc tile, every tile padded to a multiple of 8 entries (a granule) with all-ones entries.
+struct DProbeLeaf {
+    const uint32_t* cov32;  // (doc - tile_lo) << 16 | f16 score: what the cover streams; an array operand's scores are gathered from here
+    const uint16_t* arr16;  // doc - tile_lo, same indexing (null: some tile holds more than 2048 entries)
+    const uint32_t* gdir;   // granules below tile k (tile 0 starts at QHeader::bitmap_base)
+};
+struct DProbe {
+    DProbeLeaf leaf[4];
 };
 
 // The best top_k keys any span of the query has scored so far (k_scan_probe, top_k <= kPoolMaxK): a span merges its own best keys in under

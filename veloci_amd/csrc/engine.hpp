@@ -284,6 +284,15 @@ struct PostingStore {  // "<field>.textindex.to_anchor_id_score": padded segment
     // its cover list without searching or counting): entries below bitmap_base + (k << kTileDirShift)
     std::vector<int64_t> td_start;      // entry offset of list t inside `tile_dir`, or -1
     DevBuf tile_dir;
+    // ... and a tile-packed image for k_scan_probe (round 4): the list's postings grouped by 32768-doc tile, every tile padded to a
+    // multiple of 8 entries (a "granule"), as `cov32` = (doc - tile_lo) << 16 | f16 score (what a COVER streams: 4 B per posting, one
+    // 16 B/lane load per 256 postings, no index arithmetic) and — when no tile holds more than 2048 entries — as `arr16` = doc - tile_lo
+    // (what an OPERAND of fewer than 1/16 of the docs is probed in: a sorted 16-bit array per tile, Roaring's array container, 2 B per
+    // posting instead of a bit per doc).  Both share one directory: gdir[k] = granules below tile k.
+    std::vector<int64_t> pk_start;      // granule offset of list t inside `cov32`, or -1
+    std::vector<int64_t> ak_start;      // granule offset of list t inside `arr16`, or -1 (a tile with more than 2048 entries)
+    std::vector<int64_t> gd_start;      // entry offset of list t inside `gdir`
+    DevBuf cov32, arr16, gdir;
 };
 
 struct KVStore {  // IndexIdToParent<u32>: host copy + (where useful) device images
@@ -503,6 +512,9 @@ struct HList {
     const uint32_t* d_bitmap = nullptr;
     const uint32_t* d_rank_dir = nullptr;
     const uint32_t* d_tile_dir = nullptr;
+    const uint32_t* d_cov32 = nullptr;  // tile-packed image (PostingStore::cov32 / arr16 / gdir), null without one
+    const uint16_t* d_arr16 = nullptr;
+    const uint32_t* d_gdir = nullptr;
     int inline_idx = -1;  // >= 0: docs come from inline_lists[inline_idx] (carried inside the blob)
     int inline_val_idx = -1;  // >= 0: f32 values come from inline_vals[inline_val_idx]
 };
@@ -576,6 +588,7 @@ struct CompiledQuery {
     std::vector<uint16_t> loc_idx;
     DSimple2 simple2{};  // simple_flags bit 18
     DWide wide{};        // simple_flags bit 24
+    DProbe probe{};      // simple_flags bit 25
     std::vector<DFacet> facets;
     std::vector<FacetOut> facet_out;
     std::map<std::string, std::vector<std::string>> why_found_terms;  // search.rs:186: path -> matched term texts (request.why_found)

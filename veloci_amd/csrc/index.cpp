@@ -245,6 +245,71 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
                 idx->device_bytes += ps.tile_dir.bytes;
             }
         }
+        // ---- tile-packed images of the same lists (k_scan_probe: cover stream and 16-bit array operands); sized in a first pass, then
+        // built and uploaded list by list (the host never holds a second copy of the whole store)
+        ps.pk_start.assign(ps.num_tokens, -1);
+        ps.ak_start.assign(ps.num_tokens, -1);
+        ps.gd_start.assign(ps.num_tokens, -1);
+        {
+            const uint64_t ptiles = (idx->bitmap_words >> (kProbeTileShift - 5)) + 2;  // (entry `one behind the last tile` included)
+            uint64_t cov_gran = 0, arr_gran = 0;
+            std::vector<uint32_t> gd;
+            for (uint32_t t = 0; t < ps.num_tokens; ++t) {
+                if (ps.td_start[t] < 0) continue;
+                const uint32_t* d = docs.data() + ps.start[t];
+                uint64_t gran = 0;
+                uint32_t i = 0, most = 0;
+                ps.gd_start[t] = int64_t(gd.size());
+                for (uint64_t k = 0; k <= ptiles; ++k) {
+                    gd.push_back(uint32_t(gran));
+                    const uint64_t thi = uint64_t(idx->bitmap_base) + ((k + 1) << kProbeTileShift);
+                    const uint32_t i0 = i;
+                    while (i < ps.len[t] && d[i] < thi) ++i;
+                    const uint32_t g = (i - i0 + 7u) / 8u;
+                    most = std::max(most, g);
+                    gran += g;
+                }
+                if (gran >= (1ull << 28)) throw VelociError(vqreq::ERR_INVALID_ARGUMENT, "posting list too long for its tile-packed image");
+                ps.pk_start[t] = int64_t(cov_gran);
+                cov_gran += gran;
+                if (most <= 256) {  // no tile holds more than 2048 entries: the list can be an array operand
+                    ps.ak_start[t] = int64_t(arr_gran);
+                    arr_gran += gran;
+                }
+            }
+            if (cov_gran) {
+                ps.cov32.alloc(cov_gran * 32 + 4096);  // (slack: the kernel guards its loads per 16-byte vector)
+                ps.arr16.alloc(arr_gran * 16 + 4096);
+                ps.gdir.alloc(gd.size() * 4 + 16);
+                ps.gdir.upload(gd.data(), gd.size() * 4);
+                idx->device_bytes += ps.cov32.bytes + ps.arr16.bytes + ps.gdir.bytes;
+                std::vector<uint32_t> cov;
+                std::vector<uint16_t> arr;
+                for (uint32_t t = 0; t < ps.num_tokens; ++t) {
+                    if (ps.pk_start[t] < 0) continue;
+                    const uint32_t* d = docs.data() + ps.start[t];
+                    const uint16_t* sc = scores.data() + ps.start[t];
+                    cov.clear();
+                    arr.clear();
+                    uint32_t i = 0;
+                    for (uint64_t k = 0; k <= ptiles; ++k) {
+                        const uint64_t tlo = uint64_t(idx->bitmap_base) + (k << kProbeTileShift), thi = tlo + (1u << kProbeTileShift);
+                        for (; i < ps.len[t] && d[i] < thi; ++i) {
+                            const uint32_t rel = uint32_t(d[i] - tlo);
+                            cov.push_back(rel << 16 | sc[i]);
+                            arr.push_back(uint16_t(rel));
+                        }
+                        while (cov.size() % 8) {
+                            cov.push_back(0xFFFFFFFFu);
+                            arr.push_back(0xFFFFu);
+                        }
+                    }
+                    if (cov.empty()) continue;
+                    VQ_HIP(hipMemcpy(ps.cov32.as<uint8_t>() + uint64_t(ps.pk_start[t]) * 32, cov.data(), cov.size() * 4, hipMemcpyHostToDevice));
+                    if (ps.ak_start[t] >= 0) VQ_HIP(hipMemcpy(ps.arr16.as<uint8_t>() + uint64_t(ps.ak_start[t]) * 16, arr.data(), arr.size() * 2, hipMemcpyHostToDevice));
+                }
+            }
+        }
         ps.docs.alloc(docs.size() * 4 + 16);
         ps.docs.upload(docs.data(), docs.size() * 4);
         ps.scores.alloc(scores.size() * 2 + 16);

@@ -1,11 +1,15 @@
-// k_scan_probe — AND of 2..4 single-list posting leaves whose cover (the sparsest operand) is an id list and whose other operands are
-// dense lists with bitmap images: the headline shape (3-term AND, df 10 % / 3 % / 1 % of the docs).
+// k_scan_probe — AND of 2..4 single-list posting leaves whose cover (the sparsest operand) has a tile-packed image and whose other
+// operands are read per tile either as bitmap words (dense lists) or as sorted 16-bit arrays (lists below 1/16 of the docs: 2 B per
+// posting instead of a bit per doc — Roaring's two containers): the headline shape (3-term AND, df 10 % / 3 % / 1 % of the docs) reads
+// the 10 % list as words, the 3 % list as arrays and streams the 1 % list.
 //
-// The doc space is walked in tiles of 32768 docs.  The cover's tile directory (DList::tile_dir) says which of its postings fall into a
-// tile: their doc ids AND f16 scores are streamed (64 lanes x 16 B + 64 x 8 B per 256 postings) — no search, no counting, every lane
-// slot holds a posting of the tile.  The dense operands' bitmap words of the tile sit in LDS (coalesced 16 B/lane loads) and every
-// cover id tests its bit there.  Nothing is computed per bitmap word: the work per tile follows the COVER's postings (about 330 per
-// tile in the headline query), not the 1024 words per operand.
+// The doc space is walked in tiles of 32768 docs.  The cover's tile-packed image (DProbeLeaf::cov32, one word per posting: in-tile doc
+// offset << 16 | f16 score, every tile padded to 8 entries; its directory `gdir` says where a tile starts) is streamed, one 16 B/lane
+// load per 256 postings — no search, no counting, every lane slot holds a posting of the tile or an all-ones pad.  The operands' tile —
+// 1024 bitmap words, or up to 2048 16-bit offsets — sits in LDS (coalesced 16 B/lane loads; an array's loads are cut to its entries).
+// Every cover posting tests its bit in the bitmap operands' words; with array operands, the postings that passed are then looked up in
+// the arrays by a binary search in LDS, 64 at a time.  Nothing is computed per bitmap word or per array entry: the work per tile
+// follows the COVER's postings (about 330 per tile in the headline query).
 //
 // Loads are only ISSUED at the top of a tile — the next tile's words, rank entries and cover postings, the score gathers of the flush
 // in flight, the query's shared threshold — and only consumed behind the top of the next one, which waits for everything in flight
@@ -17,9 +21,10 @@
 // above — f32 add and mul are monotone — and that bound is monotone in the cover's raw f16 score, so the test per posting is one
 // integer compare against `raw_min`, recomputed whenever the threshold moves.  Pruned hits are still counted (num_hits is exact).
 //
-// Hits that stay live need their index in every dense operand (the f16 score is scores[index]): rank directory entry of the doc's
-// 512-doc group (staged in LDS with the tile) + popcount of the group's words below the doc.  Ranked hits are queued and scored
-// 64 at a time, all score gathers of a flush in flight together.
+// Hits that stay live need their index in every operand (the f16 score is scores[index]): in a bitmap operand the rank directory entry
+// of the doc's 512-doc group (staged in LDS with the tile) + popcount of the group's words below the doc; in an array operand the
+// position the search found (the score is the low half of cov32 at the same position).  Ranked hits are queued and scored 64 at a
+// time, all score gathers of a flush in flight together.
 // Same results as k_scan_simple / k_tile_scan bit for bit (tests run every such query through all three).
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -78,7 +83,7 @@ __host__ __device__ constexpr uint32_t probe_lds_tile(uint32_t nd) { return kPLd
 __host__ __device__ constexpr uint32_t probe_lds_cand(uint32_t nd) { return probe_lds_tile(nd) + nd * (kPTW + kPRk); }
 size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd) { return (size_t)(probe_lds_cand(nd) + 2 * cand_cap) * 4 + 16; }
 
-template <uint32_t ND>
+template <uint32_t ND, uint32_t NA>  // ND operands beside the cover, the last NA of them (roles NB .. ND-1) probed as 16-bit arrays
 __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, const uint32_t span, const uint32_t q, const uint32_t cand_cap,
                                            unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -86,9 +91,12 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     const VQ_CONST QHeader* H = as_const<QHeader>(blob);
     const VQ_CONST DList* gl = as_const<DList>(blob + H->off_lists);
     const VQ_CONST DOp* gops = as_const<DOp>(blob + H->off_ops);
+    const VQ_CONST DProbe* P = as_const<DProbe>(blob + H->off_simple2);
     const uint32_t sflags = H->simple_flags;
     const uint32_t top_k = H->top_k;
     constexpr uint32_t n = ND + 1u;
+    constexpr uint32_t NB = ND - NA;             // bitmap operands: roles 0 .. NB-1
+    constexpr uint32_t NB1 = NB ? NB : 1u, NA1 = NA ? NA : 1u;  // (array extents)
     PS_INIT
 
     unsigned long long* thr = reinterpret_cast<unsigned long long*>(lds);
@@ -97,52 +105,62 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     uint32_t* uq = lds + kPLdsU;
     uint32_t* rq = lds + kPLdsR;  // rdoc[kPR] rraw[kPR] ridx[ND][kPR]
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(lds + probe_lds_cand(ND));
-    uint32_t* tile = lds + probe_lds_tile(ND);  // [ND][kPTW]
-    uint32_t* rank = tile + ND * kPTW;          // [ND][kPRk]
+    uint32_t* tile = lds + probe_lds_tile(ND);  // [ND][kPTW]: a bitmap operand's 1024 words / an array operand's (up to) 2048 16-bit offsets
+    uint32_t* rank = tile + ND * kPTW;          // [ND][kPRk] (bitmap operands only)
     unsigned long long* const gthr = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(blob) + offsetof(QHeader, gthr));
     CandState cs{cand, cand_n, thr, cand_cap, gthr};
     cs.upper = H->key_upper;
     uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;
     uint8_t* const pool = H->off_pool ? const_cast<uint8_t*>(blob) + H->off_pool : nullptr;
 
-    // ---- the query's shape: the cover leaf streams its postings, the others are read as bitmap images
-    const uint32_t* cdocs = nullptr;
-    const uint16_t* cscores = nullptr;
-    const uint32_t* ctdir = nullptr;
-    uint32_t clen = 0;
-    const uint32_t* d_bitmap[ND];
-    const uint32_t* d_rank[ND];
+    // ---- the query's shape: the cover leaf streams its tile-packed postings, the others are read as bitmap words or 16-bit arrays
+    const uint32_t* ccov = nullptr;
+    const uint32_t* cgdir = nullptr;
+    const uint32_t* d_bitmap[NB1];
+    const uint32_t* d_rank[NB1];
+    const uint16_t* d_arr[NA1];
+    const uint32_t* d_agd[NA1];
     {
         const uint32_t ck = (uint32_t)__ffs((int)((sflags >> 8) & 0xFu)) - 1u;
-        uint32_t role_of[4] = {0u, 0u, 0u, 0u};  // leaf k -> 0 = cover, 1 + i = dense operand i
-        uint32_t i = 0;
+        const uint32_t am = (sflags >> 12) & 0xFu;  // leaf k is an array operand (the host instantiates NA = their number)
+        uint32_t role_of[4] = {0u, 0u, 0u, 0u};     // leaf k -> 0 = cover, 1 + i = operand i
+        uint32_t ib = 0, ia = NB;
 #pragma unroll
         for (uint32_t k = 0; k < n; ++k) {
             const VQ_CONST DList& d = gl[gops[k].list_begin];
             if (k == ck) {
-                cdocs = d.docs;
-                cscores = d.scores;
-                ctdir = d.tile_dir;
-                clen = d.len;
+                ccov = P->leaf[k].cov32;
+                cgdir = P->leaf[k].gdir;
                 if (lane == 0) {
                     sh[kShCts] = __float_as_uint(d.term_score);
                     sh[kShPrunable] = (d.term_score > 0.0f && d.max_raw < 0x7C00u) ? 1u : 0u;
                 }
             } else {
+                const bool is_arr = ((am >> k) & 1u) != 0u;  // uniform
+                const uint32_t role = is_arr ? ia : ib;
 #pragma unroll
-                for (uint32_t j = 0; j < ND; ++j)
-                    if (j == i) {
+                for (uint32_t j = 0; j < NB; ++j)
+                    if (!is_arr && j == role) {
                         d_bitmap[j] = d.bitmap;
                         d_rank[j] = d.rank_dir;
-                        if (lane == 0) {
-                            const uint16_t mr = d.max_raw;
-                            sh[kShTs + j] = __float_as_uint(d.term_score);
-                            sh[kShVmax + j] = (d.term_score > 0.0f && mr < 0x7C00u) ? __float_as_uint(posting_value(d.term_score, mr)) : 0x7F800000u;  // +inf: no bound
-                            reinterpret_cast<unsigned long long*>(sh + kShScores)[j] = (unsigned long long)(uintptr_t)d.scores;
-                        }
                     }
-                role_of[k] = 1u + i;
-                ++i;
+#pragma unroll
+                for (uint32_t a = 0; a < NA; ++a)
+                    if (is_arr && NB + a == role) {
+                        d_arr[a] = P->leaf[k].arr16;
+                        d_agd[a] = P->leaf[k].gdir;
+                    }
+                if (lane == 0) {
+                    const uint16_t mr = d.max_raw;
+                    sh[kShTs + role] = __float_as_uint(d.term_score);
+                    sh[kShVmax + role] = (d.term_score > 0.0f && mr < 0x7C00u) ? __float_as_uint(posting_value(d.term_score, mr)) : 0x7F800000u;  // +inf: no bound
+                    // where the operand's f16 scores are gathered from, as a u16 array: the list's own scores by posting index, or the low
+                    // halves of its tile-packed words by (2 x) packed position
+                    reinterpret_cast<unsigned long long*>(sh + kShScores)[role] = is_arr ? (unsigned long long)(uintptr_t)P->leaf[k].cov32 : (unsigned long long)(uintptr_t)d.scores;
+                }
+                role_of[k] = 1u + role;
+                if (is_arr) ++ia;
+                else ++ib;
             }
         }
         const KOp root(gops + n);
@@ -170,54 +188,58 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     uint32_t raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(thr_seen >> 32))), lane);
 
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const VQ_GLOBAL u32x4* cd4 = as_global(reinterpret_cast<const u32x4*>(cdocs));
-    const VQ_GLOBAL u32x2* cs2 = as_global(reinterpret_cast<const u32x2*>(cscores));
-    const uint32_t nvec = (clen + 3u) >> 2;
+    const VQ_GLOBAL u32x4* cc4 = as_global(reinterpret_cast<const u32x4*>(ccov));
 
     uint32_t un = 0, rn = 0;
     unsigned long long hits = 0;
     unsigned long long g_prev = 0ull;
 
-    // ---- tiles of the span; a slice of the cover's tile directory rides in a register (lane l: entries below tile dir_base + l)
+    // ---- tiles of the span; a slice of every tile-packed list's directory rides in a register (lane l: granules below tile dir_base + l)
     const uint32_t t_first = (span_lo - bitmap_base) >> kProbeTileShift;
     const uint32_t t_end = span_hi > span_lo ? ((span_hi - 1u - bitmap_base) >> kProbeTileShift) + 1u : t_first;  // one behind the last tile
     uint32_t dir_base = t_first;
-    auto load_dir = [&]() { return as_global(ctdir)[(dir_base + lane < t_end ? dir_base + lane : t_end) << (kProbeTileShift - kTileDirShift)]; };  // (entry t_end exists: one behind the last tile; the directory has an entry per 16384 docs)
-    uint32_t dirv = load_dir();
-    auto dir_at = [&](uint32_t tt) { return (uint32_t)__builtin_amdgcn_readlane((int)dirv, (int)(tt - dir_base)); };
-
-    // registers of the tile in flight: its words and rank entries, its cover postings (the first kPMaxR rounds)
-    u32x4 wk[ND][kPNV];
-    uint32_t rk[ND];
-    u32x4 nid[kPMaxR], cid[kPMaxR];
-    u32x2 nsc[kPMaxR], csc[kPMaxR];
+    auto load_dir = [&](const uint32_t* g) { return as_global(g)[dir_base + lane < t_end ? dir_base + lane : t_end]; };  // (entry t_end exists: one behind the last tile)
+    uint32_t dirv = load_dir(cgdir);
+    uint32_t adv[NA1];
 #pragma unroll
-    for (uint32_t r = 0; r < kPMaxR; ++r) {
-        nid[r] = cid[r] = kSent;
-        nsc[r] = csc[r] = u32x2{0u, 0u};
-    }
-    uint32_t pf_rounds = 0, pf_v0 = 0;
-    auto issue_tile = [&](const uint32_t tt, const uint32_t e0, const uint32_t e1) {  // uniform; tt < t_end; [e0, e1): the cover's postings in tile tt
-        pf_rounds = e1 > e0 ? ((e1 - (e0 & ~3u) + 255u) >> 8) : 0u;
-        pf_v0 = e0 >> 2;
+    for (uint32_t a = 0; a < NA; ++a) adv[a] = load_dir(d_agd[a]);
+    auto dir_at = [&](const uint32_t v, const uint32_t tt) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(tt - dir_base)); };
+
+    // registers of the tile in flight: its words / array vectors and rank entries, its cover postings (the first kPMaxR rounds)
+    u32x4 wk[ND][kPNV];
+    uint32_t rk[NB1];
+    u32x4 nid[kPMaxR], cid[kPMaxR];
+#pragma unroll
+    for (uint32_t r = 0; r < kPMaxR; ++r) nid[r] = cid[r] = kSent;
+    uint32_t pf_rounds = 0, pf_v0 = 0, pf_v1 = 0;
+    uint32_t na_g0[NA1], na_nv[NA1];  // array operands, tile in flight: first granule, granules (= 16-byte vectors of 8 offsets)
+    uint32_t a_g0[NA1], a_cnt[NA1];   // ... current tile: first granule, padded entries
+#pragma unroll
+    for (uint32_t a = 0; a < NA1; ++a) na_g0[a] = na_nv[a] = a_g0[a] = a_cnt[a] = 0u;
+    auto issue_tile = [&](const uint32_t tt, const uint32_t g0, const uint32_t g1) {  // uniform; tt < t_end; [g0, g1): the cover's granules of tile tt; na_g0 / na_nv set
+        pf_rounds = (g1 - g0 + 31u) >> 5;  // rounds of 256 postings
+        pf_v0 = g0 * 2u;
+        pf_v1 = g1 * 2u;
         if (pf_rounds) {  // uniform: a tile without cover postings has no hits — nothing of it is read
 #pragma unroll
-            for (uint32_t i = 0; i < ND; ++i) {
+            for (uint32_t i = 0; i < NB; ++i) {
                 const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(d_bitmap[i] + (size_t)tt * kPTW));
 #pragma unroll
                 for (uint32_t h = 0; h < kPNV; ++h) wk[i][h] = gb[h * 64u + lane];
                 rk[i] = as_global(d_rank[i])[tt * kPRk + lane];
             }
 #pragma unroll
+            for (uint32_t a = 0; a < NA; ++a) {
+                const VQ_GLOBAL u32x4* ga = as_global(reinterpret_cast<const u32x4*>(d_arr[a]) + na_g0[a]);
+#pragma unroll
+                for (uint32_t h = 0; h < kPNV; ++h)
+                    if (h * 64u + lane < na_nv[a]) wk[NB + a][h] = ga[h * 64u + lane];  // (only the lanes that hold entries of the tile)
+            }
+#pragma unroll
             for (uint32_t r = 0; r < kPMaxR; ++r) {
                 const uint32_t v = pf_v0 + r * 64u + lane;
                 nid[r] = kSent;
-                nsc[r] = u32x2{0u, 0u};
-                if (r < pf_rounds && v * 4u < e1) {  // (only the lanes that hold postings of the tile; e1 <= the list's length)
-                    nid[r] = cd4[v];
-                    nsc[r] = cs2[v];
-                }
+                if (r < pf_rounds && v < pf_v1) nid[r] = cc4[v];  // (only the lanes that hold postings of the tile)
             }
         }
     };
@@ -345,61 +367,25 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         rn -= 64u;
         push_keys(key, key > *thr && key < cs.upper, false);
     };
-    // Rank the first `cnt` (<= 64) entries of the unranked queue — live hits of the CURRENT tile, whose words are in LDS — into the ranked
-    // queue: index in dense operand i = rank directory entry of the doc's 512-doc group + set bits of the group below the doc.  The rest
-    // of the unranked queue moves to the front.
-    auto rank_some = [&](const uint32_t cnt) {
-        while (rn + cnt > kPR) flush_sync();  // uniform, warm-up only
-        probe_lds_fence();
-        if (ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
-            const uint32_t el = lane & 31u, role = lane >> 5;
-            if (el < cnt) {
-                const uint32_t e = uq[el];
-                const uint32_t rel = e >> 16;  // doc - tile_lo
-                const uint32_t slot = (rhead + rn + el) & (kPR - 1u);
-                if (role == 0u) {
-                    rq[slot] = tile_lo + rel;
-                    rq[kPR + slot] = e & 0xFFFFu;
-                }
-                const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
-                const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
-                const uint32_t* tl = tile + role * kPTW;
-                uint32_t acc = rank[role * kPRk + g] + (uint32_t)__popc(tl[rel >> 5] & below);
-                const u32x4* gw = reinterpret_cast<const u32x4*>(tl + g * 16u);
+    // index of the doc at in-tile offset `rel` in bitmap operand i: rank directory entry of its 512-doc group + set bits of the group below it
+    auto bitmap_rank = [&](const uint32_t i, const uint32_t rel) {
+        const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
+        const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
+        const uint32_t* tl = tile + i * kPTW;
+        uint32_t acc = rank[i * kPRk + g] + (uint32_t)__popc(tl[rel >> 5] & below);
+        const u32x4* gw = reinterpret_cast<const u32x4*>(tl + g * 16u);
 #pragma unroll
-                for (uint32_t v4 = 0; v4 < 4; ++v4) {
-                    const u32x4 x = gw[v4];
-                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
-                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
-                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
-                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
-                }
-                rq[(2u + role) * kPR + slot] = acc;
-            }
-        } else if (lane < cnt) {
-            const uint32_t e = uq[lane];
-            const uint32_t rel = e >> 16;  // doc - tile_lo
-            const uint32_t slot = (rhead + rn + lane) & (kPR - 1u);
-            rq[slot] = tile_lo + rel;
-            rq[kPR + slot] = e & 0xFFFFu;
-            const uint32_t g = rel >> kRankShift, wi = (rel >> 5) & 15u, below = (1u << (rel & 31u)) - 1u;
-            const int full = (int)((1u << wi) - 1u);  // bit j: word j of the group lies entirely below the doc
-#pragma unroll
-            for (uint32_t i = 0; i < ND; ++i) {
-                uint32_t acc = rank[i * kPRk + g] + (uint32_t)__popc(tile[i * kPTW + (rel >> 5)] & below);
-                const u32x4* gw = reinterpret_cast<const u32x4*>(tile + i * kPTW + g * 16u);
-#pragma unroll
-                for (uint32_t v4 = 0; v4 < 4; ++v4) {
-                    const u32x4 x = gw[v4];
-                    acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
-                    acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
-                    acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
-                    acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
-                }
-                rq[(2u + i) * kPR + slot] = acc;
-            }
+        for (uint32_t v4 = 0; v4 < 4; ++v4) {
+            const u32x4 x = gw[v4];
+            acc += (uint32_t)__popc(x.x & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 0u, 1u));
+            acc += (uint32_t)__popc(x.y & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 1u, 1u));
+            acc += (uint32_t)__popc(x.z & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 2u, 1u));
+            acc += (uint32_t)__popc(x.w & (uint32_t)__builtin_amdgcn_sbfe(full, v4 * 4u + 3u, 1u));
         }
-        rn += cnt;
+        return acc;
+    };
+    // the rest of the unranked queue moves to the front
+    auto uq_shift = [&](const uint32_t cnt) {
         if (un > cnt) {  // uniform
             const uint32_t rem = un - cnt;
             constexpr uint32_t kMove = kPU / 64u;
@@ -413,43 +399,118 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         }
         un -= cnt;
     };
+    // Take the first `cnt` (<= 64) entries of the unranked queue — postings of the CURRENT tile, whose words / arrays are in LDS — into the
+    // ranked queue.  Without array operands the entries are live hits already and only need their indices in the bitmap operands.  With array
+    // operands they are postings that passed the bitmap operands: each is looked up in every array (binary search over the tile's sorted
+    // offsets; the pads are the largest values), the ones found are the query's hits, and the strong ones among them are ranked.
+    auto rank_some = [&](const uint32_t cnt) {
+        while (rn + cnt > kPR) flush_sync();  // uniform, warm-up only
+        probe_lds_fence();
+        if (NA == 0u && ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
+            const uint32_t el = lane & 31u, role = lane >> 5;
+            if (el < cnt) {
+                const uint32_t e = uq[el];
+                const uint32_t rel = e >> 16;  // doc - tile_lo
+                const uint32_t slot = (rhead + rn + el) & (kPR - 1u);
+                if (role == 0u) {
+                    rq[slot] = tile_lo + rel;
+                    rq[kPR + slot] = e & 0xFFFFu;
+                }
+                rq[(2u + role) * kPR + slot] = bitmap_rank(role, rel);
+            }
+            rn += cnt;
+        } else if (NA == 0u) {
+            if (lane < cnt) {
+                const uint32_t e = uq[lane];
+                const uint32_t rel = e >> 16;  // doc - tile_lo
+                const uint32_t slot = (rhead + rn + lane) & (kPR - 1u);
+                rq[slot] = tile_lo + rel;
+                rq[kPR + slot] = e & 0xFFFFu;
+#pragma unroll
+                for (uint32_t i = 0; i < NB; ++i) rq[(2u + i) * kPR + slot] = bitmap_rank(i, rel);
+            }
+            rn += cnt;
+        } else {
+            uint32_t e = 0xFFFFFFFFu, pos[NA1];
+            bool found = lane < cnt;
+            if (found) e = uq[lane];
+            const uint32_t rel = e >> 16;
+#pragma unroll
+            for (uint32_t a = 0; a < NA; ++a) {
+                const uint16_t* A = reinterpret_cast<const uint16_t*>(tile + (NB + a) * kPTW);
+                uint32_t lo = 0u, len = a_cnt[a];  // uniform length: every lane takes the same number of steps
+                while (len > 1u) {
+                    const uint32_t half = len >> 1;
+                    lo = (uint32_t)A[lo + half] <= rel ? lo + half : lo;  // the last entry <= rel
+                    len -= half;
+                }
+                found = found && a_cnt[a] != 0u && (uint32_t)A[lo] == rel;
+                pos[a] = lo;
+            }
+            const unsigned long long fm = wballot(found);
+            hits += (unsigned long long)__popcll(fm);
+            const bool live = found && (e & 0xFFFFu) >= raw_min;
+            const unsigned long long lm = wballot(live);
+            if (lm) {  // uniform
+                if (live) {
+                    const uint32_t slot = (rhead + rn + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))) & (kPR - 1u);
+                    rq[slot] = tile_lo + rel;
+                    rq[kPR + slot] = e & 0xFFFFu;
+#pragma unroll
+                    for (uint32_t i = 0; i < NB; ++i) rq[(2u + i) * kPR + slot] = bitmap_rank(i, rel);
+#pragma unroll
+                    for (uint32_t a = 0; a < NA; ++a) rq[(2u + NB + a) * kPR + slot] = (a_g0[a] * 8u + pos[a]) * 2u;  // (u16 index of the packed word's low half)
+                }
+                rn += (uint32_t)__popcll(lm);
+            }
+        }
+        uq_shift(cnt);
+    };
     // one round of 256 cover postings (lane l: four consecutive ones) against the tile in LDS
-    uint32_t lo_bound = 0, width = 0;
+    uint32_t lo_rel = 0, width = 0;
     struct ProbeWords {
         uint32_t w[4];
     };
-    auto probe_read = [&](const u32x4 d4) {  // the operands' words at the four postings of a lane (AND of the operands)
-        const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    auto probe_read = [&](const u32x4 e4) {  // the bitmap operands' words at the four postings of a lane (AND of the operands)
+        const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
         ProbeWords pw;
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) {
-            const uint32_t a = (dd[c] >> 5) & (kPTW - 1u);
-            pw.w[c] = tile[a];
+            pw.w[c] = 0xFFFFFFFFu;
+            if (NB) {
+                const uint32_t a = (ee[c] >> 21) & (kPTW - 1u);
+                pw.w[c] = tile[a];
 #pragma unroll
-            for (uint32_t i = 1; i < ND; ++i) pw.w[c] &= tile[i * kPTW + a];
+                for (uint32_t i = 1; i < NB; ++i) pw.w[c] &= tile[i * kPTW + a];
+            }
         }
         return pw;
     };
-    auto probe_eval = [&](const u32x4 d4, const u32x2 s2, const ProbeWords& pw) {
-        const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
-        const uint32_t rw[4] = {s2.x & 0xFFFFu, s2.x >> 16, s2.y & 0xFFFFu, s2.y >> 16};
+    auto probe_eval = [&](const u32x4 e4, const ProbeWords& pw) {
+        const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
         unsigned long long lm[4];
         bool live[4];
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) {
-            const bool in = (dd[c] - lo_bound) < width;  // (the span's first and last tile are cut; the padding behind the list's end is outside too)
-            const bool bit = ((pw.w[c] >> (dd[c] & 31u)) & 1u) != 0u;
-            const bool strong = rw[c] >= raw_min;
+            const uint32_t rel = ee[c] >> 16;
+            const bool in = (rel - lo_rel) < width;  // (the span's first and last tile are cut; a pad's offset 65535 is outside every tile)
+            const bool bit = ((pw.w[c] >> (rel & 31u)) & 1u) != 0u;
             // (ballots of the plain compares, joined as masks: a ballot of a joined bool costs two more vector instructions)
-            const unsigned long long sm = wballot(in) & wballot(bit);
-            hits += (unsigned long long)__popcll(sm);
-            lm[c] = sm & wballot(strong);
-            live[c] = in && bit && strong;
+            const unsigned long long sm = NB ? (wballot(in) & wballot(bit)) : wballot(in);
+            if (NA == 0u) {
+                const bool strong = (ee[c] & 0xFFFFu) >= raw_min;
+                hits += (unsigned long long)__popcll(sm);
+                lm[c] = sm & wballot(strong);
+                live[c] = in && bit && strong;
+            } else {  // (the arrays decide what a hit is: rank_some counts them)
+                lm[c] = sm;
+                live[c] = in && bit;
+            }
         }
         if (lm[0] | lm[1] | lm[2] | lm[3]) {  // uniform
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
-                if (live[c]) uq[un + (uint32_t)__popcll(lm[c] & ((1ull << lane) - 1ull))] = ((dd[c] - tile_lo) << 16) | rw[c];
+                if (live[c]) uq[un + (uint32_t)__popcll(lm[c] & ((1ull << lane) - 1ull))] = ee[c];  // (in-tile offset << 16 | raw score: the packed word itself)
                 un += (uint32_t)__popcll(lm[c]);
             }
         }
@@ -457,7 +518,17 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 
     uint32_t t = t_first;
     tile_lo = bitmap_base + (t_first << kProbeTileShift);
-    if (t < t_end) issue_tile(t, dir_at(t), dir_at(t + 1u));
+    auto next_arrays = [&](const uint32_t tt) {  // uniform: array operands' slices of tile tt out of their directory registers
+#pragma unroll
+        for (uint32_t a = 0; a < NA; ++a) {
+            na_g0[a] = dir_at(adv[a], tt);
+            na_nv[a] = dir_at(adv[a], tt + 1u) - na_g0[a];
+        }
+    };
+    if (t < t_end) {
+        next_arrays(t);
+        issue_tile(t, dir_at(dirv, t), dir_at(dirv, t + 1u));
+    }
     PS_AT(0)
     while (t < t_end) {  // uniform
         PS_COUNT(8)
@@ -465,21 +536,25 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         // instruction and knows of nothing in flight behind it, so none of ITS waits can fall behind the next tile's loads)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_setprio(3);  // a wave whose data has landed goes first until its next loads are out (nothing it does in between should queue behind other waves' arithmetic)
-        const uint32_t rounds = pf_rounds, v0 = pf_v0;
+        const uint32_t rounds = pf_rounds, v0 = pf_v0, v1 = pf_v1;
         if (rounds) {  // uniform
 #pragma unroll
             for (uint32_t i = 0; i < ND; ++i) {
 #pragma unroll
                 for (uint32_t h = 0; h < kPNV; ++h) reinterpret_cast<u32x4*>(tile + i * kPTW)[h * 64u + lane] = wk[i][h];
-                rank[i * kPRk + lane] = rk[i];
+                if (i < NB) rank[i * kPRk + lane] = rk[i < NB ? i : 0u];
+            }
+#pragma unroll
+            for (uint32_t a = 0; a < NA; ++a) {
+                a_g0[a] = na_g0[a];
+                a_cnt[a] = na_nv[a] * 8u;
             }
 #pragma unroll
             for (uint32_t r = 0; r < kPMaxR; ++r) {
                 cid[r] = nid[r];
-                csc[r] = nsc[r];
                 // (a use the compiler cannot rename away: it has to wait for the postings HERE, where everything in flight has landed — not
                 //  later, behind the next tile's loads, where its only safe wait is for all of them)
-                asm volatile("" : "+v"(cid[r]), "+v"(csc[r]));
+                asm volatile("" : "+v"(cid[r]));
             }
         }
         // ---- first everything that CONSUMES a load of the last period (the flush in flight, the shared threshold word) ...
@@ -487,26 +562,31 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
            //  knows of nothing in flight, and none of its waits can fall behind the next tile's loads)
             uint32_t fr = f_r, glo = (uint32_t)g_prev, ghi = (uint32_t)(g_prev >> 32);
             asm volatile("" : "+v"(fr), "+v"(glo), "+v"(ghi), "+v"(dirv));
+#pragma unroll
+            for (uint32_t a = 0; a < NA; ++a) asm volatile("" : "+v"(adv[a]));
             f_r = (uint16_t)fr;
             g_prev = ((unsigned long long)ghi << 32) | glo;
         }
         PS_AT(1)
         if (lane == 0 && g_prev > *thr) *thr = g_prev;  // what other spans of the query have published (QHeader::gthr), asked for a tile ago
         const bool more = t + 1u < t_end;
-        uint32_t ne0 = 0, ne1 = 0;  // the next tile's slice of the cover (directory entries)
+        uint32_t ng0 = 0, ng1 = 0;  // the next tile's slice of the cover (directory entries)
         if (more) {  // uniform
-            if (t + 2u - dir_base >= 64u) {  // the directory slice is used up (62 tiles): the next one (a wait, once per 62 tiles)
+            if (t + 2u - dir_base >= 64u) {  // the directory slices are used up (62 tiles): the next ones (a wait, once per 62 tiles)
                 dir_base = t + 1u;
-                dirv = load_dir();
+                dirv = load_dir(cgdir);
+#pragma unroll
+                for (uint32_t a = 0; a < NA; ++a) adv[a] = load_dir(d_agd[a]);
             }
-            ne0 = dir_at(t + 1u);
-            ne1 = dir_at(t + 2u);
+            ng0 = dir_at(dirv, t + 1u);
+            ng1 = dir_at(dirv, t + 2u);
+            next_arrays(t + 1u);
         }
         if (f_stage || rn >= 64u) PS_COUNT(11)
         flush_service(false);  // takes the gather issued a tile ago, issues the next one (the LAST consumer of an old load: behind it only new ones go out)
         PS_AT(4)
         // ---- ... then everything the NEXT tile needs is asked for, and nothing below waits for any of it
-        if (more) issue_tile(t + 1u, ne0, ne1);  // uniform
+        if (more) issue_tile(t + 1u, ng0, ng1);  // uniform
         else pf_rounds = 0;
         if (lane == 0) g_prev = __hip_atomic_load(gthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
@@ -519,7 +599,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         }
         PS_AT(5)
 #ifdef VQ_PROBE_STREAM_ONLY  // diagnostic build: the loads and the LDS fill only (what the memory side alone takes)
-        hits += (unsigned long long)__popcll(wballot((cid[0].x ^ csc[0].x ^ cid[1].y ^ csc[1].y) == 0x12345u));  // (keeps the cover loads alive)
+        hits += (unsigned long long)__popcll(wballot((cid[0].x ^ cid[1].y) == 0x12345u));  // (keeps the cover loads alive)
         if (rounds && span == 0xFFFFFFFFu) {
 #else
         if (rounds) {  // uniform
@@ -527,7 +607,8 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             // ---- the cover's postings of the tile against the operands' words
             const uint32_t tile_end = tile_lo + kPT;
             const uint32_t tile_hi = (tile_end > tile_lo && tile_end < span_hi) ? tile_end : span_hi;
-            lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
+            const uint32_t lo_bound = tile_lo > span_lo ? tile_lo : span_lo;
+            lo_rel = lo_bound - tile_lo;
             width = tile_hi - lo_bound;
             {  // the register rounds: every LDS read of the tile's postings goes out first, then the few hits are picked up
                 ProbeWords pw[kPMaxR];
@@ -538,24 +619,20 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 for (uint32_t r = 0; r < kPMaxR; ++r)
                     if (r < rounds) {  // uniform
                         PS_COUNT(9)
-                        probe_eval(cid[r], csc[r], pw[r]);
+                        probe_eval(cid[r], pw[r]);
                     }
             }
             for (uint32_t r = kPMaxR; r < rounds; ++r) {  // a dense stretch of the cover: further rounds are fetched on the spot
                 while (un >= kPU - 256u) rank_some(64u);  // uniform: room for another round
                 const uint32_t v = v0 + r * 64u + lane;
-                u32x4 d4 = kSent;
-                u32x2 s2 = u32x2{0u, 0u};
-                if (v < nvec) {  // (a few postings of the next tile may ride along: they fail the range test)
-                    d4 = cd4[v];
-                    s2 = cs2[v];
-                }
+                u32x4 e4 = kSent;
+                if (v < v1) e4 = cc4[v];
                 PS_COUNT(9)
-                const ProbeWords pw = probe_read(d4);
-                probe_eval(d4, s2, pw);
+                const ProbeWords pw = probe_read(e4);
+                probe_eval(e4, pw);
             }
             PS_AT(2)
-            while (un) {  // uniform: the tile's live hits are ranked while its words are still in LDS
+            while (un) {  // uniform: the tile's queued postings are looked up / ranked while its words are still in LDS
                 PS_COUNT(10)
                 rank_some(un < 64u ? un : 64u);
             }
@@ -597,9 +674,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     const uint32_t q = qmap[ql];
     const uint8_t* blob = blobs + blob_off[q];
     const uint32_t n = as_const<QHeader>(blob)->simple_n;
-    if (n == 2u) probe_body<1>(blob, span, q, cand_cap, span_keys, num_hits);
-    else if (n == 3u) probe_body<2>(blob, span, q, cand_cap, span_keys, num_hits);
-    else probe_body<3>(blob, span, q, cand_cap, span_keys, num_hits);
+    const uint32_t na = (uint32_t)__popc((as_const<QHeader>(blob)->simple_flags >> 12) & 0xFu);  // operands probed as 16-bit arrays
+    if (n == 2u) {
+        if (na == 0u) probe_body<1, 0>(blob, span, q, cand_cap, span_keys, num_hits);
+        else probe_body<1, 1>(blob, span, q, cand_cap, span_keys, num_hits);
+    } else if (n == 3u) {
+        if (na == 0u) probe_body<2, 0>(blob, span, q, cand_cap, span_keys, num_hits);
+        else if (na == 1u) probe_body<2, 1>(blob, span, q, cand_cap, span_keys, num_hits);
+        else probe_body<2, 2>(blob, span, q, cand_cap, span_keys, num_hits);
+    } else {
+        if (na == 0u) probe_body<3, 0>(blob, span, q, cand_cap, span_keys, num_hits);
+        else if (na == 1u) probe_body<3, 1>(blob, span, q, cand_cap, span_keys, num_hits);
+        else if (na == 2u) probe_body<3, 2>(blob, span, q, cand_cap, span_keys, num_hits);
+        else probe_body<3, 3>(blob, span, q, cand_cap, span_keys, num_hits);
+    }
 }
 
 // max_nd: most dense operands of a query of the launch (sizes the LDS tile area)
