@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
-O=gpurun_out/r03_$tag; mkdir -p $O
+O=gpurun_out/r04_$tag; mkdir -p $O
 B="bench.py --steps 4 --warmup 2 --no-cpu --no-extra --no-latency $*"
-run() { name=$1; shift; S=/tmp/r03_${tag}_$name; rm -rf $S
+run() { name=$1; shift; S=/tmp/r04_${tag}_$name; rm -rf $S
   timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "vq::" --output-format csv --pmc "$@" -d $S -o p -- python3 $B > $O/bench_$name.json 2> $O/bench_$name.err || exit 1
   python3 tools/pmc_summary.py $S $S/sum.csv > /dev/null 2>&1; head -1 $S/sum.csv > $O/pmc_$name.csv; grep "vq::" $S/sum.csv >> $O/pmc_$name.csv; grep "k_scan" $O/pmc_$name.csv; }
 run sq_insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_WR SQ_INSTS_FLAT

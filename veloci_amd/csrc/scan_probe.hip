@@ -384,32 +384,19 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         }
         return acc;
     };
-    // the rest of the unranked queue moves to the front
-    auto uq_shift = [&](const uint32_t cnt) {
-        if (un > cnt) {  // uniform
-            const uint32_t rem = un - cnt;
-            constexpr uint32_t kMove = kPU / 64u;
-            uint32_t t[kMove];
-#pragma unroll
-            for (uint32_t r = 0; r < kMove; ++r) t[r] = r * 64u + lane < rem ? uq[cnt + r * 64u + lane] : 0u;
-            probe_lds_fence();
-#pragma unroll
-            for (uint32_t r = 0; r < kMove; ++r)
-                if (r * 64u + lane < rem) uq[r * 64u + lane] = t[r];
-        }
-        un -= cnt;
-    };
-    // Take the first `cnt` (<= 64) entries of the unranked queue — postings of the CURRENT tile, whose words / arrays are in LDS — into the
+    // Take the LAST `cnt` (<= 64) entries of the unranked queue (their order is of no consequence: nothing has to move) — postings of the CURRENT tile, whose words / arrays are in LDS — into the
     // ranked queue.  Without array operands the entries are live hits already and only need their indices in the bitmap operands.  With array
     // operands they are postings that passed the bitmap operands: each is looked up in every array (binary search over the tile's sorted
     // offsets; the pads are the largest values), the ones found are the query's hits, and the strong ones among them are ranked.
     auto rank_some = [&](const uint32_t cnt) {
         while (rn + cnt > kPR) flush_sync();  // uniform, warm-up only
         probe_lds_fence();
+        const uint32_t* const uqe = uq + (un - cnt);
+        un -= cnt;
         if (NA == 0u && ND == 2u && cnt <= 32u) {  // uniform: the usual case — both operands at once, lanes 0-31 rank in operand 0, lanes 32-63 in operand 1
             const uint32_t el = lane & 31u, role = lane >> 5;
             if (el < cnt) {
-                const uint32_t e = uq[el];
+                const uint32_t e = uqe[el];
                 const uint32_t rel = e >> 16;  // doc - tile_lo
                 const uint32_t slot = (rhead + rn + el) & (kPR - 1u);
                 if (role == 0u) {
@@ -421,7 +408,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             rn += cnt;
         } else if (NA == 0u) {
             if (lane < cnt) {
-                const uint32_t e = uq[lane];
+                const uint32_t e = uqe[lane];
                 const uint32_t rel = e >> 16;  // doc - tile_lo
                 const uint32_t slot = (rhead + rn + lane) & (kPR - 1u);
                 rq[slot] = tile_lo + rel;
@@ -433,7 +420,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         } else {
             uint32_t e = 0xFFFFFFFFu, pos[NA1];
             bool found = lane < cnt;
-            if (found) e = uq[lane];
+            if (found) e = uqe[lane];
             const uint32_t rel = e >> 16;
 #pragma unroll
             for (uint32_t a = 0; a < NA; ++a) {
@@ -464,7 +451,6 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 rn += (uint32_t)__popcll(lm);
             }
         }
-        uq_shift(cnt);
     };
     // one round of 256 cover postings (lane l: four consecutive ones) against the tile in LDS
     uint32_t lo_rel = 0, width = 0;
@@ -539,13 +525,16 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         const uint32_t rounds = pf_rounds, v0 = pf_v0, v1 = pf_v1;
         if (rounds) {  // uniform
 #pragma unroll
-            for (uint32_t i = 0; i < ND; ++i) {
+            for (uint32_t i = 0; i < NB; ++i) {
 #pragma unroll
                 for (uint32_t h = 0; h < kPNV; ++h) reinterpret_cast<u32x4*>(tile + i * kPTW)[h * 64u + lane] = wk[i][h];
-                if (i < NB) rank[i * kPRk + lane] = rk[i < NB ? i : 0u];
+                rank[i * kPRk + lane] = rk[i];
             }
 #pragma unroll
             for (uint32_t a = 0; a < NA; ++a) {
+#pragma unroll
+                for (uint32_t h = 0; h < kPNV; ++h)
+                    if (h * 64u < na_nv[a]) reinterpret_cast<u32x4*>(tile + (NB + a) * kPTW)[h * 64u + lane] = wk[NB + a][h];  // uniform: only the vectors that hold entries of the tile
                 a_g0[a] = na_g0[a];
                 a_cnt[a] = na_nv[a] * 8u;
             }
