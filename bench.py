@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0        # measured float4 copy on MI355X (same guide): what a streaming kernel can reach
+DEFAULT_BATCH = 1024          # queries per step
+DEFAULT_TRIPLES = 512         # distinct probe triples: a step runs as two launches of 512 queries (VQ_SHARD_CHUNKS=2), every query of a launch reads its own
+                              # three lists.  (1024 triples would need ~320 GB of host memory to generate and stage: the GPU boxes' limit is 300 GiB)
 
 WORKLOADS = {"and": "3-term AND", "or": "3-term OR", "single": "single-term scan", "config2": "single-term scan over df 1e3 / 1e5 / 1e6 (config #2)",
              "config3": "3-term AND + 2 phrase pairs + text locality",
@@ -88,9 +91,10 @@ def edited_terms(pool, count, seed=4):
     return out
 
 
-def make_requests(workload, meta, batch, probes=1024):
+def make_requests(workload, meta, batch, probes=1024, tri_limit=None):
     from veloci_amd import synth
-    tri = lambda i: list(meta.triples[i % len(meta.triples)])
+    n_tri = min(len(meta.triples), tri_limit or len(meta.triples))  # (tri_limit: cycle over the first few triples only — launches that hold every list several times)
+    tri = lambda i: list(meta.triples[i % n_tri])
     if workload == "and":
         return [synth.req_and(tri(i), top=10) for i in range(batch)]
     if workload == "or":
@@ -187,12 +191,12 @@ class Bench:
         self.searcher = vdist.ShardedSearcher(self.index, always_collective=True) if dist_on else None
         self.docs = docs
 
-    def run(self, workload, batch_size, steps, warmup, latency=True, chunks=None):
+    def run(self, workload, batch_size, steps, warmup, latency=True, chunks=None, tri_limit=None):
         """-> (qps, ms_per_step, p50 single-query latency ms, kernel table, first hit counts, requests as dicts)"""
         import numpy as np
         import torch
         import veloci_amd
-        reqs_json = make_requests(workload, self.meta, batch_size, self.args.probes)
+        reqs_json = make_requests(workload, self.meta, batch_size, self.args.probes, tri_limit)
         reqs = [veloci_amd.Request(r) for r in reqs_json]
         batch = veloci_amd.RequestBatch(reqs)
         index, searcher = self.index, self.searcher
@@ -280,31 +284,34 @@ def roofline_object(table, docs, triples, batch, workload, world):
             "peak_measured_copy": HBM_COPY_GBPS, "frac_of_measured_copy": round(k["GBps"] / HBM_COPY_GBPS, 4), "traffic": None,
             "bytes_min_this_layout_per_launch": k["layout_bytes_per_launch"], "launch_ms": k["launch_ms"], "launches": k["launches"],
             "queries_per_launch": k["queries_per_launch"],
-            # memory requests, not bytes, are what this kernel runs out of (profiles/r02_fetch_size_calibration.txt: the fabric serves ~40-45 G
-            # requests/s whether a request is a full 128-B line of a stream or a lone 64-B sector holding one 2-byte score): streamed bytes / 128
-            # plus one request per gathered score (an upper bound: neighbouring survivors can share a sector)
-            "requests": {"per_launch_upper_bound": int((k["layout_bytes_per_launch"] - k["gathered_bytes_per_launch"]) / 128 + k["gathered_bytes_per_launch"] / 2),
-                         "Greq_per_s_upper_bound": round(((k["layout_bytes_per_launch"] - k["gathered_bytes_per_launch"]) / 128 + k["gathered_bytes_per_launch"] / 2) / (k["launch_ms"] * 1e-3) / 1e9, 1) if k["launch_ms"] else None,
-                         "ceiling_measured_Greq_per_s": 45.0, "ceiling_source": "tools/fetch_calib.hip: 16 B/lane stream 39.5, paired 64-B sectors 42, lone 64-B sectors 44.8 G requests/s"},
-            "algorithmic_equiv": {"GBps": k["algorithmic_equiv_GBps"], "frac": round(k["algorithmic_equiv_GBps"] / HBM_PEAK_GBPS, 4),
-                                  "note": "SURVEY.md 8(d) accounting: 6 B per posting of every list + 8 B per returned hit, as if postings were streamed"},
-            "note": "achieved = bytes this layout must move (bitmap words of dense lists, 4 B per id of scattered lists, 6 B per streamed posting, "
-                    "2-4 B per gathered score / value as counted by the kernel, 8 B per key) / mean launch time from HIP events inside the timed region"}
-    # HBM traffic from PMC passes is taken offline (rocprofv3 cannot wrap a region of this process): reported only when a committed
-    # profile was taken on exactly this configuration, and labelled as such
-    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            # SURVEY.md 8(d)'s accounting (6 B per posting of every list + 8 B per returned hit, as if every posting were streamed) beside the
+            # bytes this layout really has to move: it exceeds the peak because dense lists are read as bitmap words / 16-bit arrays
+            "algorithmic_equiv": {"GBps": k["algorithmic_equiv_GBps"], "frac": round(k["algorithmic_equiv_GBps"] / HBM_PEAK_GBPS, 4)},
+            "achieved_is": "bytes this layout must move per launch (DESIGN.md 5) / mean launch time from HIP events on the launch stream inside the timed region"}
+    # HBM traffic comes from PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of this same command under rocprofv3: the counters cannot be read
+    # from inside the process): the committed figure is reported when it was taken on exactly this configuration, with its source
+    for fn in ("r04_traffic.json", "r03_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 tr = json.load(f)
             c = tr["config"]
             same_launch = c.get("queries_per_launch") is None or abs(float(c["queries_per_launch"]) - float(roof["queries_per_launch"])) < 0.5
-            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (docs, triples, batch, workload, world) and same_launch:
-                roof["traffic_profiled_offline"] = {"bytes_per_launch": tr["traffic_bytes_per_launch"], "source": f"profiles/{fn}",
-                                                    "how": tr.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes")}
+            if (c["docs"], c["triples"], c["batch"], c["workload"], c["n_gpus"]) == (docs, triples, batch, workload, world) and same_launch and tr.get("kernel", name) == name:
+                roof["traffic"] = tr["traffic_bytes_per_launch"]
+                roof["traffic_source"] = f"profiles/{fn}: " + tr.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md prescribes")
+                roof["traffic_over_layout_min"] = round(tr["traffic_bytes_per_launch"] / max(k["layout_bytes_per_launch"], 1), 3)
                 break
         except (OSError, KeyError, ValueError):
             pass
     return roof
+
+
+def leg_summary(qps, ms, table):
+    """one workload in a few numbers: what the driver's record should still show when the kernel tables are cut off"""
+    scans = {k: v for k, v in table.items() if v["scan"]} or table
+    name = dominant(scans) if scans else None
+    k = table.get(name, {})
+    return {"qps": round(qps, 1), "ms_per_step": round(ms, 3), "kernel": name, "launch_ms": k.get("launch_ms"), "frac": k.get("frac"), "queries_per_launch": k.get("queries_per_launch")}
 
 
 def main():
@@ -313,8 +320,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=100_000_000)
-    ap.add_argument("--triples", type=int, default=256, help="distinct (a,b,c) probe triples; the query stream cycles over them (256 = one per query of a 256-query launch: no list is read twice inside a launch, so nothing is served from L2 / Infinity Cache that a stream of distinct queries would not find there)")
-    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--triples", type=int, default=DEFAULT_TRIPLES, help="distinct (a,b,c) probe triples; the query stream cycles over them.  A step is ONE launch of --batch queries: with triples >= batch no posting list is read twice inside a launch, so nothing is served from L2 / Infinity Cache that a stream of distinct queries would not find there")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH)
     ap.add_argument("--terms", type=int, default=100_000, help="dictionary size")
     ap.add_argument("--probes", type=int, default=1024, help="config4: distinct fuzzy probe terms per batch")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample (0 = skip)")
@@ -330,6 +337,13 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # fewer distinct triples than queries per step: the step is cut into two launches (read once, when the library makes its first step), so that
+    # no launch holds a list twice as long as triples >= batch / 2
+    launches_per_step = 1
+    if args.triples < args.batch and args.batch >= 512 and os.environ.get("VQ_BENCH_ONE_LAUNCH") != "1":
+        os.environ.setdefault("VQ_SHARD_CHUNKS", "2")
+    if os.environ.get("VQ_SHARD_CHUNKS") == "2" and args.batch >= 512:
+        launches_per_step = 2
 
     # stdout carries ONE line — the result; whatever a library prints there (RCCL greets on stdout when a communicator is made) goes to stderr
     sys.stdout.flush()
@@ -380,11 +394,14 @@ def main():
             "dtype": "u32 doc ids + f16->f32 scores", "data": "synthetic",
             "config": {"workload": f"{args.docs}-doc synthetic index, {WORKLOADS[args.workload]} (df 10%/3%/1% of docs, planted overlap), top 10, batches of {args.batch}",
                        "docs": args.docs, "triples": args.triples, "batch": args.batch, "postings_per_query": int(sum(spec.fractions) * args.docs),
+                       "launches_per_step": launches_per_step, "distinct_triples_per_launch": min(args.triples, args.batch // launches_per_step),
+                       "copies_of_a_list_per_launch": max(1, -(-(args.batch // launches_per_step) // max(args.triples, 1))),
                        "sharding": f"doc-range x{world}", "first_hit_counts": first_hits},
             "p50_latency_ms_single_query": (round(p50, 3) if p50 is not None else None),
             "roofline": roofline_object(table, args.docs, args.triples, args.batch, args.workload, world),
-            "kernels": table,
         }
+        legs = {"headline": leg_summary(qps, ms_step, table)}
+        tables = {"headline": table}
         want_cpu = not args.no_cpu and args.cpu_seconds > 0
         if world == 1 and not dist_on and args.workload in ("and", "or", "single") and (want_cpu or not args.no_parity):
             n_tri = min(2, len(bench.meta.triples))
@@ -396,36 +413,53 @@ def main():
                 log(f"parity: {out['parity_checked']} rows of the last timed step equal the oracle's (hit counts, ids, score bits); oracle setup + check {time.time() - t0:.1f}s")
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(ora, bench.data, bench.meta, reqs_json, args, n_tri)
+            del ora
 
-    # ---- BASELINE configs #2 - #4, a few steps each (N=1): the other named shapes, same accounting
+    # ---- the other named shapes, a few steps each (N=1), same accounting: the headline index with launches that hold every list several
+    # times (what round 3 reported), BASELINE configs #2 - #4
     if rank == 0 and world == 1 and not dist_on and not args.no_extra and args.workload == "and":
-        extras = {}
 
-        def short(name, b, workload, steps=8, **kw):
+        def short(name, b, workload, steps=8, note=None, **kw):
             try:
                 q, ms, p, tab, fh, _ = b.run(workload, args.batch, steps, 3, **kw)
-                extras[name] = {"value": round(q, 1), "unit": "queries/s", "ms_per_step": round(ms, 3), "p50_latency_ms_single_query": round(p, 3) if p is not None else None,
-                                "workload": f"{b.docs}-doc index, {WORKLOADS[workload]}, batches of {args.batch}", "first_hit_counts": fh,
-                                "dominant_kernel": dominant({k: v for k, v in tab.items() if v["scan"]} or tab), "kernels": tab}
+                legs[name] = leg_summary(q, ms, tab)
+                legs[name]["index"] = f"{b.docs} docs, {len(b.meta.triples)} triples"
+                if p is not None:
+                    legs[name]["p50_ms_single_query"] = round(p, 3)
+                if note:
+                    legs[name]["note"] = note
+                tables[name] = tab
             except Exception as ex:  # noqa: BLE001 — an extra line must never take the headline down
-                extras[name] = {"error": repr(ex)[:300]}
+                legs[name] = {"error": repr(ex)[:300]}
 
-        short("config2_100m_docs", bench, "single")
+        if args.triples * launches_per_step >= args.batch and args.batch // launches_per_step >= 8:  # round 3's headline configuration: every list four times inside a launch (256 triples, launches of 1024)
+            short("headline_4_copies_per_launch", bench, "and", latency=False, tri_limit=max(1, args.batch // launches_per_step // 4), note="every list is read by four queries of a launch (round 3's configuration: 256 triples, launches of 1024): part of its traffic is served from L2 / Infinity Cache")
+        short("config2_100m_docs", bench, "single", latency=False)
         del bench
         import gc
         gc.collect()
-        for name, workload, docs, terms, triples in (("config2_1m_docs", "config2", 1_000_000, 100_000, 1),
-                                                     ("config3_10m_docs", "config3", 10_000_000, 1_000_000, 32),
-                                                     ("config4_10m_docs", "config4", 10_000_000, 1_000_000, 32)):
+        for name, workload, docs, terms, triples, note in (
+                ("config2_1m_docs", "config2", 1_000_000, 100_000, 1, "cache-resident: the whole index is 10 MB; this leg measures the host side of a step, its frac is not an HBM figure"),
+                ("config3_10m_docs", "config3", 10_000_000, 1_000_000, args.batch, None),
+                ("config4_10m_docs", "config4", 10_000_000, 1_000_000, 32, f"{min(args.probes, args.batch)} distinct fuzzy probe terms per batch (what a request reads follows its probe, not the triples)")):
             try:
                 b = Bench(args, workload, docs, terms, triples, 0, 1, local_rank, False)
             except Exception as ex:  # noqa: BLE001
-                extras[name] = {"error": repr(ex)[:300]}
+                legs[name] = {"error": repr(ex)[:300]}
                 continue
-            short(name, b, workload)
+            short(name, b, workload, note=note)
             del b
             gc.collect()
-        out["configs"] = extras
+
+    if rank == 0:
+        # the compact per-workload summary rides inside `config` (a key the driver's record keeps whole) and once more at the very end of the
+        # line (what a tail of the output still shows); the full per-kernel tables sit in between
+        out["config"]["legs"] = legs
+        out["kernels"] = tables.pop("headline")
+        if tables:
+            out["configs_kernels"] = tables
+        out["summary"] = {"value_qps": out["value"], "frac": out["roofline"].get("frac"), "launch_ms": out["roofline"].get("launch_ms"),
+                          "parity_checked": out.get("parity_checked"), "legs": {k: ({"qps": v.get("qps"), "kernel": v.get("kernel"), "frac": v.get("frac")} if "error" not in v else v) for k, v in legs.items()}}
 
     if rank == 0:
         sys.stdout.flush()
@@ -531,6 +565,20 @@ def cpu_baseline(ora, data, meta, reqs_json, args, n_tri):
         secsc, _, _ = ora.bench(sample_reqs, repeat=repc, threads=c)
         sweep[c] = len(sample_reqs) * repc / secsc
     cores = max(sweep, key=sweep.get)
+    # every visible core as a figure of its own (when the host's free memory holds one query's hit lists per thread, ~0.4 GB each)
+    all_cores_qps, all_cores_note = sweep.get(visible), None
+    if all_cores_qps is None:
+        try:
+            with open("/proc/meminfo") as f:
+                avail_gb = next(int(line.split()[1]) for line in f if line.startswith("MemAvailable")) / 1e6
+        except (OSError, StopIteration, ValueError):
+            avail_gb = 0.0
+        if avail_gb > 0.4 * visible + 8:
+            secsv, _, _ = ora.bench(sample_reqs, repeat=max(1, visible // len(sample_reqs)), threads=visible)
+            all_cores_qps = len(sample_reqs) * max(1, visible // len(sample_reqs)) / secsv
+            sweep[visible] = all_cores_qps
+        else:
+            all_cores_note = f"not run: {avail_gb:.0f} GB available for {visible} threads x ~0.4 GB of hit lists"
     per_rep = len(sample_reqs) / sweep[cores]
     repn = max(int(np.ceil(1000 / len(sample_reqs))), int(args.cpu_seconds * 0.6 / max(per_rep, 1e-6)))
     if repn * per_rep > 3 * args.cpu_seconds:  # a slow host: stay bounded, say so in `sample`
@@ -539,6 +587,7 @@ def cpu_baseline(ora, data, meta, reqs_json, args, n_tri):
     qps_n = len(sample_reqs) * repn / secsn
     log(f"cpu baseline: setup {time.time() - t0:.1f}s, 1 thread {len(sample_reqs) * rep1 / secs1:.2f} q/s, {cores} threads {qps_n:.2f} q/s over {len(sample_reqs) * repn} queries")
     return {"value": round(qps_n, 3), "unit": "queries/s", "cores": cores, "cores_visible": visible, "kind": "port", "threads_tried_qps": {str(c): round(v, 2) for c, v in sweep.items()},
+            "all_visible_cores_qps": (round(all_cores_qps, 2) if all_cores_qps is not None else None), **({"all_visible_cores_note": all_cores_note} if all_cores_note else {}),
             "measured_queries": len(sample_reqs) * repn, "p50_ms_all_cores": round(float(np.median(latn)) / 1e6, 3), "p95_ms_all_cores": round(float(np.percentile(latn, 95)) / 1e6, 3),
             "single_thread_qps": round(len(sample_reqs) * rep1 / secs1, 3), "single_thread_p50_ms": round(float(np.median(lat1)) / 1e6, 3),
             "sample": f"C++ restatement of the reference algorithm (oracle/, not the Rust binary); {n_tri} of the {len(meta.triples)} probe triples, "

@@ -352,6 +352,11 @@ const char* vq_profile_json(const vq_index*, int reset);
  * 0xFFFFFFFF when no device is available. */
 uint32_t vq_debug_div100_mismatches(void);
 
+/* The facet selection kernels (k_facet_select / k_facet_select_wide: facet.rs:19-23, count descending; ties by value id ascending) on a
+ * caller's histogram of `num_values` counts, placed `misalign` (0-3) counters behind a 16-byte boundary as inside a batch's histogram area:
+ * writes the best min(top, non-zero counts) entries, returns their number, -1 on failure. */
+int vq_debug_facet_select(const uint32_t* hist, uint32_t num_values, uint32_t top, uint32_t misalign, uint32_t* out_values, uint32_t* out_counts);
+
 const char* vq_version(void);
 
 #ifdef __cplusplus

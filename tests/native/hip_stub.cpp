@@ -100,6 +100,7 @@ static void no_device(const char* what) {
 size_t tile_scan_lds_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool, uint32_t) { return 0; }
 size_t scan_simple_lds_bytes(uint32_t, uint32_t, uint32_t, bool) { return 0; }
 size_t scan_wide_lds_bytes(uint32_t, uint32_t, uint32_t) { return 0; }
+int debug_facet_select(const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*) { return -1; }
 uint32_t debug_div100_mismatches() {
     no_device("debug_div100_mismatches");
     return 0;

@@ -335,6 +335,53 @@ def test_fast_div100_is_exact_for_every_f16():
     assert L.vq_debug_div100_mismatches() == 0
 
 
+@pytest.mark.gpu
+def test_facet_select_kernels_on_crafted_histograms():
+    """k_facet_select / k_facet_select_wide (facet.rs:19-23: count descending; this build orders ties by value id) against numpy on
+    histograms that reach every path: short ones (one-wave kernel), long sparse ones (wide kernel, bound from the thread maxima), long
+    ones whose large counters all fall to ONE thread of the wide kernel (its bound then admits more keys than the LDS buffer holds and has
+    to be raised, more than once), lengths that are no multiple of 4, fewer non-zero counters than `top`, all-zero."""
+    import ctypes as C
+    import veloci_amd
+    import torch
+    torch.cuda.init()
+    L = veloci_amd.lib()
+    rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "11")))
+
+    calls = [0]
+
+    def check(hist, top):
+        hist = np.ascontiguousarray(hist, np.uint32)
+        vals, counts = np.zeros(top, np.uint32), np.zeros(top, np.uint32)
+        calls[0] += 1  # (the histograms of a batch lie back to back: every alignment of the first counter)
+        n = L.vq_debug_facet_select(hist.ctypes.data_as(C.c_void_p), len(hist), top, calls[0] % 4, vals.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p))
+        nz = np.flatnonzero(hist)
+        order = nz[np.lexsort((nz, -hist[nz].astype(np.int64)))][:top]
+        assert n == len(order), (n, len(order), len(hist), top)
+        assert np.array_equal(vals[:n], order.astype(np.uint32)) and np.array_equal(counts[:n], hist[order]), (len(hist), top, vals[:n][:8], order[:8])
+
+    for nv in (1, 7, 1024, 4095, 4096, 4099, 65536, 70001):
+        for top in (1, 10, 64, 65, 300):
+            sparse = np.zeros(nv, np.uint32)
+            k = max(1, nv // 50)
+            sparse[rng.choice(nv, k, replace=False)] = rng.integers(1, 40, k)
+            check(sparse, top)
+            check(rng.integers(0, 5, nv), top)               # many ties
+            check(np.zeros(nv, np.uint32), top)
+            few = np.zeros(nv, np.uint32)
+            few[rng.choice(nv, min(nv, 3), replace=False)] = 9
+            check(few, top)
+    # every large counter in the slots of one thread of the wide kernel (vector v belongs to thread v % 256 of its round of 1024 vectors)
+    nv = 65536
+    for top in (1, 10, 64):
+        h = rng.integers(1, 3, nv).astype(np.uint32)
+        mine = np.flatnonzero((np.arange(nv) // 4) % 256 == 5)
+        h[mine] = rng.permutation(len(mine)).astype(np.uint32) + 1000
+        check(h, top)
+        h2 = np.full(nv, 7, np.uint32)                       # 65 536 equal counters: ties by value id, the bound climbs by value id
+        check(h2, top)
+
+
 # ---------------------------------------------------------------------------------------- fuzzy / prefix (K9)
 @pytest.fixture(scope="module")
 def words():

@@ -227,6 +227,11 @@ const char* vq_last_error(void) { return g_err.c_str(); }
 const char* vq_version(void) { return "veloci_amd 0.2 (gfx950)"; }
 /* self-check (tests): inputs for which the kernels' fast a/100 differs from the correctly rounded division, over all f16 values */
 uint32_t vq_debug_div100_mismatches(void) { return vq::debug_div100_mismatches(); }
+/* self-check (tests): the facet top-`top` kernels on a caller's histogram */
+int vq_debug_facet_select(const uint32_t* hist, uint32_t num_values, uint32_t top, uint32_t misalign, uint32_t* out_values, uint32_t* out_counts) {
+    if (!hist || !out_values || !out_counts) return -1;
+    return vq::debug_facet_select(hist, num_values, top, misalign, out_values, out_counts);
+}
 
 // ------------------------------------------------------------------ index
 vq_index_builder* vq_index_builder_new(uint32_t num_anchors, uint32_t doc_lo, uint32_t doc_hi) {
@@ -1035,6 +1040,18 @@ vq::ShardComm::~ShardComm() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+// The index lets go of its communicator — refused while a step made with it is still alive (the step's destructor and its queued merge
+// refer to it); the sum hook that points into it goes first, so that a failed re-initialisation leaves no hook without a communicator.
+static void comm_release(Index& idx, const char* who) {
+    if (idx.comm && idx.comm->live != 0)
+        throw VelociError(VQ_ERR_INVALID_ARGUMENT, std::string(who) + ": " + std::to_string(idx.comm->live) + " step(s) of this index are still in flight (vq_shard_step_end / vq_shard_step_free them first)");
+    if (idx.allreduce_fn == comm_sum_u64) {
+        idx.allreduce_fn = nullptr;
+        idx.allreduce_ctx = nullptr;
+    }
+    idx.comm.reset();
+}
+
 int vq_comm_unique_id(void* id_out) {
     return guard([&] {
         if (!id_out) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_unique_id: null argument");
@@ -1047,7 +1064,7 @@ int vq_comm_init(vq_index* index, int nranks, int rank, const void* unique_id) {
     return guard([&] {
         if (!index || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_init: bad argument");
         Index& idx = *index->idx;
-        idx.comm.reset();
+        comm_release(idx, "vq_comm_init");
         VQ_HIP(hipSetDevice(idx.device));
         auto c = std::make_unique<ShardComm>();
         c->nranks = nranks;
@@ -1071,19 +1088,14 @@ int vq_comm_init_custom(vq_index* index, int nranks, int rank, vq_allgather_fn a
         c->allgather = allgather;
         c->allreduce_u32 = allreduce_u32;
         c->ctx = ctx;
-        index->idx->comm.reset();
+        comm_release(*index->idx, "vq_comm_init_custom");
         comm_setup(*index->idx, std::move(c));
     });
 }
 int vq_comm_destroy(vq_index* index) {
     return guard([&] {
         if (!index) throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_comm_destroy: null index");
-        Index& idx = *index->idx;
-        if (idx.comm && idx.allreduce_fn == comm_sum_u64) {
-            idx.allreduce_fn = nullptr;
-            idx.allreduce_ctx = nullptr;
-        }
-        idx.comm.reset();
+        comm_release(*index->idx, "vq_comm_destroy");
     });
 }
 

@@ -663,6 +663,7 @@ struct PartialBatch {
     bool launched = false, finished = false;  // scans queued / results taken
     bool merge_launched = false;              // finish_batch phase 1 done (merge + download queued on the finish stream)
     std::chrono::steady_clock::time_point t0;
+    void release_workspace();
     ~PartialBatch();  // a batch given up before its merge waits for its scans: the workspace (pinned staging, blobs) is handed on only when the device is done with it
 };
 

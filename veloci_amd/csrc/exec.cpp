@@ -1836,7 +1836,17 @@ void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Res
 
 PartialBatch::~PartialBatch() {
     if (ws && launched && !finished && ws->ev_done) (void)hipEventSynchronize(ws->ev_done);
-    if (ws && pinned_ws && lock.owns_lock()) ws->pinned.store(false, std::memory_order_release);
+    release_workspace();
+}
+// the workspace goes back: a batch that named it takes its mark off FIRST (a workspace that stayed marked would be skipped by every later
+// batch — and four of those left an index without workspaces)
+void PartialBatch::release_workspace() {
+    if (!lock.owns_lock()) return;
+    if (ws && pinned_ws) {
+        ws->pinned.store(false, std::memory_order_release);
+        pinned_ws = false;
+    }
+    lock.unlock();
 }
 
 namespace {
@@ -2004,7 +2014,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         }
         out[i] = std::move(r);
     }
-    pb.lock.unlock();
+    pb.release_workspace();
     if (timing_enabled()) std::fprintf(stderr, "[vq timing] batch wall %.3f ms, result assembly %.3f ms\n", double(ns) * 1e-6, now_ms() - t_synced);
 }
 

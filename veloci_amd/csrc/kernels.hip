@@ -1160,6 +1160,137 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const uint8_t* __restrict__
     }
 }
 
+// A few entries out of a long histogram (top 10 of 65 536 tag values) is a streaming job: k_facet_select_wide takes those with four
+// waves and 16-byte loads, k_facet_select the rest.
+__device__ __forceinline__ bool facet_job_is_wide(const FacetJob& job) { return job.top >= 1u && job.top <= 64u && job.num_values >= 4096u; }
+
+constexpr uint32_t kFacetWideThreads = 256;
+constexpr uint32_t kFacetWideCap = 1024;  // keys at or above the bound that fit in LDS
+// One workgroup of four waves per job.  Pass 1 streams the counters (16 B per lane and load, eight loads in flight) and keeps every thread's
+// largest key; the k-th largest of the 256 thread maxima is a lower bound of the answer's smallest key (at least k keys reach it).  Pass 2 reads the counters again (from L2 / Infinity Cache) and collects the keys at or above the bound — a
+// handful; should more than kFacetWideCap reach it (one thread held all the large counters), the bound is raised to the k-th largest of those
+// collected and the pass repeats.  The collected keys are ranked by counting (keys are unique: count and value id).
+__global__ __launch_bounds__(kFacetWideThreads) void k_facet_select_wide(const FacetJob* __restrict__ jobs, const uint32_t* __restrict__ hist,
+                                                                         uint32_t* __restrict__ out_vals, uint32_t* __restrict__ out_counts,
+                                                                         uint32_t* __restrict__ out_n) {
+    __shared__ unsigned long long cand[kFacetWideCap];
+    __shared__ unsigned long long wbound[1];
+    __shared__ uint32_t cn;
+    const FacetJob job = jobs[blockIdx.x];
+    if (!facet_job_is_wide(job)) return;  // uniform
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = job.top, nv = job.num_values;
+    const uint32_t* h = hist + job.hist_off;
+    const uint32_t lead = (4u - (job.hist_off & 3u)) & 3u;  // counters in front of the first 16-byte boundary (the batch's histograms lie back to back)
+    const uint32_t nvec = (nv - lead) >> 2, tail0 = lead + (nvec << 2);
+    const VQ_GLOBAL u32x4* h4 = as_global(reinterpret_cast<const u32x4*>(h + lead));
+    auto key_of = [](uint32_t count, uint32_t v) { return ((unsigned long long)count << 32) | (unsigned long long)(0xFFFFFFFFu - v); };  // count desc, value id asc
+    constexpr uint32_t kU = 8;
+    unsigned long long mx = 0ull;
+    for (uint32_t base = 0; base < nvec; base += kU * kFacetWideThreads) {  // uniform
+        u32x4 c[kU];
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) {
+            const uint32_t v = base + j * kFacetWideThreads + tid;
+            c[j] = v < nvec ? h4[v] : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kU; ++j) {
+            const uint32_t v = lead + (base + j * kFacetWideThreads + tid) * 4u;
+            const uint32_t cc[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e)
+                if (cc[e]) {
+                    const unsigned long long key = key_of(cc[e], v + e);
+                    mx = key > mx ? key : mx;
+                }
+        }
+    }
+    for (uint32_t i = tid; i < lead + (nv - tail0); i += kFacetWideThreads) {  // (the counters in front of and behind the 16-byte vectors)
+        const uint32_t v = i < lead ? i : tail0 + (i - lead);
+        if (h[v]) {
+            const unsigned long long key = key_of(h[v], v);
+            mx = key > mx ? key : mx;
+        }
+    }
+    // the k-th largest of the 256 thread maxima (ranked by counting; zero maxima — threads without a non-zero counter — tie and are told apart by thread)
+    cand[tid] = mx;
+    if (tid == 0) wbound[0] = 0ull;
+    __syncthreads();
+    {
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < kFacetWideThreads; ++t) {
+            const unsigned long long o = cand[t];
+            rank += (o > mx || (o == mx && t < tid)) ? 1u : 0u;
+        }
+        if (rank == k - 1u) wbound[0] = mx;
+    }
+    __syncthreads();
+    unsigned long long bound = wbound[0] > 1ull ? wbound[0] : 1ull;  // (zero counts never enter)
+    __syncthreads();
+    while (true) {  // uniform
+        if (tid == 0) cn = 0u;
+        __syncthreads();
+        auto push = [&](uint32_t count, uint32_t v) {
+            if (count) {
+                const unsigned long long key = key_of(count, v);
+                if (key >= bound) {
+                    const uint32_t pos = atomicAdd(&cn, 1u);
+                    if (pos < kFacetWideCap) cand[pos] = key;
+                }
+            }
+        };
+        for (uint32_t base = 0; base < nvec; base += kU * kFacetWideThreads) {  // uniform
+            u32x4 c[kU];
+#pragma unroll
+            for (uint32_t j = 0; j < kU; ++j) {
+                const uint32_t v = base + j * kFacetWideThreads + tid;
+                c[j] = v < nvec ? h4[v] : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kU; ++j) {
+                const uint32_t v = lead + (base + j * kFacetWideThreads + tid) * 4u;
+                if ((unsigned long long)(c[j].x | c[j].y | c[j].z | c[j].w) << 32 >= (bound & 0xFFFFFFFF00000000ull)) {  // (some count of the four may reach the bound's)
+                    push(c[j].x, v);
+                    push(c[j].y, v + 1u);
+                    push(c[j].z, v + 2u);
+                    push(c[j].w, v + 3u);
+                }
+            }
+        }
+        for (uint32_t i = tid; i < lead + (nv - tail0); i += kFacetWideThreads) {
+            const uint32_t v = i < lead ? i : tail0 + (i - lead);
+            push(h[v], v);
+        }
+        __syncthreads();
+        const uint32_t n = cn < kFacetWideCap ? cn : kFacetWideCap;
+        // rank by counting: thread t takes keys t, t + 256, ...; keys are unique
+        const bool fits = cn <= kFacetWideCap;  // uniform
+        for (uint32_t i = tid; i < n; i += kFacetWideThreads) {
+            const unsigned long long key = cand[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) rank += cand[j] > key ? 1u : 0u;
+            if (fits) {
+                if (rank < k) {
+                    out_vals[job.out_off + rank] = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+                    out_counts[job.out_off + rank] = (uint32_t)(key >> 32);
+                }
+            } else if (rank == k - 1u) wbound[0] = key;  // the k-th largest of the keys collected (exactly one thread holds it): 1024 distinct keys reach the old bound, so it lies above it
+        }
+        if (fits) {
+            for (uint32_t i = n + tid; i < k; i += kFacetWideThreads) {
+                out_vals[job.out_off + i] = 0xFFFFFFFFu;
+                out_counts[job.out_off + i] = 0u;
+            }
+            if (tid == 0) out_n[blockIdx.x] = n < k ? n : k;
+            return;
+        }
+        __syncthreads();
+        bound = wbound[0];  // strictly tighter every round: the loop ends
+        __syncthreads();
+    }
+}
+
 // one workgroup per facet entry of the batch
 __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restrict__ jobs, const uint32_t* __restrict__ hist,
                                                          uint32_t* __restrict__ out_vals, uint32_t* __restrict__ out_counts,
@@ -1171,6 +1302,7 @@ __global__ __launch_bounds__(kBlock) void k_facet_select(const FacetJob* __restr
         if (threadIdx.x == 0) out_n[blockIdx.x] = 0u;
         return;
     }
+    if (facet_job_is_wide(job)) return;  // k_facet_select_wide's
     CandState cs{cand, misc + 2, reinterpret_cast<unsigned long long*>(misc), (uint32_t)kCandCap};
     if (threadIdx.x == 0) {
         *cs.thr = 0ull;
@@ -1269,10 +1401,33 @@ void launch_finalize(hipStream_t st, uint32_t nq, const uint8_t* blobs, const ui
     if (!nq) return;
     hipLaunchKernelGGL(k_finalize, dim3(nq), dim3(kBlock), 0, st, blobs, blob_off, gathered, num_shards, shard_stride, lay, res_ids, res_scores, res_n, res_hits);
 }
+// self-check (tests): the top `top` entries of one histogram through the select kernels -> number of entries written
+int debug_facet_select(const uint32_t* hist_host, uint32_t num_values, uint32_t top, uint32_t misalign, uint32_t* out_vals_host, uint32_t* out_counts_host) {
+    if (top == 0 || top > (uint32_t)kMaxTopK || misalign > 3u) return -1;
+    uint32_t *d_hist = nullptr, *d_vals = nullptr, *d_counts = nullptr, *d_n = nullptr;
+    FacetJob* d_job = nullptr;
+    const FacetJob job{misalign, num_values, top, 0u};  // (the histogram starts `misalign` counters behind a 16-byte boundary)
+    uint32_t n = 0;
+    bool ok = hipMalloc(&d_hist, (size_t)num_values * 4 + 32) == hipSuccess && hipMalloc(&d_vals, (size_t)top * 4) == hipSuccess && hipMalloc(&d_counts, (size_t)top * 4) == hipSuccess &&
+              hipMalloc(&d_n, 4) == hipSuccess && hipMalloc(&d_job, sizeof job) == hipSuccess;
+    ok = ok && hipMemcpy(d_hist + misalign, hist_host, (size_t)num_values * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_job, &job, sizeof job, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        launch_facet_select(nullptr, 1, d_job, d_hist, d_vals, d_counts, d_n);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(out_vals_host, d_vals, (size_t)top * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(out_counts_host, d_counts, (size_t)top * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_hist);
+    (void)hipFree(d_vals);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_n);
+    (void)hipFree(d_job);
+    return ok ? (int)n : -1;
+}
 void launch_facet_select(hipStream_t st, uint32_t n_jobs, const FacetJob* jobs, const uint32_t* hist, uint32_t* out_vals, uint32_t* out_counts,
                          uint32_t* out_n) {
     if (!n_jobs) return;
     hipLaunchKernelGGL(k_facet_select, dim3(n_jobs), dim3(kBlock), 0, st, jobs, hist, out_vals, out_counts, out_n);
+    hipLaunchKernelGGL(k_facet_select_wide, dim3(n_jobs), dim3(kFacetWideThreads), 0, st, jobs, hist, out_vals, out_counts, out_n);
 }
 
 }  // namespace vq

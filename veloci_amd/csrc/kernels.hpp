@@ -49,6 +49,7 @@ void launch_scan_leaf_f32(hipStream_t st, uint32_t total_spans, const uint8_t* b
                           uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist);
 size_t scan_simple_lds_bytes(uint32_t cand_cap, uint32_t nv, uint32_t n_scatter, bool facet_cache);
 uint32_t debug_div100_mismatches();
+int debug_facet_select(const uint32_t* hist_host, uint32_t num_values, uint32_t top, uint32_t misalign, uint32_t* out_vals_host, uint32_t* out_counts_host);
 void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base,
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool facet_cache = false);
 size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd);

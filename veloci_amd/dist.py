@@ -171,6 +171,8 @@ class ShardedSearcher:
 
     def _partial(self, requests):
         from .search import PartialBatch
+        if any(g.named for g in self._garbage):  # finished chunks of a one-collective step still hold their workspaces by name: hand them back first
+            self._free_finished()
         pb = PartialBatch(self.index, requests)
         self._free_finished()  # (this batch's scan is queued: the GPU is busy while the host tidies up)
         if self.stream is not None:  # the collective (finish stream) must wait for this batch's scan, not for the next one's
@@ -226,6 +228,8 @@ class ShardedSearcher:
         if any(sb.has_facets for sb in subs):
             return False
         pbs, arena_off = [], 0
+        if any(g.named for g in self._garbage):  # the previous step's chunks hold the very workspaces this step names
+            self._free_finished()
         try:
             for c, sb in enumerate(subs):
                 pb = PartialBatch(self.index, sb, slot=c, arena_offset=arena_off)

@@ -281,6 +281,7 @@ class PartialBatch:
         self.L = _lib.lib()
         self.index = index
         self.arena_offset = arena_offset
+        self.named = arena_offset is not None  # holds a workspace by name until it is closed (nobody else may take that one meanwhile)
         if isinstance(requests, RequestBatch):
             self.reqs, n, arr = requests.reqs, requests.n, requests.arr
         else:

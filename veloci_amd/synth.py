@@ -212,10 +212,12 @@ def generate(spec: SynthSpec, doc_lo=0, doc_hi=None, device=None):
     total = int(offsets[-1])
     anchors = np.zeros(total, np.uint32)
     scores = np.zeros(total, np.uint32)
-    for tid, (docs, sc) in lists.items():
+    for tid in sorted(lists):  # (every list is let go of as soon as it is copied: the generator never holds the postings twice)
+        docs, sc = lists.pop(tid)
         o = int(offsets[tid])
         anchors[o:o + len(docs)] = docs
         scores[o:o + len(docs)] = sc
+        del docs, sc
     data.add_token_to_anchor_score("body.textindex.to_anchor_id_score", offsets, anchors, scores, None)
     meta.local_lens["body.textindex.to_anchor_id_score"] = lens
     if spec.with_t2t:
