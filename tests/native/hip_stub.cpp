@@ -5,6 +5,7 @@
 // AddressSanitizer + UndefinedBehaviorSanitizer.  Never linked into the product library.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -63,6 +64,7 @@ hipError_t hipEventCreate(hipEvent_t* e) {
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { return hipEventCreate(e); }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) {
     std::free(e);
     return hipSuccess;
@@ -87,13 +89,22 @@ hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
     return hipSuccess;
 }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+void vq_stub_fail_launches_after(long k);
 }
 
 namespace vq {
 // VQ_STUB_NOOP_LAUNCH=1 (tools/host_step_profile.py only): launches do nothing instead of throwing, so that the host side of a whole step
 // (compile, pack, launch calls, result assembly — over garbage "results") can be timed on a machine without a GPU
+// vq_stub_fail_launches_after(k) (tests/native/gloo_step_driver.py): the k+1-th launch from now and every later one fail — a device error in the
+// middle of a step, on one rank only; k < 0 switches it off again
+static std::atomic<long> g_fail_after{-1};
+void stub_set_fail_after(long k) { g_fail_after.store(k); }
 static void no_device(const char* what) {
     static const bool noop = std::getenv("VQ_STUB_NOOP_LAUNCH") != nullptr;
+    if (g_fail_after.load() >= 0 && g_fail_after.fetch_sub(1) <= 0) {
+        g_fail_after.store(0);
+        throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("device layer stubbed: injected failure of ") + what);
+    }
     if (noop) return;
     throw vqreq::VelociError(vqreq::ERR_DEVICE, std::string("device layer stubbed: ") + what);
 }
@@ -175,3 +186,5 @@ size_t seg_sort_u64(void*, size_t, const unsigned long long*, unsigned long long
 void launch_b1n_map(hipStream_t, const B1nJob*, uint32_t, const uint32_t*, uint32_t*, float*, B1nResult*) { no_device("k_b1n_map"); }
 void launch_explain(hipStream_t, uint32_t, const ExQuery*, const uint32_t*, const uint32_t*, const ExOp*, const uint16_t*, const ExList*, const DColBoost*, uint32_t*) { no_device("k_explain"); }
 }  // namespace vq
+
+extern "C" void vq_stub_fail_launches_after(long k) { vq::stub_set_fail_after(k); }

@@ -199,3 +199,42 @@ def test_sharded_deep_paging_loop_pages_until_reach_and_applies_skip_and_top():
     assert isinstance(out[len(cases) + 1], VelociError) and out[len(cases) + 1].kind == "Unsupported"
     assert len(out[-1].ids) == 50
     assert rounds and max(rounds) <= len(reqs)  # every round carries only the requests that still page
+
+
+def _run_gloo_step_drivers(scenario):
+    """two processes of tests/native/gloo_step_driver.py over the host-stub build -> their stdout / stderr tails"""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "veloci_amd", "csrc"), "-j6", "hoststub"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    so = os.path.join(ROOT, "veloci_amd", "_host_stub", "libveloci_host_stub.so")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, VQ_LIB=so, VQ_STUB_NOOP_LAUNCH="1", VQ_HOST_THREADS="2", RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "native", "gloo_step_driver.py"), scenario], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank of the in-library step hung")
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+@pytest.mark.parametrize("scenario", ["ok", "fail"])
+def test_in_library_step_with_two_gloo_ranks(scenario):
+    """vq_shard_step_begin / _end driven from TWO processes through vq_comm_init_custom (the exchange: gloo), on the host-stub build of the
+    library — pipelined steps with and without facet histograms issue the same collectives in the same order on both ranks (`ok`); when one
+    rank's step fails between its collectives, BOTH ranks get an error for that step instead of one of them waiting for ever, the communicator
+    is down afterwards on both, and the shard answers alone again once it is destroyed (`fail`).  SURVEY.md 8(e); capi.cpp vq_shard_step_*."""
+    outs = _run_gloo_step_drivers(scenario)
+    for rank, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and "GLOO_STEP_DRIVER_OK" in o, f"rank {rank} rc {rc}\n{o[-1500:]}\n{e[-4000:]}"
+    stats = [json.loads(o.split("GLOO_STEP_DRIVER_OK ", 1)[1]) for _, o, _ in outs]
+    assert stats[0]["steps"] == stats[1]["steps"] >= 5 and stats[1]["collectives"] >= 5
+    assert stats[0]["collectives"] == stats[1]["collectives"] + (1 if scenario == "fail" else 0)  # (rank 0 entered the failed step's exchange, rank 1 never got there)
+    if scenario == "fail":
+        assert "injected failure" in stats[1]["failed_step_error"] and "all-gather failed" in stats[0]["failed_step_error"]

@@ -1,5 +1,6 @@
 // extern "C" boundary (include/veloci_amd.h).  No torch types, no exceptions across the ABI.
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -957,6 +958,8 @@ struct Rccl {
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;                 // optional
+    int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;   // optional
     const char* (*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t (rccl.h)
@@ -974,6 +977,8 @@ static Rccl& rccl_api() {
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
         x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+        x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(sym("ncclCommAbort"));
+        x.CommGetAsyncError = reinterpret_cast<decltype(x.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
         return x;
     }();
@@ -1117,6 +1122,54 @@ struct vq_shard_step {
     }
 };
 namespace {
+// A step failed as a whole on this rank (an exception between its collectives: out of device memory in a pre-pass, a failed launch), or did not
+// complete in time: this rank's exchanges no longer line up with the other ranks'.  The communicator is marked down — every later step on it is
+// refused — and an RCCL communicator is aborted, so that ranks waiting for this one inside a collective see an error instead of waiting for ever.
+void comm_fail(ShardComm& c, const std::string& why) {
+    if (!c.failed.empty()) return;
+    c.failed = why;
+    if (c.nccl) {
+        try {
+            if (rccl_api().CommAbort) (void)rccl_api().CommAbort(static_cast<ncclComm_t>(c.nccl));
+            c.nccl = nullptr;  // (aborted: nothing is left to destroy)
+        } catch (...) {
+        }
+    }
+}
+// Wait for a step's last event, but not for ever: a rank that never joined an exchange (it failed before, or died) must end this rank's step with
+// an error, not hang it.  VQ_STEP_TIMEOUT_MS (default 120 000; 0: no limit).  An error RCCL reports asynchronously (a peer gone) ends the wait at once.
+void bounded_wait(const Index& idx, ShardComm& c, hipEvent_t ev) {
+    static const long limit_ms = [] {
+        const char* e = std::getenv("VQ_STEP_TIMEOUT_MS");
+        return e ? std::atol(e) : 120000L;
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) {
+            comm_fail(c, std::string("the step's stream reported ") + hipGetErrorString(q));
+            throw VelociError(VQ_ERR_DEVICE, "sharded step: " + c.failed);
+        }
+        if (spins < 2000) continue;  // (the usual case: the step is about to finish)
+        if ((spins & 63u) == 0) {
+            if (c.nccl && rccl_api().CommGetAsyncError) {
+                int aerr = 0;
+                if (rccl_api().CommGetAsyncError(static_cast<ncclComm_t>(c.nccl), &aerr) == 0 && aerr != 0) {
+                    comm_fail(c, std::string("RCCL reported ") + (rccl_api().GetErrorString ? rccl_api().GetErrorString(aerr) : "an error") + " while the step was in flight (a rank is gone)");
+                    throw VelociError(VQ_ERR_DEVICE, "sharded step: " + c.failed);
+                }
+            }
+            const long waited = long(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count());
+            if (limit_ms > 0 && waited > limit_ms) {
+                comm_fail(c, "a step did not complete within " + std::to_string(limit_ms) + " ms (VQ_STEP_TIMEOUT_MS): a rank did not join its exchange");
+                throw VelociError(VQ_ERR_DEVICE, "sharded step: " + c.failed);
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    (void)idx;
+}
 // The step's merge and download go onto the finish stream, behind its exchange.  The NEXT step's scans are ordered behind them (ev_fin): a
 // scan launch fills every wave slot of the chip at once, and a merge queued beside it would wait for slots to free up (measured: 0.8-1.5 ms
 // for a kernel that takes 8 us on an idle chip) — the GPU idles for the tens of microseconds of the exchange instead.
@@ -1144,6 +1197,7 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
             comm_setup(const_cast<Index&>(idx), std::move(local));
         }
         ShardComm& c = *idx.comm;
+        if (!c.failed.empty()) throw VelociError(VQ_ERR_DEVICE, "vq_shard_step_begin: the communicator is down (" + c.failed + "): make it again (vq_comm_init / vq_comm_init_custom) on every rank");
         const bool exchange = c.nccl != nullptr || c.allgather != nullptr;
         static const bool timing = std::getenv("VQ_TIMING") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
@@ -1171,6 +1225,8 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
             throw VelociError(VQ_ERR_INVALID_ARGUMENT, "vq_shard_step_begin: both step slots are held (end a step first)");
         }
         c.busy[step->parity] = true;
+        auto tb2 = tb1;
+        try {
         // One launch per step: with two steps in flight the compilation of step i + 1 already overlaps the scans of step i, and one launch of
         // 1024 requests fills the chip more evenly than two of 512 (100 M docs: 7.25 against 7.41 ms per step).  VQ_SHARD_CHUNKS=2 cuts a step in two.
         static const size_t chunks_env = [] {
@@ -1183,7 +1239,7 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
             step->first.push_back(b);
             step->pbs.push_back(run_partial(idx, reqs.data() + b, e - b, step->parity * 2 + int(k)));
         }
-        const auto tb2 = std::chrono::steady_clock::now();
+        tb2 = std::chrono::steady_clock::now();
         // ---- the exchange: behind the step's scans, on the collective stream.  Per chunk the part of its partial in front of the histograms
         // (hit counts, statistics, top-k keys: the same size on every rank) is all-gathered, the histograms are summed in place.
         size_t off = 0;
@@ -1212,6 +1268,12 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
             }
             VQ_HIP(hipEventRecord(c.ev_xchg[step->parity], c.stream));
         }
+        } catch (const std::exception& ex) {
+            // Whatever was thrown from here on ends the step on THIS rank only (requests that fail on their own ride along as statuses and never
+            // throw): with other ranks around, their exchange of this step will miss this rank — the communicator goes down with the step.
+            if (exchange && c.nranks > 1) comm_fail(c, std::string("a step failed on rank ") + std::to_string(c.rank) + ": " + ex.what());
+            throw;
+        }
         c.unmerged = step.get();
         *out = step.release();
         if (timing) {
@@ -1231,7 +1293,9 @@ int vq_shard_step_end(vq_shard_step* step_raw, size_t stride, uint64_t* num_hits
         VQ_HIP(hipSetDevice(idx.device));
         static const bool timing = std::getenv("VQ_TIMING") != nullptr;
         const auto te0 = std::chrono::steady_clock::now();
+        if (!c.failed.empty()) throw VelociError(VQ_ERR_DEVICE, "vq_shard_step_end: the communicator is down (" + c.failed + ")");
         step_queue_merge(*step);
+        bounded_wait(idx, c, c.ev_fin[step->parity]);
         if (timing) {
             VQ_HIP(hipStreamSynchronize(idx.fin_stream));
             std::fprintf(stderr, "[vq timing] shard step end: waited %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count());

@@ -446,6 +446,8 @@ struct ShardComm {
     DevBuf gathered[2];
     DevBuf red;  // scratch of the sums-over-shards hook (u64)
     bool busy[2] = {false, false};  // parity (workspace pair, gather buffer, events) held by a live step
+    std::string failed;  // != "": a step of this communicator failed as a whole on this rank (or did not complete in time): the ranks' exchanges no longer line
+                         // up, every further step is refused until the communicator is made again (vq_comm_init / vq_comm_init_custom)
     std::mutex mu;  // the hook may be called from compile threads of two steps
     ~ShardComm();
 };
