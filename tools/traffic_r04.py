@@ -21,8 +21,9 @@ def mean(name, counter, kernel="k_scan_probe"):
 bench = json.loads(open(f"{d}/bench_fetch.json").read().strip().splitlines()[-1])
 roof, cfg = bench["roofline"], bench["config"]
 k = bench["kernels"][roof["kernel"]]
-fetch, n = mean("fetch", "FETCH_SIZE")
+fetch, n = mean("fetch", "FETCH_SIZE")   # rocprofv3 reports both in KiB
 write, _ = mean("write", "WRITE_SIZE")
+fetch, write = fetch * 1024.0, write * 1024.0
 layout, gathered = k["layout_bytes_per_launch"], k["gathered_bytes_per_launch"]
 streamed = layout - gathered
 traffic = streamed + (fetch - streamed / 2) + write

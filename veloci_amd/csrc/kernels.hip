@@ -2218,8 +2218,11 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
 #ifndef VQ_RICH_WAVES
 #define VQ_RICH_WAVES 4
 #endif
+#ifndef VQ_SIMPLE_WAVES
+#define VQ_SIMPLE_WAVES 5
+#endif
 template <uint32_t NV, bool RICH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RICH ? VQ_RICH_WAVES : 5, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RICH ? VQ_RICH_WAVES : VQ_SIMPLE_WAVES, 8))) void k_scan_simple(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                     const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                     uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
                                                     unsigned long long* __restrict__ num_hits, uint32_t* __restrict__ hist, uint32_t fc_off) {
