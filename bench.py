@@ -337,13 +337,18 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
-    # fewer distinct triples than queries per step: the step is cut into two launches (read once, when the library makes its first step), so that
-    # no launch holds a list twice as long as triples >= batch / 2
+    # Fewer distinct triples than queries per step: the HEADLINE's steps are cut into two launches (VQ_SHARD_CHUNKS, read by the library at every
+    # step), so that no launch holds a list twice as long as triples >= batch / 2 — on shards of 40 M docs and more.  Below that (a rank's share
+    # at N >= 4) a step stays ONE launch: two launches of 512 queries fill the chip worse there (1/8 shard: 1.67 against 1.37 ms per step), and a
+    # list's two readers are 512 queries — more than a gigabyte of other lists — apart, far beyond the 256 MiB the caches hold.
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
     launches_per_step = 1
-    if args.triples < args.batch and args.batch >= 512 and os.environ.get("VQ_BENCH_ONE_LAUNCH") != "1":
-        os.environ.setdefault("VQ_SHARD_CHUNKS", "2")
-    if os.environ.get("VQ_SHARD_CHUNKS") == "2" and args.batch >= 512:
+    explicit_chunks = os.environ.get("VQ_SHARD_CHUNKS")  # (a caller's own setting wins, for every leg)
+    if explicit_chunks:
+        launches_per_step = 2 if explicit_chunks == "2" and args.batch >= 512 else 1
+    elif args.triples < args.batch and args.batch >= 512 and os.environ.get("VQ_BENCH_ONE_LAUNCH") != "1" and args.docs // max(world_env, 1) >= 40_000_000 and args.workload == "and":
         launches_per_step = 2
+    os.environ["VQ_SHARD_CHUNKS"] = str(launches_per_step)
 
     # stdout carries ONE line — the result; whatever a library prints there (RCCL greets on stdout when a communicator is made) goes to stderr
     sys.stdout.flush()
@@ -419,7 +424,9 @@ def main():
     # times (what round 3 reported), BASELINE configs #2 - #4
     if rank == 0 and world == 1 and not dist_on and not args.no_extra and args.workload == "and":
 
-        def short(name, b, workload, steps=8, note=None, **kw):
+        def short(name, b, workload, steps=8, note=None, launches=1, **kw):
+            if not explicit_chunks:
+                os.environ["VQ_SHARD_CHUNKS"] = str(launches)  # (the other legs' queries are distinct inside a launch of the whole step)
             try:
                 q, ms, p, tab, fh, _ = b.run(workload, args.batch, steps, 3, **kw)
                 legs[name] = leg_summary(q, ms, tab)
@@ -433,7 +440,7 @@ def main():
                 legs[name] = {"error": repr(ex)[:300]}
 
         if args.triples * launches_per_step >= args.batch and args.batch // launches_per_step >= 8:  # round 3's headline configuration: every list four times inside a launch (256 triples, launches of 1024)
-            short("headline_4_copies_per_launch", bench, "and", latency=False, tri_limit=max(1, args.batch // launches_per_step // 4), note="every list is read by four queries of a launch (round 3's configuration: 256 triples, launches of 1024): part of its traffic is served from L2 / Infinity Cache")
+            short("headline_4_copies_per_launch", bench, "and", latency=False, launches=launches_per_step, tri_limit=max(1, args.batch // launches_per_step // 4), note="every list is read by four queries of a launch (round 3's configuration: 256 triples, launches of 1024): a quarter of the footprint")
         short("config2_100m_docs", bench, "single", latency=False)
         del bench
         import gc

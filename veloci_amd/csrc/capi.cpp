@@ -1229,7 +1229,8 @@ int vq_shard_step_begin(const vq_index* index, const vq_request* const* requests
         try {
         // One launch per step: with two steps in flight the compilation of step i + 1 already overlaps the scans of step i, and one launch of
         // 1024 requests fills the chip more evenly than two of 512 (100 M docs: 7.25 against 7.41 ms per step).  VQ_SHARD_CHUNKS=2 cuts a step in two.
-        static const size_t chunks_env = [] {
+        // (read at every step: a host program may cut only some of its steps in two — bench.py does for the headline's launches of distinct queries)
+        const size_t chunks_env = [] {
             const char* e = std::getenv("VQ_SHARD_CHUNKS");
             return size_t(e ? std::min(2, std::max(1, std::atoi(e))) : 0);
         }();
