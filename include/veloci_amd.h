@@ -352,6 +352,10 @@ const char* vq_profile_json(const vq_index*, int reset);
  * 0xFFFFFFFF when no device is available. */
 uint32_t vq_debug_div100_mismatches(void);
 
+/* Requests of this index that were run a second time on the exact kernels because the short cut of a speculative one could not be confirmed:
+ * an OR of the shape k_scan_probe_or takes ranks only the docs that hold its rarest term and is confirmed by the k-th key it returns. */
+uint64_t vq_index_speculative_reruns(const vq_index*);
+
 /* The facet selection kernels (k_facet_select / k_facet_select_wide: facet.rs:19-23, count descending; ties by value id ascending) on a
  * caller's histogram of `num_values` counts, placed `misalign` (0-3) counters behind a 16-byte boundary as inside a batch's histogram area:
  * writes the best min(top, non-zero counts) entries, returns their number, -1 on failure. */

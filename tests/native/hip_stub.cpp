@@ -125,7 +125,7 @@ void launch_scan_simple(hipStream_t, bool, uint32_t, uint32_t, const uint8_t*, c
                         uint32_t*, bool) { no_device("k_scan_simple"); }
 void launch_scan_wide(hipStream_t, uint32_t, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*,
                       unsigned long long*) { no_device("k_scan_wide"); }
-void launch_scan_probe(hipStream_t, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*) {
+void launch_scan_probe(hipStream_t, uint32_t, uint32_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, unsigned long long*, unsigned long long*, bool, bool) {
     no_device("k_scan_probe");
 }
 size_t scan_probe_lds_bytes(uint32_t, uint32_t) { return 0; }

@@ -304,12 +304,12 @@ def test_generic_kernel_also_matches_for_simple_queries():
 
 
 @pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
-                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_NO_PROBE": "1"}, {"VQ_PROBE_NO_ARR": "1"}, {"VQ_PROBE_MIN_DOCS": "40000000"},
+                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_NO_PROBE": "1"}, {"VQ_PROBE_NO_ARR": "1"}, {"VQ_PROBE_MIN_DOCS": "40000000"}, {"VQ_NO_PROBE_OR": "1"},
                                  pytest.param({"VQ_RING": "1"}, marks=pytest.mark.skipif(os.environ.get("VQ_TEST_RING") != "1", reason="the persistent ring kernel is opt-in (VQ_RING=1); its parity leg runs with VQ_TEST_RING=1")),
                                  {"VQ_NO_WEIGHTED_SPANS": "1", "VQ_UNION_SPAN": "512", "VQ_BATCH_HALVES": "0", "VQ_FLAT_SMALL_CHUNKS": "1", "VQ_FLAT_CHUNKS": "4"}],
                          ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
                               "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
-                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "ands_on_k_scan_simple", "probe_operands_as_bitmap_words_only", "shipped_routing_of_shards_below_40m_docs", "ands_on_the_persistent_ring_kernel",
+                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "ands_on_k_scan_simple", "probe_operands_as_bitmap_words_only", "shipped_routing_of_shards_below_40m_docs", "ors_on_k_scan_simple", "ands_on_the_persistent_ring_kernel",
                               "spans_chunks_and_host_threads_as_before_the_scheduling_changes"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results.
@@ -997,6 +997,51 @@ def test_and_probe_kernel_shapes(corpus, big_corpus):
         for r, g, w in zip(reqs, _search_batch_over_shards(data, reqs, 2), wants):
             assert not isinstance(g, Exception), (str(g), json.dumps(r))
             assert_same(r, g, w)
+
+
+def test_or_probe_kernel_shapes_and_reruns(corpus, big_corpus):
+    """k_scan_probe_or (ORs of 2-4 leaves with a term slot each, the sparsest operand streamed as the cover, the others read as bitmap words): it
+    counts the union from the words and ranks only the docs that hold the cover; finish_batch confirms the result by its k-th key or runs the
+    request again on the exact kernels (set_op.rs:87-220).  Every operand order, top from 1 to beyond the candidate buffer, skip, deep pages,
+    leaf boosts — among them ones that push the cover's docs BELOW the others' (the short cut must be refused: vq_index_speculative_reruns grows) —,
+    a cover with fewer hits than `top`, single requests and batches, against the oracle."""
+    import itertools
+    import veloci_amd
+    from veloci_amd import synth
+    from parity import assert_same
+    L = veloci_amd.lib()
+    for cp in (corpus, big_corpus):
+        data, meta, idx, ora = cp
+        a, b = list(meta.triples[0]), list(meta.triples[1])
+        leaf = lambda t, boost=None: {"search": dict({"path": "body", "terms": [t]}, **({"boost": boost} if boost is not None else {}))}
+        orq = lambda leaves, **kw: dict({"search_req": {"or": {"queries": leaves}}, "top": 10}, **kw)
+        reqs = [synth.req_or(list(terms)) for terms in itertools.permutations(a)]
+        reqs += [synth.req_or([a[0], a[2]]), synth.req_or([a[2], a[1]], top=1), synth.req_or([a[0], a[1], b[0], a[2]], top=20), synth.req_or([b[2], a[0], b[0], a[1]], top=3),
+                 synth.req_or([a[0], b[1], b[2]], top=100), dict(synth.req_or(a, top=700), skip=300), dict(synth.req_or(a, top=5), skip=2000), synth.req_or(a, top=1500),
+                 dict(synth.req_or([a[1], a[2]], top=10), skip=10**7)]
+        wants = [ora.search_json(json.dumps(r)) for r in reqs]
+        before = int(L.vq_index_speculative_reruns(idx.h))
+        for r, w in zip(reqs[:11], wants[:11]):  # (windows of at most 20 hits: the planted overlap puts them into all the lists — nothing to run again)
+            assert_same(r, veloci_amd.search(r, idx), w)
+        plain_reruns = int(L.vq_index_speculative_reruns(idx.h)) - before
+        for r, w in zip(reqs[11:], wants[11:]):
+            assert_same(r, veloci_amd.search(r, idx), w)
+        for r, g, w in zip(reqs * 3, veloci_amd.search_batch(reqs * 3, idx), wants * 3):
+            assert_same(r, g, w)
+        # the rarest term's postings made worthless / the other terms' boosted: the best hits no longer hold the cover — and a window
+        # (top + skip) that reaches beyond the cover's hits
+        tricky = [orq([leaf(a[0], 5.0), leaf(a[1], 4.0), leaf(a[2], 0.001)]), orq([leaf(a[0]), leaf(a[1]), leaf(a[2], 0.0)]), orq([leaf(a[0], 9.0), leaf(a[2], 0.01)], top=50),
+                  orq([leaf(a[0]), leaf(a[1], -1.0), leaf(a[2])]), orq([leaf(a[0]), leaf(a[1]), leaf(a[2], -2.0)]), dict(synth.req_or(a, top=400), skip=10**5 * (4 if cp is big_corpus else 1) // 10)]
+        before = int(L.vq_index_speculative_reruns(idx.h))
+        twants = [ora.search_json(json.dumps(r)) for r in tricky]
+        for r, g, w in zip(tricky, veloci_amd.search_batch(tricky, idx), twants):
+            assert_same(r, g, w)
+        for r, w in zip(tricky, twants):
+            assert_same(r, veloci_amd.search(r, idx), w)
+        route_on = os.environ.get("VQ_PROBE_MIN_DOCS") == "0" and not any(os.environ.get(k) for k in ("VQ_FORCE_GENERIC", "VQ_NO_PROBE", "VQ_NO_PROBE_OR"))
+        if route_on:  # (the legs of test_alternative_kernel_routes_match run this test on other kernels: nothing is speculative there)
+            assert int(L.vq_index_speculative_reruns(idx.h)) - before >= 4, "requests whose best hits lack the cover must be run again on the exact kernels"
+            assert plain_reruns == 0, plain_reruns  # (the planted overlap puts the best hits into all three lists)
 
 
 def test_full_size_index_matches_the_oracle():

@@ -22,7 +22,7 @@ SYMBOLS = [
     "vq_partial_hist_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
     "vq_search_batch_partial_at", "vq_partial_slots", "vq_index_partial_arena_ptr", "vq_partial_total_bytes", "vq_merge_partials_flat_strided",
     "vq_comm_unique_id", "vq_comm_init", "vq_comm_init_custom", "vq_comm_destroy", "vq_shard_step_begin", "vq_shard_step_end", "vq_shard_step_free", "vq_shard_step_flat",
-    "vq_profile_read", "vq_profile_enable", "vq_profile_json", "vq_debug_div100_mismatches", "vq_debug_facet_select", "vq_version",
+    "vq_profile_read", "vq_profile_enable", "vq_profile_json", "vq_debug_div100_mismatches", "vq_debug_facet_select", "vq_index_speculative_reruns", "vq_version",
 ]
 COMM_ID_BYTES = 128
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -120,6 +120,7 @@ def lib():
         "vq_profile_json": (cp, [vp, i]),
         "vq_debug_div100_mismatches": (u32, []),
         "vq_debug_facet_select": (i, [vp, u32, u32, u32, vp, vp]),
+        "vq_index_speculative_reruns": (u64, [vp]),
         "vq_merge_partials": (i, [vp, vp, vp, u32, C.POINTER(vp), C.POINTER(i)]),
         "vq_merge_partials_flat": (i, [vp, vp, vp, u32, sz, vp, vp, vp, vp, vp]),
         "vq_partial_free": (None, [vp]),

@@ -228,6 +228,8 @@ const char* vq_last_error(void) { return g_err.c_str(); }
 const char* vq_version(void) { return "veloci_amd 0.2 (gfx950)"; }
 /* self-check (tests): inputs for which the kernels' fast a/100 differs from the correctly rounded division, over all f16 values */
 uint32_t vq_debug_div100_mismatches(void) { return vq::debug_div100_mismatches(); }
+/* tests, tools: requests that ran a second time because a speculative route's result could not be confirmed (k_scan_probe_or) */
+uint64_t vq_index_speculative_reruns(const vq_index* index) { return index ? index->idx->or_reruns.load() : 0; }
 /* self-check (tests): the facet top-`top` kernels on a caller's histogram */
 int vq_debug_facet_select(const uint32_t* hist, uint32_t num_values, uint32_t top, uint32_t misalign, uint32_t* out_values, uint32_t* out_counts) {
     if (!hist || !out_values || !out_counts) return -1;

@@ -2109,6 +2109,46 @@ struct Compiler {
                     }
                     probe = probe && covers == 1;
                 }
+                // An OR of leaves with a term slot each whose sparsest operand has a tile-packed image and whose other operands are bitmap words, on an
+                // unsharded index: k_scan_probe_or counts the union from the words' set bits and scores only the docs that hold the cover (the
+                // sparsest operand) — a doc without it scores at most `or_skip_bound`, and finish_batch confirms that the request's k-th best key lies
+                // above that before the result is handed out (otherwise the request runs again with exact_routes_only).  Sharded: a rank's partial
+                // leaves for the exchange before the host sees it, so shards keep k_scan_simple.  VQ_NO_PROBE_OR=1 switches the route off.
+                static const bool no_probe_or = std::getenv("VQ_NO_PROBE_OR") != nullptr;
+                uint32_t or_cover = UINT32_MAX;
+                if (!probe && !no_probe && !no_probe_or && !req.exact_routes_only && cq.simple_n >= 2 && cq.simple_n <= 4 && cq.ops[cq.simple_n].kind == OP_OR &&
+                    cq.ops[cq.simple_n].nslots == cq.simple_n && !idx.sharded() && !(idx.comm && idx.comm->nranks > 1) && uint64_t(idx.doc_hi) - idx.doc_lo >= probe_min_docs) {
+                    for (uint32_t k = 0; k < cq.simple_n; ++k) {
+                        const HList& l = cq.lists[cq.ops[k].list_begin];
+                        if (l.d_cov32 && (or_cover == UINT32_MAX || l.len < cq.lists[cq.ops[or_cover].list_begin].len)) or_cover = k;
+                    }
+                    double sum = 0.0, cnt = 0.0;
+                    for (uint32_t k = 0; k < cq.simple_n && or_cover != UINT32_MAX; ++k) {
+                        if (k == or_cover) continue;
+                        const HList& l = cq.lists[cq.ops[k].list_begin];
+                        if (!(l.flags & LIST_BITMAP) || (l.flags & LIST_F32) || l.max_raw >= 0x7C00 || !(l.term_score >= 0.0f)) {
+                            or_cover = UINT32_MAX;
+                            break;
+                        }
+                        const uint16_t h = l.max_raw;  // finite non-negative f16
+                        const int e = (h >> 10) & 31, m = h & 1023;
+                        const double a = e ? std::ldexp(1.0 + m / 1024.0, e - 15) : std::ldexp(m / 1024.0, -14);
+                        const double v = double(l.term_score) * (a / 100.0);
+                        if (v >= 0.00001 * (1.0 - 1e-5)) cnt += 1.0;  // (set_op.rs:180: a slot counts from 1e-5 on)
+                        sum += v;
+                    }
+                    if (or_cover != UINT32_MAX) {
+                        const HList& c = cq.lists[cq.ops[or_cover].list_begin];
+                        if (!(c.term_score > 0.0f) || c.max_raw >= 0x7C00) or_cover = UINT32_MAX;  // (the kernel's bound is taken over the cover's raw scores)
+                        else {
+                            const double b = sum * cnt * cnt * (1.0 + 1e-5);  // f32 rounding of the kernel's sums stays below the margin
+                            cq.or_skip_bound = b < 3.0e38 ? float(b) : std::numeric_limits<float>::infinity();
+                            if (cq.or_skip_bound < float(b)) cq.or_skip_bound = std::nextafter(cq.or_skip_bound, std::numeric_limits<float>::infinity());
+                            probe = true;
+                        }
+                    }
+                }
+                const bool or_probe = or_cover != UINT32_MAX && probe;
                 bool seq = false;
                 for (uint32_t k = 0; k < cq.simple_n && !probe; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
@@ -2116,7 +2156,7 @@ struct Compiler {
                 }
                 if (seq) f |= 1u << 16;
                 if (probe) {
-                    f |= 1u << 25 | arr_mask << 12;
+                    f |= 1u << 25 | arr_mask << 12 | (or_probe ? 1u << 27 : 0u);
                     cq.probe = DProbe{};
                     for (uint32_t k = 0; k < cq.simple_n; ++k) {
                         const HList& l = cq.lists[cq.ops[k].list_begin];
@@ -2128,10 +2168,10 @@ struct Compiler {
                 // Measured on launches that read no list twice (256 distinct queries per launch, 100 M docs): 1.95 ms against k_scan_probe's 1.94 —
                 // the stream side reaches 5.9 TB/s alone, the consumer waves do not keep up: opt-in, VQ_RING=1
                 static const bool ring = std::getenv("VQ_RING") != nullptr && std::atoi(std::getenv("VQ_RING")) != 0;
-                if (probe && ring && !arr_mask && cq.top_k >= 1 && cq.top_k <= kPoolMaxK) f |= 1u << 26;
+                if (probe && ring && !arr_mask && !or_probe && cq.top_k >= 1 && cq.top_k <= kPoolMaxK) f |= 1u << 26;
                 for (uint32_t k = 0; k < cq.simple_n; ++k) {
                     const HList& l = cq.lists[cq.ops[k].list_begin];
-                    const bool cover = l.flags & LIST_COVER;
+                    const bool cover = or_probe ? k == or_cover : (l.flags & LIST_COVER) != 0;
                     if (cover) f |= 1u << (8 + k);
                     if ((l.flags & LIST_BITMAP) && (seq || !cover) && !((arr_mask >> k) & 1u)) f |= 1u << k;
                     if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);

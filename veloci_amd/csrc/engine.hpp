@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <chrono>
 #include <cstdint>
 #include <map>
@@ -463,6 +464,7 @@ struct Index {
         if (!sharded() || v.empty()) return;
         if (!allreduce_fn || allreduce_fn(allreduce_ctx, v.data(), v.size()) != 0) throw vqreq::VelociError(vqreq::ERR_DEVICE, "all-reduce over the shards failed");
     }
+    mutable std::atomic<uint64_t> or_reruns{0};  // requests that ran a second time because k_scan_probe_or's short cut could not be confirmed (tests, tools)
     mutable std::unique_ptr<HostPool> pool;  // created on first use
     mutable std::mutex pool_mu;
     uint32_t num_anchors = 0, doc_lo = 0, doc_hi = 0;
@@ -599,6 +601,10 @@ struct CompiledQuery {
     uint64_t algorithmic_bytes = 0;
     uint64_t layout_bytes = 0;   // static part of KernelProfile::layout_bytes for this query (set when the kernel route is known)
     uint64_t key_upper = ~0ull;  // QHeader::key_upper
+    // k_scan_probe_or (simple_flags bit 27) scores only the docs that hold the cover; a doc without it scores at most this (the OR formula on the
+    // other operands' list maxima).  The finished request is exact if its k-th best key lies above: finish_batch checks and otherwise asks for a
+    // second run without the short cut (Result::rerun_exact).  NaN: not such a query.
+    float or_skip_bound = std::numeric_limits<float>::quiet_NaN();
     bool deep = false;           // top + skip > kMaxTopK: this compilation ranks the first kMaxTopK only; the caller pages on (search_pages)
     uint32_t tile_words = 0, n_spans = 1, stack_depth = 1;
     uint32_t max_spans = 1;  // tiles of the query's doc range (<= 4096): a small batch splits its queries further, up to this (exec.cpp)
@@ -638,6 +644,7 @@ struct Result {
     bool has_explain = false;
     std::vector<std::pair<bool, ExplainRecs>> explain;  // per returned hit: (the reference's map has an entry for the hit, its records) — search.rs:86,96
     bool deep = false;  // holds the first page of a deep request (see CompiledQuery::deep)
+    bool rerun_exact = false;  // k_scan_probe_or's short cut could not be confirmed (CompiledQuery::or_skip_bound): finish_batch runs the request again
     mutable std::string json;
 };
 
@@ -666,6 +673,7 @@ struct PartialBatch {
     bool merge_launched = false;              // finish_batch phase 1 done (merge + download queued on the finish stream)
     std::chrono::steady_clock::time_point t0;
     void release_workspace();
+    std::vector<const vqreq::Request*> reqs;  // the batch's requests as handed in (alive until the batch is finished: a request may have to run again)
     ~PartialBatch();  // a batch given up before its merge waits for its scans: the workspace (pinned staging, blobs) is handed on only when the device is done with it
 };
 

@@ -40,7 +40,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 const char* const kKernelNames[K_COUNT_] = {"k_dict_scan", "k_union<count>", "k_union<write>", "k_range_hits", "k_tile_scan<count pre-pass>", "k_scan_leaf_f32",
-                                            "k_scan_simple<2,rich>", "k_scan_ring (AND)", "k_scan_probe (AND)", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
+                                            "k_scan_simple<2,rich>", "k_scan_ring (AND)", "k_scan_probe (AND / OR)", "k_scan_simple<2> (AND)", "k_scan_simple<2>", "k_scan_union", "k_scan_wide", "k_tile_scan",
                                             "k_merge_spans", "k_finalize", "k_facet_select", "k_locality", "k_boost1n"};
 
 LaunchTimer::LaunchTimer(bool on, Workspace& w, hipStream_t s, int kernel, uint64_t layout_bytes, uint64_t algorithmic_bytes, uint64_t queries) {
@@ -886,6 +886,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     const double t_start = now_ms();
     auto pb = std::make_unique<PartialBatch>();
     pb->index = &idx;
+    pb->reqs.assign(reqs, reqs + n);
     pb->t0 = std::chrono::steady_clock::now();
     if (slot < 0) {
         // any workspace: the first free one from the round-robin position on, never one that a batch holds by name (the chunks of a sharded step
@@ -1228,6 +1229,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     uint32_t n_leaf = 0, spans_leaf = 0;
     uint32_t n_xwide = 0, spans_xwide = 0, leaves_xwide = 0, scatter_xwide = 0;
     uint32_t n_probe = 0, spans_probe = 0, nd_probe = 1;
+    bool probe_any_and = false, probe_any_or = false;
     uint32_t n_ring = 0, items_ring = 0, nd_ring = 1, ring_spans_each = 0;
     uint64_t cls_layout[K_COUNT_] = {}, cls_algo[K_COUNT_] = {}, cls_q[K_COUNT_] = {};
     {
@@ -1315,6 +1317,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
                 items_ring += cq.n_spans;
             } else if ((cq.simple_flags >> 25) & 1u) {
                 kclass = K_SCAN_PROBE;
+                ((cq.simple_flags >> 27) & 1u ? probe_any_or : probe_any_and) = true;
                 nd_probe = std::max<uint32_t>(nd_probe, cq.simple_n - 1);
                 sp[n_probe] = accp;
                 mp[n_probe++] = qi;
@@ -1446,7 +1449,7 @@ std::unique_ptr<PartialBatch> run_partial(const Index& idx, const vqreq::Request
     VQ_HIP(hipGetLastError());
     if (spans_probe) {
         LaunchTimer t(prof, ws, st, K_SCAN_PROBE, cls_layout[K_SCAN_PROBE], cls_algo[K_SCAN_PROBE], cls_q[K_SCAN_PROBE]);
-        launch_scan_probe(st, nd_probe, spans_probe, pb->d_blobs, pb->d_blob_off, tab(up_span_p), tab(up_qmap_p), n_probe, cand_cap, keys_ptr, hits_ptr);
+        launch_scan_probe(st, nd_probe, spans_probe, pb->d_blobs, pb->d_blob_off, tab(up_span_p), tab(up_qmap_p), n_probe, cand_cap, keys_ptr, hits_ptr, probe_any_and, probe_any_or);
     }
     VQ_HIP(hipGetLastError());
     if (spans_wide) {
@@ -1975,6 +1978,12 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         r->ids.assign(ids + from, ids + to);
         r->scores.assign(scores + from, scores + to);
         r->deep = cq.deep;
+        if (!std::isnan(cq.or_skip_bound)) {
+            // k_scan_probe_or ranked only the docs that hold the OR's cover operand.  Nothing was missed if every hit holds it, or if the last key of
+            // the ranked window lies above what a doc WITHOUT the cover can score at best
+            const bool confirmed = r->num_hits == have || (have == cq.top_k && cq.top_k > 0 && scores[cq.top_k - 1] > cq.or_skip_bound);
+            r->rerun_exact = !confirmed;
+        }
         key_off += cq.top_k;
         if (!cq.facet_out.empty()) r->has_facets = true;
         r->why_found_terms = cq.why_found_terms;
@@ -2015,6 +2024,35 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         out[i] = std::move(r);
     }
     pb.release_workspace();
+    {  // requests whose speculative route could not be confirmed run again, as a batch of their own, on the exact routes (rare: an OR whose best
+       // hits lack its rarest term, or fewer such hits than the request asks for)
+        std::vector<size_t> redo;
+        for (size_t i = 0; i < n; ++i)
+            if (out[i] && out[i]->rerun_exact) redo.push_back(i);
+        if (!redo.empty()) {
+            std::vector<vqreq::Request> again;
+            again.reserve(redo.size());
+            for (size_t i : redo) {
+                again.push_back(*pb.reqs[i]);
+                again.back().exact_routes_only = true;
+            }
+            std::vector<const vqreq::Request*> arr;
+            for (auto& a : again) arr.push_back(&a);
+            std::vector<std::unique_ptr<Result>> r2;
+            std::vector<int> st2;
+            std::vector<std::string> er2;
+            {
+                auto pb2 = run_partial(idx, arr.data(), arr.size());
+                finish_batch(idx, *pb2, nullptr, 1, r2, st2, er2, 0);
+            }
+            for (size_t k = 0; k < redo.size(); ++k) {
+                out[redo[k]] = std::move(r2[k]);
+                status[redo[k]] = st2[k];
+                errors[redo[k]] = er2[k];
+            }
+            idx.or_reruns.fetch_add(redo.size(), std::memory_order_relaxed);
+        }
+    }
     if (timing_enabled()) std::fprintf(stderr, "[vq timing] batch wall %.3f ms, result assembly %.3f ms\n", double(ns) * 1e-6, now_ms() - t_synced);
 }
 

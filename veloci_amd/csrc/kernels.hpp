@@ -54,7 +54,7 @@ void launch_scan_simple(hipStream_t st, bool wide, uint32_t n_scatter, uint32_t 
                         const uint32_t* qmap, uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, uint32_t* hist, bool facet_cache = false);
 size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd);
 void launch_scan_probe(hipStream_t st, uint32_t max_nd, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
-                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits);
+                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, bool any_and = true, bool any_or = false);
 // k_scan_ring (scan_ring.hip): persistent loader / consumer form of k_scan_probe.  `work`: two zeroed u32 (item counter, error word)
 uint32_t scan_ring_consumers(uint32_t max_nd);
 uint32_t scan_ring_slots(uint32_t maxnd, uint32_t consumers);

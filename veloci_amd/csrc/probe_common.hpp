@@ -56,10 +56,34 @@ __device__ __forceinline__ float probe_sum(const ProbeShape<ND>& S, float vc, co
     return score;
 }
 
+// The OR's score (set_op.rs:169-186) of a doc that holds the cover and the operands in `mask` (bit i: operand i), every leaf a term slot of
+// its own, slots in leaf order: per slot the largest value of its present leaves — at least 0 —, a slot counts when that is >= 1e-5, and the
+// sum over the slots is multiplied by their number twice.
+template <uint32_t ND>
+__device__ __forceinline__ float probe_or_sum(const ProbeShape<ND>& S, float vc, const float (&vd)[ND], uint32_t mask) {
+    float sum = 0.0f, nd = 0.0f;
+#pragma unroll
+    for (uint32_t j = 0; j <= ND; ++j) {
+        float v = vc;
+        bool present = true;
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i)
+            if (S.src[j] == 1u + i) {
+                v = vd[i];
+                present = ((mask >> i) & 1u) != 0u;
+            }
+        const float m = present ? fmaxf(0.0f, v) : 0.0f;
+        if (m >= 0.00001f) nd += 1.0f;
+        sum += m;
+    }
+    return sum * nd * nd;
+}
+
 // Smallest raw f16 score of a cover posting whose hit can still reach the threshold score `thr_f` (wave-wide 64-ary search over the
 // finite non-negative f16 patterns; the bound is monotone in raw).  0: everything stays live.
+// or_mask != ~0: the OR's bound of a doc that holds the cover and exactly the operands of that mask
 template <uint32_t ND>
-__device__ __forceinline__ uint32_t probe_raw_min(const uint32_t* sh, float thr_f, const uint32_t lane) {
+__device__ __forceinline__ uint32_t probe_raw_min(const uint32_t* sh, float thr_f, const uint32_t lane, const uint32_t or_mask = 0xFFFFFFFFu) {
     const ProbeShape<ND> S = probe_shape<ND>(sh);
     if (!S.prunable) return 0u;
     uint32_t lo = 0u, hi = 0x7C00u;
@@ -67,7 +91,10 @@ __device__ __forceinline__ uint32_t probe_raw_min(const uint32_t* sh, float thr_
         const uint32_t step = (hi - lo + 63u) >> 6;
         const uint32_t p = lo + lane * step;
         bool dead = false;
-        if (p < hi) dead = probe_sum<ND>(S, posting_value_fast(S.cts, (uint16_t)p), S.vmax) < thr_f;  // (p is a finite f16: the short division is exact, tests check all 2^16)  NaN threshold (none yet): never dead
+        if (p < hi) {
+            const float vc = posting_value_fast(S.cts, (uint16_t)p);
+            dead = (or_mask == 0xFFFFFFFFu ? probe_sum<ND>(S, vc, S.vmax) : probe_or_sum<ND>(S, vc, S.vmax, or_mask)) < thr_f;
+        }  // (p is a finite f16: the short division is exact, tests check all 2^16)  NaN threshold (none yet): never dead
         const uint32_t c = (uint32_t)__popcll(wballot(dead));
         if (c == 0u) hi = lo;
         else {

@@ -100,6 +100,7 @@ struct Request {  // src/search/request/mod.rs:15-87
     // internal, never parsed: only hits ranking BELOW this key are returned (~0: no bound) — page p of a deep request (top + skip beyond
     // what one scan ranks) asks for what lies below the last key of page p-1
     uint64_t key_upper = ~0ull;
+    bool exact_routes_only = false;  // (internal) second run of a request whose speculative route could not be confirmed: no k_scan_probe_or
 };
 
 

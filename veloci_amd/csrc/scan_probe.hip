@@ -83,7 +83,8 @@ __host__ __device__ constexpr uint32_t probe_lds_tile(uint32_t nd) { return kPLd
 __host__ __device__ constexpr uint32_t probe_lds_cand(uint32_t nd) { return probe_lds_tile(nd) + nd * (kPTW + kPRk); }
 size_t scan_probe_lds_bytes(uint32_t cand_cap, uint32_t nd) { return (size_t)(probe_lds_cand(nd) + 2 * cand_cap) * 4 + 16; }
 
-template <uint32_t ND, uint32_t NA>  // ND operands beside the cover, the last NA of them (roles NB .. ND-1) probed as 16-bit arrays
+// OR: the root is an OR of leaves with a term slot each (set_op.rs:87-220) — see the kernel's comment
+template <uint32_t ND, uint32_t NA, bool OR = false>  // ND operands beside the cover, the last NA of them (roles NB .. ND-1) probed as 16-bit arrays
 __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, const uint32_t span, const uint32_t q, const uint32_t cand_cap,
                                            unsigned long long* __restrict__ span_keys, unsigned long long* __restrict__ num_hits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -166,7 +167,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         const KOp root(gops + n);
 #pragma unroll
         for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t k = root.and_order(j);
+            const uint32_t k = OR ? j : root.and_order(j);  // (an OR's leaves arrive in slot order: compile.cpp sorts them)
             if (lane == 0) sh[kShSrc + j] = k == 0u ? role_of[0] : k == 1u ? role_of[1] : k == 2u ? role_of[2] : role_of[3];
         }
     }
@@ -185,12 +186,23 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     }
     __syncthreads();
     unsigned long long thr_seen = *thr;
-    uint32_t raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(thr_seen >> 32))), lane);
+    // the smallest raw cover score that can still reach the threshold: one for an AND, one per set of present operands for an OR
+    uint32_t raw_min = 0u;
+    constexpr uint32_t kMasks = OR ? (1u << ND) : 1u;
+    uint32_t rmin[kMasks];
+    auto take_raw_min = [&](const float thr_f) {
+        if (OR) {
+#pragma unroll
+            for (uint32_t m = 0; m < kMasks; ++m) rmin[m] = probe_raw_min<ND>(sh, thr_f, lane, m);
+        } else raw_min = probe_raw_min<ND>(sh, thr_f, lane);
+    };
+    take_raw_min(__uint_as_float(unorder_f32((uint32_t)(thr_seen >> 32))));
 
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const VQ_GLOBAL u32x4* cc4 = as_global(reinterpret_cast<const u32x4*>(ccov));
 
     uint32_t un = 0, rn = 0;
+    uint32_t ucnt = 0;  // OR: this lane's share of the set bits of the operands' ORed words
     unsigned long long hits = 0;
     unsigned long long g_prev = 0ull;
 
@@ -220,7 +232,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         pf_rounds = (g1 - g0 + 31u) >> 5;  // rounds of 256 postings
         pf_v0 = g0 * 2u;
         pf_v1 = g1 * 2u;
-        if (pf_rounds) {  // uniform: a tile without cover postings has no hits — nothing of it is read
+        if (OR || pf_rounds) {  // uniform: (AND) a tile without cover postings has no hits — nothing of it is read
 #pragma unroll
             for (uint32_t i = 0; i < NB; ++i) {
                 const VQ_GLOBAL u32x4* gb = as_global(reinterpret_cast<const u32x4*>(d_bitmap[i] + (size_t)tt * kPTW));
@@ -284,13 +296,15 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 probe_pool_merge<true>(cs, top_k, pool, lane);
             }
             const unsigned long long tn = *thr;
-            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))), lane);
+            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) take_raw_min(__uint_as_float(unorder_f32((uint32_t)(tn >> 32))));
             thr_seen = tn;
         }
     };
     // the last stage of a flush: the scores are final, the keys go to the candidate buffer
+    uint32_t f_mask = 0;  // OR: the operands that hold the doc (an absent one has no index: all ones in the ranked queue)
+    auto sum_of = [&](const ProbeShape<ND>& S, const float vc, const float (&vd)[ND], const uint32_t mask) { return OR ? probe_or_sum<ND>(S, vc, vd, mask) : probe_sum<ND>(S, vc, vd); };
     auto flush_final = [&](const ProbeShape<ND>& S, const bool final) {
-        const float score = probe_sum<ND>(S, f_vc, f_vd);
+        const float score = sum_of(S, f_vc, f_vd, f_mask);
         const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)f_doc;
         f_stage = 0;
         PS_COUNT(12)
@@ -313,10 +327,10 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                     f_vd[i] = posting_value(S.ts[i], f_r);
                     if (i + 1u < ND) {  // hits that can no longer reach the threshold drop out, the next operand's gather goes out
                         constexpr uint32_t zero = 0;
-                        f_alive = f_alive && !(probe_sum<ND>(S, f_vc, f_vd) < thr_f);
+                        f_alive = f_alive && !(sum_of(S, f_vc, f_vd, f_mask) < thr_f);
                         if (stat && lane == 0) *stat += 2u * (uint32_t)__popcll(wballot(f_alive));
                         gp = sptr[i + 1u < ND ? i + 1u : zero];
-                        gidx = f_alive ? f_idx[i + 1u < ND ? i + 1u : zero] : 0u;
+                        gidx = (f_alive && (!OR || ((f_mask >> (i + 1u < ND ? i + 1u : zero)) & 1u))) ? f_idx[i + 1u < ND ? i + 1u : zero] : 0u;
                         last = false;
                     }
                 }
@@ -334,11 +348,16 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
 #pragma unroll
                 for (uint32_t i = 0; i < ND; ++i) f_idx[i] = rq[(2u + i) * kPR + slot];
             }
+            if (OR) {
+                f_mask = 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < ND; ++i) f_mask |= f_idx[i] != 0xFFFFFFFFu ? 1u << i : 0u;
+            }
             f_vc = posting_value(__uint_as_float(sh[kShCts]), (uint16_t)raw);
 #pragma unroll
             for (uint32_t i = 0; i < ND; ++i) f_vd[i] = __uint_as_float(sh[kShVmax + i]);
             if (stat && lane == 0) *stat += 2u * count;  // gathered bytes of the span
-            gidx = f_alive ? f_idx[0] : 0u;
+            gidx = (f_alive && (!OR || (f_mask & 1u))) ? f_idx[0] : 0u;
             f_stage = 1u;
             rhead = (rhead + count) & (kPR - 1u);
             rn -= count;
@@ -355,13 +374,16 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         const uint32_t doc = rq[slot];
         const float vc = posting_value(S.cts, (uint16_t)rq[kPR + slot]);
         float vd[ND];
+        uint32_t mask = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
             const uint16_t* sp = reinterpret_cast<const uint16_t*>((uintptr_t) reinterpret_cast<const unsigned long long*>(sh + kShScores)[i]);
-            vd[i] = posting_value(S.ts[i], as_global(sp)[rq[(2u + i) * kPR + slot]]);
+            const uint32_t ix = rq[(2u + i) * kPR + slot];
+            if (ix != 0xFFFFFFFFu) mask |= 1u << i;
+            vd[i] = posting_value(S.ts[i], as_global(sp)[(OR && ix == 0xFFFFFFFFu) ? 0u : ix]);
         }
         if (stat && lane == 0) *stat += 2u * ND * 64u;
-        const float score = probe_sum<ND>(S, vc, vd);
+        const float score = sum_of(S, vc, vd, mask);
         const unsigned long long key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
         rhead = (rhead + 64u) & (kPR - 1u);
         rn -= 64u;
@@ -403,7 +425,8 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                     rq[slot] = tile_lo + rel;
                     rq[kPR + slot] = e & 0xFFFFu;
                 }
-                rq[(2u + role) * kPR + slot] = bitmap_rank(role, rel);
+                const bool here = !OR || ((tile[role * kPTW + (rel >> 5)] >> (rel & 31u)) & 1u) != 0u;  // (an OR's doc need not be in every operand)
+                rq[(2u + role) * kPR + slot] = here ? bitmap_rank(role, rel) : 0xFFFFFFFFu;
             }
             rn += cnt;
         } else if (NA == 0u) {
@@ -414,7 +437,10 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
                 rq[slot] = tile_lo + rel;
                 rq[kPR + slot] = e & 0xFFFFu;
 #pragma unroll
-                for (uint32_t i = 0; i < NB; ++i) rq[(2u + i) * kPR + slot] = bitmap_rank(i, rel);
+                for (uint32_t i = 0; i < NB; ++i) {
+                    const bool here = !OR || ((tile[i * kPTW + (rel >> 5)] >> (rel & 31u)) & 1u) != 0u;
+                    rq[(2u + i) * kPR + slot] = here ? bitmap_rank(i, rel) : 0xFFFFFFFFu;
+                }
             }
             rn += cnt;
         } else {
@@ -455,19 +481,24 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
     // one round of 256 cover postings (lane l: four consecutive ones) against the tile in LDS
     uint32_t lo_rel = 0, width = 0;
     struct ProbeWords {
-        uint32_t w[4];
+        uint32_t w[OR ? ND : 1u][4];  // AND: the operands' words ANDed; OR: every operand's word
     };
-    auto probe_read = [&](const u32x4 e4) {  // the bitmap operands' words at the four postings of a lane (AND of the operands)
+    auto probe_read = [&](const u32x4 e4) {  // the bitmap operands' words at the four postings of a lane
         const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
         ProbeWords pw;
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) {
-            pw.w[c] = 0xFFFFFFFFu;
-            if (NB) {
-                const uint32_t a = (ee[c] >> 21) & (kPTW - 1u);
-                pw.w[c] = tile[a];
+            const uint32_t a = (ee[c] >> 21) & (kPTW - 1u);
+            if (OR) {
 #pragma unroll
-                for (uint32_t i = 1; i < NB; ++i) pw.w[c] &= tile[i * kPTW + a];
+                for (uint32_t i = 0; i < ND; ++i) pw.w[OR ? i : 0u][c] = tile[i * kPTW + a];
+            } else {
+                pw.w[0][c] = 0xFFFFFFFFu;
+                if (NB) {
+                    pw.w[0][c] = tile[a];
+#pragma unroll
+                    for (uint32_t i = 1; i < NB; ++i) pw.w[0][c] &= tile[i * kPTW + a];
+                }
             }
         }
         return pw;
@@ -480,7 +511,20 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         for (uint32_t c = 0; c < 4; ++c) {
             const uint32_t rel = ee[c] >> 16;
             const bool in = (rel - lo_rel) < width;  // (the span's first and last tile are cut; a pad's offset 65535 is outside every tile)
-            const bool bit = ((pw.w[c] >> (rel & 31u)) & 1u) != 0u;
+            if (OR) {
+                // the operands that hold the doc decide its bound; a cover posting in none of them is a hit the words' popcount has not seen
+                uint32_t mask = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < ND; ++i) mask |= ((pw.w[OR ? i : 0u][c] >> (rel & 31u)) & 1u) << i;
+                uint32_t need = rmin[0];
+#pragma unroll
+                for (uint32_t m = 1; m < kMasks; ++m) need = mask == m ? rmin[OR ? m : 0u] : need;
+                hits += (unsigned long long)__popcll(wballot(in && mask == 0u));
+                live[c] = in && (ee[c] & 0xFFFFu) >= need;
+                lm[c] = wballot(live[c]);
+                continue;
+            }
+            const bool bit = ((pw.w[0][c] >> (rel & 31u)) & 1u) != 0u;
             // (ballots of the plain compares, joined as masks: a ballot of a joined bool costs two more vector instructions)
             const unsigned long long sm = NB ? (wballot(in) & wballot(bit)) : wballot(in);
             if (NA == 0u) {
@@ -523,7 +567,16 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_setprio(3);  // a wave whose data has landed goes first until its next loads are out (nothing it does in between should queue behind other waves' arithmetic)
         const uint32_t rounds = pf_rounds, v0 = pf_v0, v1 = pf_v1;
-        if (rounds) {  // uniform
+        if (OR || rounds) {  // uniform
+            if (OR) {  // every doc of an operand is a hit: the set bits of the operands' words, ORed (the cover's postings outside them are counted as they pass)
+#pragma unroll
+                for (uint32_t h = 0; h < kPNV; ++h) {
+                    u32x4 u = wk[0][h];
+#pragma unroll
+                    for (uint32_t i = 1; i < NB; ++i) u |= wk[i][h];
+                    ucnt += (uint32_t)__popc(u.x) + (uint32_t)__popc(u.y) + (uint32_t)__popc(u.z) + (uint32_t)__popc(u.w);
+                }
+            }
 #pragma unroll
             for (uint32_t i = 0; i < NB; ++i) {
 #pragma unroll
@@ -582,7 +635,7 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         probe_lds_fence();
         {
             const unsigned long long tn = *thr;
-            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) raw_min = probe_raw_min<ND>(sh, __uint_as_float(unorder_f32((uint32_t)(tn >> 32))), lane);  // uniform
+            if ((uint32_t)(tn >> 32) != (uint32_t)(thr_seen >> 32)) take_raw_min(__uint_as_float(unorder_f32((uint32_t)(tn >> 32))));  // uniform
             thr_seen = tn;
             ++tiles_since_merge;
         }
@@ -638,31 +691,39 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
         unsigned long long* out = span_keys + (size_t)keys_base + (size_t)span * top_k;
         for (uint32_t i = lane; i < top_k; i += 64u) out[i] = i < cn ? cand[i] : 0ull;
     }
+    if (OR) {
+        uint32_t total;
+        (void)wave_excl_scan_u32(ucnt, &total);
+        hits += (unsigned long long)total;
+    }
     if (lane == 0 && hits) atomicAdd(&num_hits[q], hits);
     if (lane == 0 && H->stat_off && lds[4]) atomicAdd(&num_hits[H->stat_off], (unsigned long long)lds[4]);
     PS_AT(6)
     PS_FLUSH
 }
 
+// which (query, span) a workgroup of the launch runs
+__device__ __forceinline__ void probe_item(const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq, uint32_t* q, uint32_t* span) {
+    uint32_t lo = 0, hi = nq;
+    const uint32_t wg = blockIdx.x;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (span_base[mid] <= wg) lo = mid;
+        else hi = mid;
+    }
+    *span = blockIdx.x - span_base[lo];
+    *q = qmap[lo];
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_scan_probe(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
                                                                                                const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
                                                                                                uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
                                                                                                unsigned long long* __restrict__ num_hits) {
-    uint32_t ql;
-    {
-        uint32_t lo = 0, hi = nq;
-        const uint32_t wg = blockIdx.x;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (span_base[mid] <= wg) lo = mid;
-            else hi = mid;
-        }
-        ql = lo;
-    }
-    const uint32_t span = blockIdx.x - span_base[ql];
-    const uint32_t q = qmap[ql];
+    uint32_t q, span;
+    probe_item(span_base, qmap, nq, &q, &span);
     const uint8_t* blob = blobs + blob_off[q];
     const uint32_t n = as_const<QHeader>(blob)->simple_n;
+    if ((as_const<QHeader>(blob)->simple_flags >> 27) & 1u) return;  // an OR: k_scan_probe_or's (same grid)
     const uint32_t na = (uint32_t)__popc((as_const<QHeader>(blob)->simple_flags >> 12) & 0xFu);  // operands probed as 16-bit arrays
     if (n == 2u) {
         if (na == 0u) probe_body<1, 0>(blob, span, q, cand_cap, span_keys, num_hits);
@@ -679,11 +740,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
 }
 
-// max_nd: most dense operands of a query of the launch (sizes the LDS tile area)
+// The OR form of the same scan (simple_flags bit 27): an OR of 2..4 leaves with a term slot each whose sparsest operand streams as the cover
+// and whose other operands are bitmap words.  num_hits is the union: the set bits of the operands' ORed words plus the cover's postings
+// outside them.  Scored are the docs that hold the COVER — with whatever operands hold them too, each such set with its own bound.  Docs
+// WITHOUT the cover are counted, never scored: exact as long as none of them can reach the request's k-th best score — their scores are
+// bounded by the OR formula on the operands' list maxima (CompiledQuery::or_skip_bound), and the host checks the k-th key of the finished
+// request against that bound (finish_batch), running the request again on k_scan_simple when the check fails (an OR whose best hits lack
+// its rarest term).  Its own kernel: its register needs are not the AND's.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_scan_probe_or(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ blob_off,
+                                                                                                  const uint32_t* __restrict__ span_base, const uint32_t* __restrict__ qmap, uint32_t nq,
+                                                                                                  uint32_t cand_cap, unsigned long long* __restrict__ span_keys,
+                                                                                                  unsigned long long* __restrict__ num_hits) {
+    uint32_t q, span;
+    probe_item(span_base, qmap, nq, &q, &span);
+    const uint8_t* blob = blobs + blob_off[q];
+    const uint32_t n = as_const<QHeader>(blob)->simple_n;
+    if (!((as_const<QHeader>(blob)->simple_flags >> 27) & 1u)) return;
+    if (n == 2u) probe_body<1, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
+    else if (n == 3u) probe_body<2, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
+    else probe_body<3, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
+}
+
+// max_nd: most dense operands of a query of the launch (sizes the LDS tile area); any_and / any_or: which kinds of query the launch holds
 void launch_scan_probe(hipStream_t st, uint32_t max_nd, uint32_t total_spans, const uint8_t* blobs, const uint32_t* blob_off, const uint32_t* span_base, const uint32_t* qmap,
-                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits) {
+                       uint32_t nq, uint32_t cand_cap, unsigned long long* span_keys, unsigned long long* num_hits, bool any_and, bool any_or) {
     if (!total_spans) return;
-    hipLaunchKernelGGL(k_scan_probe, dim3(total_spans), dim3(64), scan_probe_lds_bytes(cand_cap, max_nd), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+    if (any_and)
+        hipLaunchKernelGGL(k_scan_probe, dim3(total_spans), dim3(64), scan_probe_lds_bytes(cand_cap, max_nd), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
+    if (any_or)
+        hipLaunchKernelGGL(k_scan_probe_or, dim3(total_spans), dim3(64), scan_probe_lds_bytes(cand_cap, max_nd), st, blobs, blob_off, span_base, qmap, nq, cand_cap, span_keys, num_hits);
 }
 
 }  // namespace vq
