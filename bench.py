@@ -271,6 +271,7 @@ class Bench:
                 veloci_amd.search_batch([reqs[i % len(reqs)]], index)
             lat.append((time.perf_counter() - a) * 1e3)
         p50 = float(np.median(lat[10:])) if lat else None
+        self.speculative_reruns = index.speculative_reruns  # (ORs on k_scan_probe_or that had to be run again on the exact kernels, whole life of the index)
         self.last_outputs = tuple(np.array(x) for x in last)  # (num_hits, counts, ids, scores) of the LAST TIMED step: what main() diffs against the oracle
         return batch_size * steps / dt, dt / steps * 1e3, p50, kernel_table(prof), [int(x) for x in last[0][:3]], reqs_json
 
@@ -403,6 +404,7 @@ def main():
                        "copies_of_a_list_per_launch": max(1, -(-(args.batch // launches_per_step) // max(args.triples, 1))),
                        "sharding": f"doc-range x{world}", "first_hit_counts": first_hits},
             "p50_latency_ms_single_query": (round(p50, 3) if p50 is not None else None),
+            **({"speculative_reruns": bench.speculative_reruns} if args.workload in ("or", "mix") else {}),
             "roofline": roofline_object(table, args.docs, args.triples, args.batch, args.workload, world),
         }
         legs = {"headline": leg_summary(qps, ms_step, table)}
@@ -441,6 +443,7 @@ def main():
 
         if args.triples * launches_per_step >= args.batch and args.batch // launches_per_step >= 8:  # round 3's headline configuration: every list four times inside a launch (256 triples, launches of 1024)
             short("headline_4_copies_per_launch", bench, "and", latency=False, launches=launches_per_step, tri_limit=max(1, args.batch // launches_per_step // 4), note="every list is read by four queries of a launch (round 3's configuration: 256 triples, launches of 1024): a quarter of the footprint")
+        short("or_100m_docs", bench, "or", latency=False, note="3-term OR over the headline's lists, one launch per step (k_scan_probe_or; ranks only the docs that hold the rarest term, confirmed by the k-th key)")
         short("config2_100m_docs", bench, "single", latency=False)
         del bench
         import gc

@@ -110,6 +110,15 @@ class ShardedSearcher:
         # this module drives partial -> torch.distributed all-gather -> merge).
         self.native = bool(self.collective and dist.get_backend(group) == "nccl" and not os.environ.get("VQ_PY_COLLECTIVE"))
         if self.native:
+            # every rank first finds out whether IT can load RCCL (taking an id does: cheap, nothing is joined yet) and the ranks agree — a rank that
+            # could not would never enter ncclCommInitRank, and the others would wait in it for ever
+            probe = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+            can = torch.tensor([1 if _lib.lib().vq_comm_unique_id(probe) == 0 else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(can, op=dist.ReduceOp.MIN, group=group)
+            if int(can.item()) == 0:
+                print(f"[veloci_amd.dist] rank {dist.get_rank(group)}: RCCL cannot be loaded on every rank; all ranks use the module's own path", flush=True)
+                self.native = False
+        if self.native:
             L = _lib.lib()
             rank = dist.get_rank(group)
             failed = 0

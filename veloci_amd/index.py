@@ -184,6 +184,11 @@ class Index:
         return int(self.L.vq_index_device_bytes(self.h))
 
     @property
+    def speculative_reruns(self):
+        """requests that ran a second time because a speculative kernel's short cut could not be confirmed (vq_index_speculative_reruns)"""
+        return int(self.L.vq_index_speculative_reruns(self.h))
+
+    @property
     def partial_arena_ptr(self):
         """device address of the partial arena (vq_index_partial_arena_ptr): where the chunks of a one-collective sharded step put their partials"""
         p = self.L.vq_index_partial_arena_ptr(self.h)
