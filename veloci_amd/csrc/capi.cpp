@@ -225,7 +225,7 @@ void dump_parts(std::string& s, const std::optional<std::vector<vqreq::RequestSe
 extern "C" {
 
 const char* vq_last_error(void) { return g_err.c_str(); }
-const char* vq_version(void) { return "veloci_amd 0.2 (gfx950)"; }
+const char* vq_version(void) { return "veloci_amd 0.3 (gfx950)"; }
 /* self-check (tests): inputs for which the kernels' fast a/100 differs from the correctly rounded division, over all f16 values */
 uint32_t vq_debug_div100_mismatches(void) { return vq::debug_div100_mismatches(); }
 /* tests, tools: requests that ran a second time because a speculative route's result could not be confirmed (k_scan_probe_or) */
