@@ -2116,7 +2116,7 @@ struct Compiler {
                 // leaves for the exchange before the host sees it, so shards keep k_scan_simple.  VQ_NO_PROBE_OR=1 switches the route off.
                 static const bool no_probe_or = std::getenv("VQ_NO_PROBE_OR") != nullptr;
                 uint32_t or_cover = UINT32_MAX;
-                if (!probe && !no_probe && !no_probe_or && !req.exact_routes_only && cq.simple_n >= 2 && cq.simple_n <= 4 && cq.ops[cq.simple_n].kind == OP_OR &&
+                if (!probe && !no_probe && !no_probe_or && !req.exact_routes_only && cq.top_k >= 1 && cq.simple_n >= 2 && cq.simple_n <= 4 && cq.ops[cq.simple_n].kind == OP_OR &&
                     cq.ops[cq.simple_n].nslots == cq.simple_n && !idx.sharded() && !(idx.comm && idx.comm->nranks > 1) && uint64_t(idx.doc_hi) - idx.doc_lo >= probe_min_docs) {
                     for (uint32_t k = 0; k < cq.simple_n; ++k) {
                         const HList& l = cq.lists[cq.ops[k].list_begin];
