@@ -1000,7 +1000,7 @@ def test_and_probe_kernel_shapes(corpus, big_corpus):
 
 
 def test_or_probe_kernel_shapes_and_reruns(corpus, big_corpus):
-    """k_scan_probe_or (ORs of 2-4 leaves with a term slot each, the sparsest operand streamed as the cover, the others read as bitmap words): it
+    """k_scan_probe_or (ORs of 2-3 leaves with a term slot each — the 4-leaf requests below run on k_scan_simple —, the sparsest operand streamed as the cover, the others read as bitmap words): it
     counts the union from the words and ranks only the docs that hold the cover; finish_batch confirms the result by its k-th key or runs the
     request again on the exact kernels (set_op.rs:87-220).  Every operand order, top from 1 to beyond the candidate buffer, skip, deep pages,
     leaf boosts — among them ones that push the cover's docs BELOW the others' (the short cut must be refused: vq_index_speculative_reruns grows) —,

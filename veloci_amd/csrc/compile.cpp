@@ -2109,14 +2109,14 @@ struct Compiler {
                     }
                     probe = probe && covers == 1;
                 }
-                // An OR of leaves with a term slot each whose sparsest operand has a tile-packed image and whose other operands are bitmap words, on an
+                // An OR of 2 or 3 leaves with a term slot each whose sparsest operand has a tile-packed image and whose other operands are bitmap words, on an
                 // unsharded index: k_scan_probe_or counts the union from the words' set bits and scores only the docs that hold the cover (the
                 // sparsest operand) — a doc without it scores at most `or_skip_bound`, and finish_batch confirms that the request's k-th best key lies
                 // above that before the result is handed out (otherwise the request runs again with exact_routes_only).  Sharded: a rank's partial
                 // leaves for the exchange before the host sees it, so shards keep k_scan_simple.  VQ_NO_PROBE_OR=1 switches the route off.
                 static const bool no_probe_or = std::getenv("VQ_NO_PROBE_OR") != nullptr;
                 uint32_t or_cover = UINT32_MAX;
-                if (!probe && !no_probe && !no_probe_or && !req.exact_routes_only && cq.top_k >= 1 && cq.simple_n >= 2 && cq.simple_n <= 4 && cq.ops[cq.simple_n].kind == OP_OR &&
+                if (!probe && !no_probe && !no_probe_or && !req.exact_routes_only && cq.top_k >= 1 && cq.simple_n >= 2 && cq.simple_n <= 3 && cq.ops[cq.simple_n].kind == OP_OR &&
                     cq.ops[cq.simple_n].nslots == cq.simple_n && !idx.sharded() && !(idx.comm && idx.comm->nranks > 1) && uint64_t(idx.doc_hi) - idx.doc_lo >= probe_min_docs) {
                     for (uint32_t k = 0; k < cq.simple_n; ++k) {
                         const HList& l = cq.lists[cq.ops[k].list_begin];

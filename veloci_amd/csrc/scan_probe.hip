@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
 }
 
-// The OR form of the same scan (simple_flags bit 27): an OR of 2..4 leaves with a term slot each whose sparsest operand streams as the cover
+// The OR form of the same scan (simple_flags bit 27): an OR of 2 or 3 leaves with a term slot each whose sparsest operand streams as the cover
 // and whose other operands are bitmap words.  num_hits is the union: the set bits of the operands' ORed words plus the cover's postings
 // outside them.  Scored are the docs that hold the COVER — with whatever operands hold them too, each such set with its own bound.  Docs
 // WITHOUT the cover are counted, never scored: exact as long as none of them can reach the request's k-th best score — their scores are
@@ -757,8 +757,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     const uint32_t n = as_const<QHeader>(blob)->simple_n;
     if (!((as_const<QHeader>(blob)->simple_flags >> 27) & 1u)) return;
     if (n == 2u) probe_body<1, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
-    else if (n == 3u) probe_body<2, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
-    else probe_body<3, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);
+    else probe_body<2, 0, true>(blob, span, q, cand_cap, span_keys, num_hits);  // (compile.cpp sends ORs of 2 or 3 leaves: a fourth operand's eight bounds spill)
 }
 
 // max_nd: most dense operands of a query of the launch (sizes the LDS tile area); any_and / any_or: which kinds of query the launch holds
