@@ -320,8 +320,10 @@ def test_alternative_kernel_routes_match(env):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or 1n_boost or random_requests_match or (reference_integration and (or_connect or minimal or simple_search or boost))"],
+    select = "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or 1n_boost or random_requests_match or (reference_integration and (or_connect or minimal or simple_search or boost))"
+    if any(k.startswith("VQ_PROBE") or k == "VQ_NO_PROBE_OR" for k in env):  # the legs about the probe kernels' routing: the tests whose requests can reach those kernels
+        select = "test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or random_requests_on_synthetic"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", select],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -1042,6 +1044,37 @@ def test_or_probe_kernel_shapes_and_reruns(corpus, big_corpus):
         if route_on:  # (the legs of test_alternative_kernel_routes_match run this test on other kernels: nothing is speculative there)
             assert int(L.vq_index_speculative_reruns(idx.h)) - before >= 4, "requests whose best hits lack the cover must be run again on the exact kernels"
             assert plain_reruns == 0, plain_reruns  # (the planted overlap puts the best hits into all three lists)
+
+
+def test_random_ors_with_leaf_boosts_on_the_speculative_route(big_corpus):
+    """240 random ORs of 2-3 terms (every df of the corpus, repeated terms, leaf boosts from -2 to 20 — zero, tiny and negative ones among them —, top 1-300,
+    skips up to beyond the hits) in batches: whatever k_scan_probe_or confirms and whatever it has to hand back to the exact kernels must equal the oracle
+    (set_op.rs:87-220); some of both must occur."""
+    import veloci_amd
+    from parity import assert_same
+    data, meta, idx, ora = big_corpus
+    rng = np.random.default_rng(int(os.environ.get("VQ_TEST_SEED", "77")))
+    pool = [t for tri in meta.triples for t in tri] + list(meta.extra_probes) + list(meta.background[:6])
+    boosts = [None, None, None, 1.0, 2.5, 0.5, 0.01, 0.0, 20.0, -1.0, 1e-7]
+    reqs = []
+    for _ in range(240):
+        n = int(rng.integers(2, 4))
+        leaves = []
+        for t in rng.choice(len(pool), n, replace=bool(rng.random() < 0.1)):
+            b = boosts[int(rng.integers(0, len(boosts)))]
+            leaves.append({"search": dict({"path": "body", "terms": [pool[int(t)]]}, **({"boost": b} if b is not None else {}))})
+        r = {"search_req": {"or": {"queries": leaves}}, "top": int(rng.choice([1, 3, 10, 10, 10, 40, 300]))}
+        if rng.random() < 0.2:
+            r["skip"] = int(rng.choice([1, 7, 100, 5000, 10**7]))
+        reqs.append(r)
+    before = idx.speculative_reruns
+    for lo in range(0, len(reqs), 80):
+        part = reqs[lo:lo + 80]
+        for r, g in zip(part, veloci_amd.search_batch(part, idx)):
+            assert_same(r, g, ora.search_json(json.dumps(r)))
+    again = idx.speculative_reruns - before
+    if os.environ.get("VQ_PROBE_MIN_DOCS") == "0" and not any(os.environ.get(k) for k in ("VQ_FORCE_GENERIC", "VQ_NO_PROBE", "VQ_NO_PROBE_OR")):
+        assert 0 < again < len(reqs), again
 
 
 def test_full_size_index_matches_the_oracle():
