@@ -259,6 +259,7 @@ struct Compiler {
     std::vector<CountReq> count_reqs;   // operands whose result sizes a count pre-pass must measure
     std::vector<CountReq> maybe_reqs;   // ... only if some OR needs the label of a two-operand AND
     bool label_wanted = false;
+    std::vector<const BoostColumn*> col_store;  // the boost column behind cq.cols[k] (request-level boosts): its value range bounds the boost's factor
     bool explain_on = false;                 // every leaf of the score tree carries options.explain (execution_plan.rs:46-85 after request.explain)
     std::shared_ptr<ExplainPlan> xplan;
 
@@ -1476,6 +1477,129 @@ struct Compiler {
 
     // Rich simple queries (DSimple2, k_scan_simple<2, true>): <= 4 single-list posting leaves in a tree of depth <= 2, no filter, no facets,
     // sink stages that need membership in <= 4 id lists, the leaves' own presence, or a gather by doc id.
+    // DSimple2::ub / prune: per set of present leaves an upper bound of what the score tree and the column boosts can give a doc (see device_types.hpp).
+    // Everything is taken on list / column maxima in double precision and handed over 1e-5 above: the kernel's f32 arithmetic on real values stays below.
+    void rich_bounds(DSimple2& S, const std::vector<uint16_t>& leaves, uint32_t n) {
+        S.prune = 0;
+        for (float& u : S.ub) u = std::numeric_limits<float>::infinity();
+        static const bool off = std::getenv("VQ_NO_RICH_PRUNE") != nullptr;
+        if (off || !cq.facets.empty() || cq.top_k < 1 || col_store.size() != cq.cols.size()) return;
+        double v[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < n; ++k) {
+            const HList& l = cq.lists[leaves[k]];
+            if (l.flags & LIST_F32) v[k] = l.max_value;
+            else if (l.max_raw >= 0x7C00 || !(l.term_score >= 0.0f)) return;
+            else {
+                const uint16_t h = l.max_raw;  // finite non-negative f16
+                const int e = (h >> 10) & 31, m = h & 1023;
+                v[k] = double(l.term_score) * ((e ? std::ldexp(1.0 + m / 1024.0, e - 15) : std::ldexp(m / 1024.0, -14)) / 100.0);
+            }
+            if (!(v[k] >= 0.0) || std::isinf(v[k])) return;
+        }
+        for (uint32_t g = 0; g < S.n_grp; ++g)
+            if (!(S.grp_mult[g] >= 0.0f) || std::isinf(S.grp_mult[g])) return;
+        for (uint32_t t = 0; t < S.n_tb; ++t)
+            if (!(S.tb_mult[t] >= 0.0f) || std::isinf(S.tb_mult[t])) return;
+        // the column boosts as monotone maps of the score (boost.rs:283-377): a doc may have no value (the score stays), else the factor / summand is
+        // largest at the column's largest value — provided no value turns a factor negative
+        struct Col {
+            int fun;
+            double hi;  // vmax + param
+            bool any;
+        };
+        std::vector<Col> colb;
+        for (size_t k = 0; k < cq.cols.size(); ++k) {
+            const DColBoost& cb = cq.cols[k];
+            const BoostColumn& bc = *col_store[k];
+            if (cb.nskip || cb.expr_op != EX_NONE || bc.has_nan) return;
+            const double lo = double(bc.vmin) + double(cb.param), hi = double(bc.vmax) + double(cb.param);
+            if (bc.any_value) {
+                if (cb.fun == BF_MULTIPLY && !(lo >= 0.0)) return;
+                if ((cb.fun == BF_LOG10 || cb.fun == BF_LOG2) && !(lo >= 1.0)) return;
+                if (std::isinf(hi) || hi != hi) return;
+            }
+            colb.push_back({cb.fun, hi, bc.any_value});
+        }
+        for (uint32_t pm = 0; pm < (1u << n); ++pm) {
+            double gv[4] = {0, 0, 0, 0};
+            bool gp[4] = {false, false, false, false};
+            for (uint32_t g = 0; g < S.ngroups; ++g) {
+                const uint32_t gm = S.g_mask[g], kind = S.g_kind[g];
+                if (kind == OP_AND) {
+                    for (uint32_t k = 0; k < n; ++k)
+                        if ((gm >> k) & 1u) gv[g] += v[k];
+                    gp[g] = (pm & gm) == gm;
+                } else if (kind == OP_OR) {
+                    double sum = 0.0, nd = 0.0;
+                    for (uint32_t sl = 0; sl < S.g_nslots[g]; ++sl) {
+                        double m = 0.0;
+                        bool any = false;
+                        for (uint32_t k = 0; k < n; ++k)
+                            if (((gm >> k) & 1u) && S.g_slot[g][k] == sl && ((pm >> k) & 1u)) {
+                                m = std::max(m, v[k]);
+                                any = true;
+                            }
+                        if (any) nd += 1.0;  // (at most: a slot counts from 1e-5 on)
+                        sum += m;
+                    }
+                    gv[g] = sum * nd * nd;
+                    gp[g] = (pm & gm) != 0;
+                } else {  // a leaf, or one leaf over several lists (the largest present value)
+                    for (uint32_t k = 0; k < n; ++k)
+                        if (((gm >> k) & 1u) && ((pm >> k) & 1u)) gv[g] = std::max(gv[g], v[k]);
+                    gp[g] = (pm & gm) != 0;
+                }
+            }
+            double s = 0.0;
+            bool present;
+            if (S.root_kind == OP_AND) {
+                present = true;
+                for (uint32_t g = 0; g < S.ngroups; ++g) {
+                    present = present && gp[g];
+                    s += gv[g];
+                }
+            } else if (S.root_kind == OP_OR) {
+                present = false;
+                double sum = 0.0, nd = 0.0;
+                for (uint32_t sl = 0; sl < S.root_nslots; ++sl) {
+                    double m = 0.0;
+                    bool any = false;
+                    for (uint32_t g = 0; g < S.ngroups; ++g)
+                        if (S.r_slot[g] == sl && gp[g]) {
+                            m = std::max(m, gv[g]);
+                            any = true;
+                        }
+                    if (any) nd += 1.0;
+                    sum += m;
+                    present = present || any;
+                }
+                s = sum * nd * nd;
+            } else {
+                present = gp[0];
+                s = gv[0];
+            }
+            if (!present) continue;  // (no hit has this set of leaves: the bound stays +inf)
+            for (const Col& c : colb) {
+                if (!c.any) continue;
+                double b = s;
+                switch (c.fun) {
+                    case BF_LOG10: b = s * std::log10(c.hi); break;
+                    case BF_LOG2: b = s * std::log2(c.hi); break;
+                    case BF_MULTIPLY: b = s * c.hi; break;
+                    case BF_ADD: b = s + c.hi; break;
+                    case BF_REPLACE: b = c.hi; break;
+                    default: break;
+                }
+                s = std::max(s, b);
+            }
+            const double up = s * (1.0 + 1e-5) + 1e-30;
+            float f = up < 3.0e38 ? float(up) : std::numeric_limits<float>::infinity();
+            if (double(f) < up) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+            S.ub[pm] = f;
+        }
+        S.prune = 1;
+    }
+
     void detect_rich_simple() {
         static const bool off = std::getenv("VQ_FORCE_GENERIC") != nullptr || std::getenv("VQ_NO_RICH") != nullptr;
         if (off || !count_reqs.empty() || cq.ops.empty() || cq.facets.size() > 2) return;
@@ -1637,6 +1761,7 @@ struct Compiler {
             if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);
         }
         if (!any_cover) return;
+        rich_bounds(S, leaves, n);
         cq.simple2 = S;
         cq.simple_n = n;
         cq.simple_flags = f;
@@ -1833,6 +1958,7 @@ struct Compiler {
                 cb.num_keys = it->second.num_keys;
                 fill_boost_params(cb, b);
                 cq.cols.push_back(cb);
+                col_store.push_back(&it->second);
                 cq.algorithmic_bytes += 0;  // 4 B gather per hit, unknown until run time
             }
         cq.n_top_cols = uint32_t(cq.cols.size());

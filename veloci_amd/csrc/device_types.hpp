@@ -139,6 +139,13 @@ struct DSimple2 {
     uint16_t side_list[4];                      // list index of side list s
     float grp_mult[4];
     float tb_mult[4];
+    // Exact top-k pruning at queueing time (round 4): ub[m] bounds the score — score tree and column boosts, on the leaves' list maxima and the
+    // boost columns' largest values — of a doc that holds exactly the leaves of mask m; the kernel multiplies in the phrase / term boosts and the
+    // text-locality factor the doc really gets (its side-list memberships are known when it is queued) and drops the doc — counted as a hit,
+    // never scored — when that product lies below the span's threshold.  prune == 0: some factor is not monotone (a negative boost, an expression,
+    // skip_when_score, a boost column with values that turn a factor negative) or the request wants facets: every hit is scored.
+    float ub[16];
+    uint8_t prune, pad4, pad5, pad6;
 };
 
 // "Wide" queries (k_scan_wide): 5..16 single-list posting leaves in a tree of depth <= 2 — the query generator's shapes, one leaf per term

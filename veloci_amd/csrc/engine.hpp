@@ -345,6 +345,8 @@ struct PhraseStore {
 struct BoostColumn {
     uint32_t key_base = 0, num_keys = 0;
     bool has_present = false;
+    float vmin = 0.0f, vmax = 0.0f;  // smallest / largest present value (any_value false: none)
+    bool any_value = false, has_nan = false;
     DevBuf values;   // f32
     DevBuf present;  // bitmap u32
     std::vector<uint32_t> host_bits;    // host copy, kept for 1:n boost columns (keys are value ids, resolved on the host)

@@ -450,6 +450,18 @@ std::unique_ptr<Index> build_index(const IndexBuilder& b, int device) {
         BoostColumn c;
         c.key_base = bc.key_base;
         c.num_keys = uint32_t(bc.bits.size());
+        for (size_t i = 0; i < bc.bits.size(); ++i) {  // the range of the present values: what bounds a boost factor (exact top-k pruning of boosted requests)
+            if (!bc.present.empty() && !bc.present[i]) continue;
+            float v;
+            std::memcpy(&v, &bc.bits[i], 4);
+            if (v != v) {
+                c.has_nan = true;
+                continue;
+            }
+            c.vmin = c.any_value ? std::min(c.vmin, v) : v;
+            c.vmax = c.any_value ? std::max(c.vmax, v) : v;
+            c.any_value = true;
+        }
         c.values.alloc(bc.bits.size() * 4 + 16);
         c.values.upload(bc.bits.data(), bc.bits.size() * 4);
         idx->device_bytes += c.values.bytes;

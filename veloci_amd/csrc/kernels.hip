@@ -1450,8 +1450,9 @@ namespace vq {
 constexpr uint32_t kSW = 8192;   // docs per tile
 constexpr uint32_t kSWW = 256;   // bitmap words per tile
 constexpr uint32_t kQCap = 128;  // survivor queue entries
-// LDS map (u32): misc[8] | qdoc[kQCap] | qidx[4][kQCap] | qmask[kQCap] | cand[2*cand_cap] | bm[scattered lists][SWW]
-constexpr uint32_t kSLdsQDoc = 8;
+// LDS map (u32): misc[8] | ub[16] (rich queries: DSimple2::ub) | qdoc[kQCap] | qidx[4][kQCap] | qmask[kQCap] | cand[2*cand_cap] | bm[scattered lists][SWW]
+constexpr uint32_t kSLdsUb = 8;
+constexpr uint32_t kSLdsQDoc = kSLdsUb + 16;
 constexpr uint32_t kSLdsQIdx = kSLdsQDoc + kQCap;
 constexpr uint32_t kSLdsQMask = kSLdsQIdx + 4 * kQCap;  // rich queries: side-list membership bits of the queued doc
 constexpr uint32_t kSLdsCand = kSLdsQMask + kQCap;
@@ -1551,6 +1552,7 @@ struct RichShape {
     float grp_mult[4], tb_mult[4];
     const DColBoost* cols;
     uint32_t n_col;
+    uint32_t prune;  // DSimple2::prune: docs whose bound (DSimple2::ub, in LDS) lies below the threshold are counted, not queued
 };
 __device__ __forceinline__ uint32_t b8(uint32_t x, uint32_t i) { return (x >> (8u * i)) & 0xFFu; }
 
@@ -1577,6 +1579,7 @@ __device__ __forceinline__ RichShape load_rich_shape(const DSimple2* S2, const D
     R.loc_side2 = (uint32_t)S2->loc_side[0] | ((uint32_t)S2->loc_side[1] << 8);
     R.cols = cols;
     R.n_col = n_col;
+    R.prune = S2->prune;
     return R;
 }
 
@@ -1827,6 +1830,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         R.facets = reinterpret_cast<const DFacet*>(blob + H->off_facets);
         R.n_facets = H->n_facets;
         R.hist = hist;
+        if (lane < 16u) lds[kSLdsUb + lane] = __float_as_uint(S2->ub[lane]);  // (ordered in front of its first use by the barrier below)
         if (fc_off && R.n_facets) {  // uniform
             R.fc_keys = lds + fc_off;
             for (uint32_t s2 = lane; s2 < kFacetCache; s2 += 64u) {
@@ -2122,6 +2126,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
             uint32_t rr[NW];
 #pragma unroll
             for (uint32_t t = 0; t < NW; ++t) rr[t] = comp4(r[t >> 2], t & 3u);
+            const float rich_thr_f = __uint_as_float(unorder_f32((uint32_t)(*thr >> 32)));  // the span's threshold score (NaN: none yet) — what a queued doc's bound must reach
             while (true) {  // uniform
                 uint32_t j = 0u, rw = 0u;  // this lane's first word that still has a surviving doc
 #pragma unroll
@@ -2131,17 +2136,16 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                         rw = rr[t];
                     }
                 const bool has = rw != 0u;
-                const unsigned long long mask = __ballot(has);
-                if (!mask) break;
+                if (!__ballot(has)) break;
+                bool keep = false;
+                uint32_t qi[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, pm = 0u, m = 0u, b = 0u;
                 if (has) {
-                    const uint32_t b = (uint32_t)__ffs((int)rw) - 1u;
+                    b = (uint32_t)__ffs((int)rw) - 1u;
                     const uint32_t cleared = rw & (rw - 1u);
 #pragma unroll
                     for (uint32_t t = 0; t < NW; ++t)
                         if (t == j) rr[t] = cleared;
                     const uint32_t below = (1u << b) - 1u;
-                    const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    qdoc[p] = tile_lo + ((lane * NW + j) << 5) + b;
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
                         if (k < n) {
@@ -2150,16 +2154,54 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                             for (uint32_t t = 0; t < NW; ++t)
                                 if (t == j) word = comp4(wk[k][t >> 2], t & 3u);
                             const uint32_t before = (uint32_t)(excl[k] >> (8u * j)) & 0xFFu;
-                            qidx[k * kQCap + p] = ((word >> b) & 1u) ? run[k] + before + (uint32_t)__popc(word & below) : 0xFFFFFFFFu;
+                            if ((word >> b) & 1u) {
+                                qi[k] = run[k] + before + (uint32_t)__popc(word & below);
+                                pm |= 1u << k;
+                            }
                         }
                     }
+                    keep = true;
                     if constexpr (RICH) {
-                        uint32_t m = 0;
 #pragma unroll
                         for (uint32_t s2 = 0; s2 < 4; ++s2)
                             if (s2 < R.n_side) m |= ((bml[sslot[s2] + lane * NW + j] >> b) & 1u) << s2;
-                        qmask[p] = m;
+                        if (R.prune) {  // uniform
+                            // what this doc can score at best: the bound of its set of leaves (score tree + column boosts on list / column maxima),
+                            // times the phrase / term boosts and the locality factor it really gets — the sink stages of rich_flush on the bound
+                            float ub = __uint_as_float(lds[kSLdsUb + pm]);
+#pragma unroll
+                            for (uint32_t g = 0; g < 4; ++g)
+                                if (g < R.n_grp && (m & b8(R.grp_mask4, g))) ub *= R.grp_mult[g];
+#pragma unroll
+                            for (uint32_t t = 0; t < 4; ++t)
+                                if (t < R.n_tb && ((m >> b8(R.tb_side4, t)) & 1u)) ub *= R.tb_mult[t];
+                            if (R.n_loc) {
+                                float best = 0.0f;
+                                bool hav = false;
+#pragma unroll
+                                for (uint32_t f = 0; f < 2; ++f)
+                                    if (f < R.n_loc) {
+                                        const uint32_t cnt = (uint32_t)__popc(pm & b8(R.loc_leaf2, f)) + (uint32_t)__popc(m & b8(R.loc_side2, f));
+                                        if (cnt > 1u) {
+                                            const float bv = 2.0f * (float)cnt * (float)cnt;
+                                            if (!hav || bv < best) best = bv;
+                                            hav = true;
+                                        }
+                                    }
+                                if (hav) ub *= best;
+                            }
+                            keep = !(ub < rich_thr_f);  // (NaN while the span has no threshold: everything is kept)
+                        }
                     }
+                }
+                const unsigned long long mask = __ballot(keep);  // the docs that are queued (the others were counted as hits above and can no longer enter the top-k)
+                if (keep) {
+                    const uint32_t p = qlen + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    qdoc[p] = tile_lo + ((lane * NW + j) << 5) + b;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (k < n) qidx[k * kQCap + p] = qi[k];
+                    if constexpr (RICH) qmask[p] = m;
                 }
                 qlen += (uint32_t)__popcll(mask);
                 if (qlen >= 64u) {  // uniform
