@@ -1823,6 +1823,8 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
     const DList* gl = reinterpret_cast<const DList*>(blob + H->off_lists);
     const DOp* gops = reinterpret_cast<const DOp*>(blob + H->off_ops);
     const bool seq = (sflags >> 16) & 1u;
+    VQ_STAMP_INIT
+    VQ_STAMP_COUNT(8)
     const DSimple2* S2 = reinterpret_cast<const DSimple2*>(blob + H->off_simple2);  // RICH only
     RichShape R{};
     if constexpr (RICH) {
@@ -1926,6 +1928,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         }
     unsigned long long or_thr_seen = ~0ull;
     uint32_t or_live = 0xFFFFu;
+    VQ_STAMP_AT(0)
     uint32_t pos = span_lo;  // sequential mode: next doc to cover
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const u32x4 kZero = u32x4{0u, 0u, 0u, 0u};
@@ -1968,6 +1971,8 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 }
             }
         }
+        VQ_STAMP_AT(1)
+        VQ_STAMP_COUNT(7)
         // scatter the id lists (rounds of 64 x 16 B, counted with ballots; see k_tile_scan P2)
         if constexpr (RICH) {
             u32x4 sfirst[4];
@@ -2001,6 +2006,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 for (uint32_t h = 0; h < NV; ++h) wk[k][h] = reinterpret_cast<const u32x4*>(bml + bslot[k])[lane * NV + h];
             }
 
+        VQ_STAMP_AT(2)
         // presence of the root
         u32x4 r[NV];
         uint32_t rpop = 0;
@@ -2101,6 +2107,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                     if (!S2) continue;  // uniform: nothing in this tile can enter the top-k
                 }
             }
+            VQ_STAMP_AT(3)
             // rank of each list at this lane's first word (one DPP scan per list), and — packed one byte per word — the popcounts
             // of the lane's words before word j: bytes of (pk * 0x0101..01) << 8 are the exclusive prefix sums of the bytes of pk
             uint32_t run[4] = {0, 0, 0, 0};
@@ -2121,6 +2128,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                     run[k] = base_idx[k] + wave_excl_scan_u32(tot, &dummy);
                 }
             }
+            VQ_STAMP_AT(4)
             // every round each lane emits its next surviving doc (lowest word, lowest bit first): the number of
             // rounds is the largest survivor count of a lane (1-2 for an AND tile, up to 128 for a dense OR tile)
             uint32_t rr[NW];
@@ -2205,10 +2213,13 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                 }
                 qlen += (uint32_t)__popcll(mask);
                 if (qlen >= 64u) {  // uniform
+                    VQ_STAMP_AT(5)
+                    VQ_STAMP_COUNT(9)
                     __syncthreads();
                     uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;  // (misc word 4: gathered bytes of the span, < 2^32)
                     if constexpr (RICH) rich_flush(64u, n, lf, R, qdoc, qidx, qmask, cs, top_k, stat);
                     else simple_flush(64u, n, kind, lf, order, slot, nslots, qdoc, qidx, cs, top_k, stat);
+                    VQ_STAMP_AT(10)
                     // move the remainder to the front
                     const uint32_t rem = qlen - 64u;
                     uint32_t td = 0, tm = 0, ti[4] = {0, 0, 0, 0};
@@ -2231,8 +2242,10 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
                     qlen = rem;
                 }
             }
+            VQ_STAMP_AT(5)
         }
     }
+    VQ_STAMP_AT(1)
     __syncthreads();
     if (qlen) {
         uint32_t* const stat = H->stat_off ? lds + 4 : nullptr;
@@ -2253,6 +2266,8 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
             facet_cache_flush(R.fc_keys, hist);
         }
     }
+    VQ_STAMP_AT(6)
+    VQ_STAMP_FLUSH
 }
 
 // 16384-doc tiles (NV = 2) cut the per-tile instruction overhead — with LDS sized by need the kernel is VALU-issue bound, not
