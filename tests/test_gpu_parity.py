@@ -304,12 +304,12 @@ def test_generic_kernel_also_matches_for_simple_queries():
 
 
 @pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
-                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_NO_PROBE": "1"}, {"VQ_PROBE_NO_ARR": "1"}, {"VQ_PROBE_MIN_DOCS": "40000000"}, {"VQ_NO_PROBE_OR": "1"}, {"VQ_NO_RICH_PRUNE": "1"},
+                                 {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_PROBE_NO_ARR": "1"}, {"VQ_PROBE_MIN_DOCS": "40000000"}, {"VQ_NO_PROBE_OR": "1", "VQ_NO_RICH_PRUNE": "1"},
                                  pytest.param({"VQ_RING": "1"}, marks=pytest.mark.skipif(os.environ.get("VQ_TEST_RING") != "1", reason="the persistent ring kernel is opt-in (VQ_RING=1); its parity leg runs with VQ_TEST_RING=1")),
                                  {"VQ_NO_WEIGHTED_SPANS": "1", "VQ_UNION_SPAN": "512", "VQ_BATCH_HALVES": "0", "VQ_FLAT_SMALL_CHUNKS": "1", "VQ_FLAT_CHUNKS": "4"}],
                          ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
                               "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
-                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "ands_on_k_scan_simple", "probe_operands_as_bitmap_words_only", "shipped_routing_of_shards_below_40m_docs", "ors_on_k_scan_simple", "rich_queries_without_bound_pruning", "ands_on_the_persistent_ring_kernel",
+                              "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "probe_operands_as_bitmap_words_only", "shipped_routing_of_shards_below_40m_docs_ands_and_ors_on_k_scan_simple", "ors_on_k_scan_simple_and_rich_queries_without_bound_pruning", "ands_on_the_persistent_ring_kernel",
                               "spans_chunks_and_host_threads_as_before_the_scheduling_changes"])
 def test_alternative_kernel_routes_match(env):
     """Single leaves run on k_scan_union and ORs on k_scan_simple by default; the other assignment must give the same results.
@@ -321,7 +321,7 @@ def test_alternative_kernel_routes_match(env):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     select = "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or 1n_boost or random_requests_match or (reference_integration and (or_connect or minimal or simple_search or boost))"
-    if any(k.startswith("VQ_PROBE") or k == "VQ_NO_PROBE_OR" for k in env):  # the legs about the probe kernels' routing: the tests whose requests can reach those kernels
+    if all(k.startswith("VQ_PROBE") for k in env):  # the legs about the probe kernels' routing: the tests whose requests can reach those kernels
         select = "test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or random_requests_on_synthetic"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", select],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
