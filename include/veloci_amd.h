@@ -311,7 +311,7 @@ void vq_partial_free(vq_partial_batch*);
  * `vq_index_set_allreduce` asks a caller for).  `vq_shard_step_begin` returns as soon as the step's work is queued, `vq_shard_step_end`
  * delivers it: a caller that begins step i+1 before it ends step i keeps two steps in flight (the scans of one overlap the exchange and
  * merge of the other; at most two).  Results are those of `vq_search_batch_flat` on the unsharded index, bit for bit; requests whose
- * top + skip exceeds 1024 are declined here (page them through vq_merge_partials).  On an index without a communicator the step is the same
+ * top + skip exceeds 1024 are declined here when the step has an exchange (page them through vq_merge_partials); an index that answers alone pages them itself.  On an index without a communicator the step is the same
  * pipeline without an exchange: begin / end then keep two batches in flight on an unsharded index.
  * `vq_comm_init_custom` takes the exchange from the caller instead (all-gather of `bytes_per_rank` bytes per rank into a rank-major
  * buffer; in-place sum of u32 counters — both on device memory, to be ordered on `hip_stream` or finished before they return): several

@@ -1222,6 +1222,14 @@ def test_deep_paging_beyond_one_scan(big_corpus):
     for k, (r, w) in enumerate(plain):
         assert int(num_hits[k]) == w.num_hits and list(ids[k, :counts[k]]) == list(w.ids), json.dumps(r)
         assert np.array_equal(scores[k, :counts[k]].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
+    # the step functions on an index that answers alone page as well (over shards they decline: the merge's caller pages, below)
+    from veloci_amd import dist as vdist
+    sb = veloci_amd.RequestBatch([veloci_amd.Request(r) for r, _ in plain])
+    num_hits, counts, ids, scores, status = vdist.shard_step_end(vdist.shard_step_begin(idx, sb), 2000)
+    assert not status.any()
+    for k, (r, w) in enumerate(plain):
+        assert int(num_hits[k]) == w.num_hits and list(ids[k, :counts[k]]) == list(w.ids), json.dumps(r)
+        assert np.array_equal(scores[k, :counts[k]].view(np.uint32), np.asarray(w.scores, np.float32).view(np.uint32))
     # more ranked hits than 64 scans reach: declined, not truncated
     with pytest.raises(veloci_amd.VelociError) as e:
         veloci_amd.search(dict(synth.req_or(a), top=10, skip=70000), idx)

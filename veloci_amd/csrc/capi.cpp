@@ -1309,7 +1309,10 @@ int vq_shard_step_end(vq_shard_step* step_raw, size_t stride, uint64_t* num_hits
             std::vector<int> st;
             std::vector<std::string> errs;
             finish_batch(idx, *step->pbs[k], step->used && step->pbs[k]->nq_dev ? gathered + step->arena_off[k] : nullptr, uint32_t(c.nranks), results, st, errs);
-            decline_deep(results, st, errs);
+            // a request that reaches beyond one scan's ranking: on an index that answers alone (no exchange) its further pages are scanned here, like on
+            // the flat batch path; over shards every rank would have to page on the MERGED page — declined there (vq_merge_partials pages)
+            if (!step->used && c.nranks == 1) complete_deep_requests(idx, step->pbs[k]->reqs.data(), step->pbs[k]->reqs.size(), results, st, errs);
+            else decline_deep(results, st, errs);
             decline_explain(results, st, errs, "the sharded step");
             copy_flat(results, st, errs, step->first[k], stride, num_hits, counts, ids, scores, status);
             step->pbs[k].reset();  // (destroyed here, by the thread that uses these allocations next: handing the frees to a background thread was tried and
