@@ -320,9 +320,11 @@ def test_alternative_kernel_routes_match(env):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    select = "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or 1n_boost or random_requests_match or (reference_integration and (or_connect or minimal or simple_search or boost))"
+    select = "single_term or test_and or test_or or nested or leaf_boost or batch_equals or two_shards or case_insensitive or random_requests_on_synthetic or phrase_and_locality or column_boosts or and_of_ors or boost_term or fuzzy or starts_with or wide_nodes or 1n_boost or random_requests_match or (reference_integration and (or_connect or minimal or simple_search or boost))"
     if all(k.startswith("VQ_PROBE") for k in env):  # the legs about the probe kernels' routing: the tests whose requests can reach those kernels
-        select = "test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or random_requests_on_synthetic"
+        select = "test_and or test_or or nested or leaf_boost or batch_equals or two_shards or and_probe_kernel_shapes or probe_or_kernel_shapes or random_requests_on_synthetic"
+    if "VQ_NO_PROBE_OR" in env:
+        select += " or probe_or_kernel_shapes"  # (the same ORs on k_scan_simple)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", select],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -1001,7 +1003,7 @@ def test_and_probe_kernel_shapes(corpus, big_corpus):
             assert_same(r, g, w)
 
 
-def test_or_probe_kernel_shapes_and_reruns(corpus, big_corpus):
+def test_probe_or_kernel_shapes_and_reruns(corpus, big_corpus):
     """k_scan_probe_or (ORs of 2-3 leaves with a term slot each — the 4-leaf requests below run on k_scan_simple —, the sparsest operand streamed as the cover, the others read as bitmap words): it
     counts the union from the words and ranks only the docs that hold the cover; finish_batch confirms the result by its k-th key or runs the
     request again on the exact kernels (set_op.rs:87-220).  Every operand order, top from 1 to beyond the candidate buffer, skip, deep pages,
@@ -1046,7 +1048,7 @@ def test_or_probe_kernel_shapes_and_reruns(corpus, big_corpus):
             assert plain_reruns == 0, plain_reruns  # (the planted overlap puts the best hits into all three lists)
 
 
-def test_random_ors_with_leaf_boosts_on_the_speculative_route(big_corpus):
+def test_probe_or_random_requests_with_leaf_boosts(big_corpus):
     """240 random ORs of 2-3 terms (every df of the corpus, repeated terms, leaf boosts from -2 to 20 — zero, tiny and negative ones among them —, top 1-300,
     skips up to beyond the hits) in batches: whatever k_scan_probe_or confirms and whatever it has to hand back to the exact kernels must equal the oracle
     (set_op.rs:87-220); some of both must occur."""
