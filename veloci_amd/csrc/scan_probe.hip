@@ -452,12 +452,20 @@ __device__ __forceinline__ void probe_body(const uint8_t* __restrict__ blob, con
             for (uint32_t a = 0; a < NA; ++a) {
                 const uint16_t* A = reinterpret_cast<const uint16_t*>(tile + (NB + a) * kPTW);
                 uint32_t lo = 0u, len = a_cnt[a];  // uniform length: every lane takes the same number of steps
+#ifdef VQ_PROBE_NO_SEARCH  // diagnostic build (wrong results): what the kernel takes without the lookups' dependent reads
+                lo = rel & 7u;
+                len = 0u;
+#endif
                 while (len > 1u) {
                     const uint32_t half = len >> 1;
                     lo = (uint32_t)A[lo + half] <= rel ? lo + half : lo;  // the last entry <= rel
                     len -= half;
                 }
+#ifdef VQ_PROBE_NO_SEARCH
+                found = found && a_cnt[a] != 0u && ((uint32_t)A[lo] ^ rel) < 0x2000u;  // (one read; about a quarter of the candidates "found", as in the real query)
+#else
                 found = found && a_cnt[a] != 0u && (uint32_t)A[lo] == rel;
+#endif
                 pos[a] = lo;
             }
             const unsigned long long fm = wballot(found);
