@@ -303,11 +303,11 @@ def test_generic_kernel_also_matches_for_simple_queries():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
+@pytest.mark.parametrize("env", [{"VQ_UNION_OR": "1", "VQ_NO_UNION_COV": "1"}, {"VQ_NO_UNION": "1"}, {"VQ_SIMPLE_NV": "1"}, {"VQ_NO_RICH": "1"}, {"VQ_NO_RICH": "1", "VQ_NO_QUEUE": "1"}, {"VQ_FORCE_GENERIC": "1"}, {"VQ_NO_LEAF_F32": "1"},
                                  {"VQ_NO_WIDE": "1"}, {"VQ_NO_LEAF_FUSION": "1"}, {"VQ_BOOST1N_DEVICE": "1"}, {"VQ_PROBE_NO_ARR": "1"}, {"VQ_PROBE_MIN_DOCS": "40000000"}, {"VQ_NO_PROBE_OR": "1", "VQ_NO_RICH_PRUNE": "1"},
                                  pytest.param({"VQ_RING": "1"}, marks=pytest.mark.skipif(os.environ.get("VQ_TEST_RING") != "1", reason="the persistent ring kernel is opt-in (VQ_RING=1); its parity leg runs with VQ_TEST_RING=1")),
                                  {"VQ_NO_WEIGHTED_SPANS": "1", "VQ_UNION_SPAN": "512", "VQ_BATCH_HALVES": "0", "VQ_FLAT_SMALL_CHUNKS": "1", "VQ_FLAT_CHUNKS": "4"}],
-                         ids=["or_on_k_scan_union", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
+                         ids=["or_on_k_scan_union_and_single_leaves_on_the_id_stream", "single_leaf_on_k_scan_simple", "k_scan_simple_8192_doc_tiles", "rich_queries_on_k_tile_scan",
                               "k_tile_scan_without_survivor_queue", "everything_on_k_tile_scan", "materialised_leaves_on_the_tile_kernels",
                               "wide_queries_on_k_tile_scan", "same_term_or_operands_not_fused", "one_to_n_boost_lists_resolved_on_the_device", "probe_operands_as_bitmap_words_only", "shipped_routing_of_shards_below_40m_docs_ands_and_ors_on_k_scan_simple", "ors_on_k_scan_simple_and_rich_queries_without_bound_pruning", "ands_on_the_persistent_ring_kernel",
                               "spans_chunks_and_host_threads_as_before_the_scheduling_changes"])

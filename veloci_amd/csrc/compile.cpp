@@ -2302,6 +2302,16 @@ struct Compiler {
                     if ((l.flags & LIST_BITMAP) && (seq || !cover) && !((arr_mask >> k) & 1u)) f |= 1u << k;
                     if (uint64_t(l.len) * 8192 >= 200 * (uint64_t(idx.doc_hi) - idx.doc_lo)) f |= 1u << (20 + k);
                 }
+                // a single leaf whose list has a tile-packed image: k_scan_union streams that (4 B per posting) instead of ids + scores (6 B)
+                static const bool no_union_cov = std::getenv("VQ_NO_UNION_COV") != nullptr;
+                if (cq.simple_n == 1 && !no_union_cov) {
+                    const HList& l = cq.lists[cq.ops[0].list_begin];
+                    if (l.d_cov32 && l.d_gdir && l.d_tile_dir && l.term_score > 0.0f && !(l.flags & LIST_F32) && l.inline_idx < 0) {
+                        f |= 1u << 28;
+                        cq.probe = DProbe{};
+                        cq.probe.leaf[0] = DProbeLeaf{l.d_cov32, l.d_arr16, l.d_gdir};
+                    }
+                }
                 cq.simple_flags = f;
             }
         }
@@ -2424,7 +2434,7 @@ struct Compiler {
         uint64_t b = 8ull * cq.top_k;
         if ((cq.simple_flags >> 19) & 1u) b += 8ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_leaf_f32
         else if (simple && !((cq.simple_flags >> 18) & 1u) && cq.simple_n == 1 && std::getenv("VQ_NO_UNION") == nullptr)
-            b += 6ull * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed
+            b += (((cq.simple_flags >> 28) & 1u) ? 4ull : 6ull) * cq.lists[cq.ops[0].list_begin].len;  // k_scan_union: ids and scores streamed, or the tile-packed words
         else if (wide) {
             for (uint32_t k = 0; k < cq.wide.n_leaves; ++k) b += ((cq.wide.bitmap_mask >> k) & 1u) ? bitmap_cost() : 4ull * cq.lists[cq.wide.leaf_list[k]].len;
         } else if ((cq.simple_flags >> 25) & 1u) {  // k_scan_probe: the cover's tile-packed (id, score) words are streamed, a bitmap operand's tiles come with 64 rank entries, an array operand costs 2 B per posting

@@ -202,7 +202,8 @@ struct QHeader {
                              // bit 18: rich simple query (DSimple2); bit 19: one materialised leaf (k_scan_leaf_f32); bits 20-23: leaf k has enough
                              // entries per tile to prefetch its next 1 KiB round; bit 24: wide query (DWide, k_scan_wide); bit 25: AND whose
                              // cover is ONE id list and whose other leaves are bitmap images or 16-bit arrays per tile (k_scan_probe, DProbe);
-                             // bits 12-15: leaf k is probed as a 16-bit array; bit 27: the root is an OR (k_scan_probe_or: docs without the cover
+                             // bits 12-15: leaf k is probed as a 16-bit array; bit 28: a single leaf whose tile-packed image
+                             // k_scan_union streams (DProbe::leaf[0]); bit 27: the root is an OR (k_scan_probe_or: docs without the cover
                              // are counted but not scored — CompiledQuery::or_skip_bound); bit 26: all operands bitmaps, top_k <= 32, opted in: k_scan_ring
 };
 

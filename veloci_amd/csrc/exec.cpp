@@ -132,7 +132,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     h.off_pres = uint32_t(section(cq.pres.size() * sizeof(DPresOp)));
     h.off_pres_in = uint32_t(section(cq.pres_in.size() * sizeof(uint16_t)));
     h.off_loc_idx = uint32_t(section(cq.loc_idx.size() * sizeof(uint16_t)));
-    h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : (cq.simple_flags >> 24) & 1u ? sizeof(DWide) : (cq.simple_flags >> 25) & 1u ? sizeof(DProbe) : 0));
+    h.off_simple2 = uint32_t(section((cq.simple_flags >> 18) & 1u ? sizeof(DSimple2) : (cq.simple_flags >> 24) & 1u ? sizeof(DWide) : ((cq.simple_flags >> 25) & 1u) || ((cq.simple_flags >> 28) & 1u) ? sizeof(DProbe) : 0));
     const bool pool = ((cq.simple_flags >> 25) & 1u) && cq.top_k <= kPoolMaxK;
     h.off_pool = pool ? uint32_t(section(sizeof(DPool) + 8 * size_t(cq.top_k))) : 0u;
     h.n_temps = cq.n_temps;
@@ -188,7 +188,7 @@ static size_t pack_blob(const CompiledQuery& cq, const Index& idx, uint8_t* dst,
     if (!cq.loc_idx.empty()) std::memcpy(dst + h.off_loc_idx, cq.loc_idx.data(), cq.loc_idx.size() * sizeof(uint16_t));
     if ((cq.simple_flags >> 18) & 1u) std::memcpy(dst + h.off_simple2, &cq.simple2, sizeof(DSimple2));
     if ((cq.simple_flags >> 24) & 1u) std::memcpy(dst + h.off_simple2, &cq.wide, sizeof(DWide));
-    if ((cq.simple_flags >> 25) & 1u) std::memcpy(dst + h.off_simple2, &cq.probe, sizeof(DProbe));
+    if (((cq.simple_flags >> 25) & 1u) || ((cq.simple_flags >> 28) & 1u)) std::memcpy(dst + h.off_simple2, &cq.probe, sizeof(DProbe));
     if (!cq.pres.empty()) std::memcpy(dst + h.off_pres, cq.pres.data(), cq.pres.size() * sizeof(DPresOp));
     if (!cq.pres_in.empty()) std::memcpy(dst + h.off_pres_in, cq.pres_in.data(), cq.pres_in.size() * sizeof(uint16_t));
     DFacet* df = reinterpret_cast<DFacet*>(dst + h.off_facets);

@@ -3532,8 +3532,10 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
 
     const uint32_t n_spans = H->n_spans;
     const unsigned long long range = (unsigned long long)(H->doc_hi - H->doc_lo);
-    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & ~(kSW - 1u));
-    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & ~(kSW - 1u));
+    const bool cov_mode = n == 1u && ((H->simple_flags >> 28) & 1u) != 0u;  // the single leaf streams its tile-packed image (spans end on its tiles)
+    const uint32_t span_mask = cov_mode ? ~((1u << kProbeTileShift) - 1u) : ~(kSW - 1u);
+    const uint32_t span_lo = span == 0 ? H->doc_lo : ((H->doc_lo + (uint32_t)(range * span / n_spans)) & span_mask);
+    const uint32_t span_hi = span + 1 == n_spans ? H->doc_hi : ((H->doc_lo + (uint32_t)(range * (span + 1) / n_spans)) & span_mask);
     const uint32_t keys_base = H->keys_base;
 
     uint32_t cur[4] = {0, 0, 0, 0}, end[4] = {0, 0, 0, 0};
@@ -3552,17 +3554,18 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
     const u32x4 kSent = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 
     if (n == 1) {
+        auto stream_postings = [&](const uint32_t c0, const uint32_t e0) {  // uniform bounds: postings [c0, e0) of the list, ids and scores
+        if (e0 <= c0) return;
         // ---- K1: stream [cur, end) of the one list, kU1 vectors of 4 postings per lane and round, the next round in flight.
         // With a positive term score the value is monotone in the raw f16 bits, so postings are pre-filtered by comparing the raw
         // bits with `raw_min`, the smallest raw score that can still reach the threshold; only those build a key.
-        hits = end[0] - cur[0];
         const VQ_GLOBAL u32x4* dptr = reinterpret_cast<const VQ_GLOBAL u32x4*>(docs[0]);
         const VQ_GLOBAL uint2* sptr = reinterpret_cast<const VQ_GLOBAL uint2*>(scs[0]);
-        const uint32_t v_end = (end[0] + 3u) >> 2;
+        const uint32_t v_end = (e0 + 3u) >> 2;
         constexpr uint32_t kU1 = 3;
         u32x4 d4[kU1];
         uint2 s4[kU1];
-        const uint32_t v_first = cur[0] >> 2;
+        const uint32_t v_first = c0 >> 2;
         // rounds run from the END of the slice to its start: under (score desc, id desc) a later posting wins every tie, so an
         // ascending scan of a list with few distinct scores would push on every tie; descending, ties never beat the threshold
         const uint32_t n_rounds = (v_end - v_first + kU1 * 64u - 1u) / (kU1 * 64u);
@@ -3609,7 +3612,7 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
                 }
             }
             // interior rounds need no index checks
-            const bool interior = (v0 << 2) >= cur[0] && ((v0 + kU1 * 64u) << 2) <= end[0];
+            const bool interior = (v0 << 2) >= c0 && ((v0 + kU1 * 64u) << 2) <= e0;
             bool any = false;
             bool pass[kU1 * 4];
 #pragma unroll
@@ -3621,7 +3624,7 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
                     const uint32_t raw = j == 0 ? (s4[u].x & 0xFFFFu) : j == 1 ? (s4[u].x >> 16) : j == 2 ? (s4[u].y & 0xFFFFu) : (s4[u].y >> 16);
                     // raw >= raw_min as integers: true for every candidate (negative / NaN patterns compare high and take the exact path)
                     bool p = raw >= raw_min;
-                    if (!interior) p = p && v < v_end && (i0 + j) >= cur[0] && (i0 + j) < end[0];
+                    if (!interior) p = p && v < v_end && (i0 + j) >= c0 && (i0 + j) < e0;
                     pass[u * 4 + j] = p;
                     any = any || p;
                 }
@@ -3644,6 +3647,116 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
             for (uint32_t u = 0; u < kU1; ++u) {
                 d4[u] = nd4[u];
                 s4[u] = ns4[u];
+            }
+        }
+        };
+        hits = end[0] - cur[0];
+        if (!cov_mode) stream_postings(cur[0], end[0]);
+        else {
+            // The list's tile-packed image (cov32: in-tile offset << 16 | f16 score, 4 B per posting instead of 6) is streamed instead of its ids and
+            // scores.  A packed word says which doc it is only together with its tile, so the few postings that pass the raw-score test look their
+            // tile up in the directory (a binary search per lane, rare once the threshold stands); the span's LAST tiles — about 2048 postings — still
+            // run on the id stream and set that threshold first.  Without one (fewer hits than the request ranks) everything stays on the id stream.
+            const uint32_t* tdir = gl[gops[0].list_begin].tile_dir;
+            const uint32_t* gdir = as_const<DProbe>(blob + H->off_simple2)->leaf[0].gdir;
+            const VQ_GLOBAL u32x4* cc4 = as_global(reinterpret_cast<const u32x4*>(as_const<DProbe>(blob + H->off_simple2)->leaf[0].cov32));
+            const uint32_t bitmap_base = H->bitmap_base;
+            const uint32_t t_first = (span_lo - bitmap_base) >> kProbeTileShift;
+            const uint32_t t_end = span_hi > span_lo ? ((span_hi - 1u - bitmap_base) >> kProbeTileShift) + 1u : t_first;
+            uint32_t t_switch = t_end;
+            {
+                const uint32_t want = end[0] - cur[0] > 2048u ? end[0] - 2048u : cur[0];
+                // the 32768-doc tile that holds posting `want` (directory: one entry per 16384 docs, entries below a boundary): from its start on
+                // — at least 2048 postings, at most a tile more — the id stream runs
+                const uint32_t i = wave_lower_bound(tdir + 2u * t_first, 2u * (t_end - t_first) + 1u, want + 1u);  // first boundary with more than `want` postings below it
+                t_switch = t_first + ((i ? i - 1u : 0u) >> 1);
+                t_switch = t_switch < t_end ? t_switch : t_end;
+            }
+            const uint32_t split = as_global(tdir)[2u * t_switch];  // postings below tile t_switch
+            stream_postings(split > cur[0] ? split : cur[0], end[0]);
+            if (t_switch > t_first) {  // uniform
+                __syncthreads();
+                if (*thr == 0ull) stream_postings(cur[0], split < end[0] ? split : end[0]);  // uniform: no threshold yet
+                else {
+                    const uint32_t g_first = as_global(gdir)[t_first], g_end = as_global(gdir)[t_switch];
+                    const uint32_t v_first = g_first * 2u, v_end = g_end * 2u;  // 16-byte vectors of 4 packed words
+#ifndef VQ_UC
+#define VQ_UC 4
+#endif
+                    constexpr uint32_t kUc = VQ_UC;
+                    const uint32_t n_rounds = (v_end - v_first + kUc * 64u - 1u) / (kUc * 64u);
+                    const u32x4 kPad = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    u32x4 e4[kUc];
+#pragma unroll
+                    for (uint32_t u = 0; u < kUc; ++u) {
+                        const uint32_t v = v_first + (n_rounds ? (n_rounds - 1u) * kUc * 64u : 0u) + u * 64u + lane;
+                        e4[u] = v < v_end ? cc4[v] : kPad;
+                    }
+                    unsigned long long thr_seen = ~0ull;
+                    uint32_t raw_min = 0;
+                    for (uint32_t r = n_rounds; r-- > 0;) {  // uniform; descending like the id stream (ties never beat the threshold)
+                        const uint32_t v0 = v_first + r * kUc * 64u;
+                        u32x4 ne4[kUc];
+#pragma unroll
+                        for (uint32_t u = 0; u < kUc; ++u) {
+                            const uint32_t vn = v0 - kUc * 64u + u * 64u + lane;  // the round before (only read when r > 0)
+                            ne4[u] = (r > 0 && vn >= v_first && vn < v_end) ? cc4[vn] : kPad;
+                        }
+                        const unsigned long long thr_reg = *thr;
+                        if (thr_reg != thr_seen) {  // uniform: the threshold rose — smallest positive-f16 bit pattern whose value EXCEEDS its score.
+                            // (A posting that merely ties the threshold's score loses on the doc id without its doc being known: the threshold as
+                            //  read at the top of a round holds keys of earlier rounds only — docs above every doc of this round.  With the few
+                            //  distinct f16 scores of a list, ties are most of what reaches the threshold's score.)
+                            thr_seen = thr_reg;
+                            const uint32_t tbits = (uint32_t)(thr_reg >> 32);
+                            uint32_t lo = 0, hi = 0x7C00u;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (order_f32(__float_as_uint(posting_value_fast(ts[0], (uint16_t)mid))) <= tbits) lo = mid + 1;
+                                else hi = mid;
+                            }
+                            raw_min = lo;
+                        }
+                        bool any = false;
+#pragma unroll
+                        for (uint32_t u = 0; u < kUc; ++u) {
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t e = comp4(e4[u], j);
+                                any = any || ((e & 0xFFFFu) >= raw_min && e != 0xFFFFFFFFu);
+                            }
+                        }
+                        if (__ballot(any)) {  // uniform; rare
+#pragma unroll
+                            for (uint32_t u = 0; u < kUc; ++u) {
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; ++j) {
+                                    const uint32_t e = comp4(e4[u], j);
+                                    const bool p = (e & 0xFFFFu) >= raw_min && e != 0xFFFFFFFFu;
+                                    if (__ballot(p)) {  // uniform
+                                        unsigned long long key = 0ull;
+                                        if (p) {
+                                            // the tile of granule g: the last directory entry <= g among tiles [t_first, t_switch)
+                                            const uint32_t g = (v0 + u * 64u + lane) >> 1;
+                                            uint32_t lo = t_first, hi = t_switch;  // invariant: gdir[lo] <= g < gdir[hi]
+                                            while (hi - lo > 1u) {
+                                                const uint32_t mid = (lo + hi) >> 1;
+                                                if (as_global(gdir)[mid] <= g) lo = mid;
+                                                else hi = mid;
+                                            }
+                                            const uint32_t doc = bitmap_base + (lo << kProbeTileShift) + (e >> 16);
+                                            const float score = posting_value_fast(ts[0], (uint16_t)(e & 0xFFFFu));
+                                            key = ((unsigned long long)order_f32(__float_as_uint(score)) << 32) | (unsigned long long)doc;
+                                        }
+                                        union_push(p && key > *thr && key < cs.upper, key, cs, top_k);
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < kUc; ++u) e4[u] = ne4[u];
+                    }
+                }
             }
         }
     } else {
