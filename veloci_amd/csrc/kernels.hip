@@ -3665,7 +3665,8 @@ __global__ __launch_bounds__(64) void k_scan_union(const uint8_t* __restrict__ b
             const uint32_t t_end = span_hi > span_lo ? ((span_hi - 1u - bitmap_base) >> kProbeTileShift) + 1u : t_first;
             uint32_t t_switch = t_end;
             {
-                const uint32_t want = end[0] - cur[0] > 2048u ? end[0] - 2048u : cur[0];
+                const uint32_t warm = top_k * 4u > 2048u ? top_k * 4u : 2048u;  // (the candidate buffer holds 2 x top_k keys before its first prune sets a threshold)
+                const uint32_t want = end[0] - cur[0] > warm ? end[0] - warm : cur[0];
                 // the 32768-doc tile that holds posting `want` (directory: one entry per 16384 docs, entries below a boundary): from its start on
                 // — at least 2048 postings, at most a tile more — the id stream runs
                 const uint32_t i = wave_lower_bound(tdir + 2u * t_first, 2u * (t_end - t_first) + 1u, want + 1u);  // first boundary with more than `want` postings below it
