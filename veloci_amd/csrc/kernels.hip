@@ -1993,7 +1993,7 @@ __device__ __forceinline__ void scan_simple_body(const uint8_t* __restrict__ blo
         for (uint32_t k = 0; k < 4; ++k)
             if (k < n && !((sflags >> k) & 1u))
                 base_idx[k] = simple_scatter_list(lf[k].docs, lf[k].len, cur[k], nxt[k], bml + bslot[k], wk[k][0], (sflags >> (20 + k)) & 1u, tile_lo, tile_hi, lo_bound);
-        if (kind != OP_AND && (tiles_done++ & 3u) == 0u && lane == 0) {  // (an AND has few survivors: nothing to prune) adopt the threshold other
+        if ((RICH ? R.prune != 0u : kind != OP_AND) && (tiles_done++ & 3u) == 0u && lane == 0) {  // (a plain AND has few survivors: nothing to prune; a rich query that prunes by bounds does, whatever its root) adopt the threshold other
                                                                           // spans of the query have published (QHeader::gthr)
             const unsigned long long g = *reinterpret_cast<volatile unsigned long long*>(cs.gthr);
             if (g > *thr) *thr = g;
