@@ -37,7 +37,7 @@ enum {
     VQ_ERR_FST_NOT_FOUND = 2,
     /* VelociError::StringError("Did not found path in indices ...") (src/persistence.rs:454-458) */
     VQ_ERR_INDEX_NOT_FOUND = 3,
-    /* request uses a feature outside the GPU hot path (select, why_found_info highlighting, snippets, the declined explain combinations ...): never silently ignored */
+    /* request uses a feature outside the GPU hot path (snippets inside a search, the declined explain combinations, why_found_info on the flat / sharded entry points ...): never silently ignored */
     VQ_ERR_UNSUPPORTED = 4,
     /* HIP runtime failure / no device / extension missing */
     VQ_ERR_DEVICE = 5,
@@ -182,13 +182,20 @@ const char* vq_result_facet_field(const vq_result*, size_t facet);
 size_t vq_result_facet_len(const vq_result*, size_t facet);
 const char* vq_result_facet_value(const vq_result*, size_t facet, size_t i);
 uint64_t vq_result_facet_count(const vq_result*, size_t facet, size_t i);
-/* serde_json rendering of the SearchResult (ids/scores/facets/why_found_terms), for diffing. */
+/* serde_json rendering of the SearchResult (ids/scores/facets/why_found_terms/why_found_info), for diffing. */
 const char* vq_result_to_json(const vq_result*);
 /* `SearchResult.why_found_terms` (src/search/result/search_result.rs:21-25, filled at src/search.rs:186 when the request says
  * `why_found: true`): per text index path the matched dictionary terms, as JSON {"<path>": ["term", ...]} (thread-local string;
- * the reference's map and list orders are unspecified).  `why_found` together with `select` (why_found_info: highlighting of the
- * returned documents) is declined. */
+ * the reference's map and list orders are unspecified). */
 const char* vq_result_why_found_terms_json(const vq_result*);
+/* `SearchResult.why_found_info` (src/search.rs:220-224 = get_why_found, src/search/why_found.rs:11-50; what to_documents hands out per hit when
+ * the request has a `select`, search.rs:83-88): for `why_found: true` together with `select`, per returned anchor and searched field the
+ * anchor's texts of the field that hold a matched token, highlighted like vq_highlight_json's snippets with the default snippet options — as JSON
+ * {"<anchor id>": {"<field>": ["text with <b>hits</b>", ...]}} (thread-local string); "null" when the request did not ask.  `select` itself is not
+ * looked at, as in search::search: reading the selected fields is to_documents' work on the caller's document store.  Host work on the final
+ * window of hits (needs the fields' `.parent_to_value_id` and `.text_id_to_token_ids` stores); vq_search / vq_search_json / vq_search_batch
+ * only — the flat and the sharded entry points answer VQ_ERR_UNSUPPORTED for such a request. */
+const char* vq_result_why_found_info_json(const vq_result*);
 /* `explain: true` (src/search/request/mod.rs:83-86; or `options.explain` on the single leaf of a request): the `Explain` records
  * (src/search/result/explain.rs:2-21) of the returned hits, i.e. `SearchResult.explain.get(&hit.id)` of src/search.rs:86,96 — a JSON array
  * parallel to the hits, each element null or the hit's records in serde's form ({"TermToAnchor":{"term_score":..,"anchor_score":..,

@@ -54,6 +54,8 @@ def lib():
         L.vo_result_free.argtypes = [C.c_void_p]
         L.vo_result_why_found_terms_json.restype = C.c_char_p
         L.vo_result_why_found_terms_json.argtypes = [C.c_void_p]
+        L.vo_result_why_found_info_json.restype = C.c_char_p
+        L.vo_result_why_found_info_json.argtypes = [C.c_void_p]
         L.vo_result_explain_json.restype = C.c_char_p
         L.vo_result_explain_json.argtypes = [C.c_void_p]
         L.vo_suggest_json.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -169,6 +171,8 @@ class OracleIndex:
             res = OracleResult(int(self.L.vo_result_num_hits(out)), ids, scores, facets, int(self.L.vo_result_execution_time_ns(out)))
             import json as _json
             res.why_found_terms = _json.loads(self.L.vo_result_why_found_terms_json(out).decode())
+            # search.rs:220-224 (why_found with select): {anchor id: {field: [highlighted texts]}}
+            res.why_found_info = {int(k): v for k, v in _json.loads(self.L.vo_result_why_found_info_json(out).decode()).items()}
             res.explain_json = self.L.vo_result_explain_json(out).decode()  # per hit: null or the Explain records (search.rs:86,96)
             res.explain = _json.loads(res.explain_json)
             return res

@@ -18,7 +18,7 @@ struct ResultBox {
     SearchResult r;
     std::vector<uint32_t> ids;
     std::vector<float> scores;
-    std::string why_json, explain_json;
+    std::string why_json, why_info_json, explain_json;
 };
 int fail(const VelociError& e) {
     g_err = e.what();
@@ -123,6 +123,33 @@ const char* vo_result_why_found_terms_json(const void* r) {
             vqjson::escape_to(s, kv.second[i]);
         }
         s += ']';
+    }
+    s += '}';
+    return s.c_str();
+}
+// why_found_info (search.rs:220-224) as JSON {"<anchor id>": {"<field>": ["highlighted text", ...]}}
+const char* vo_result_why_found_info_json(const void* r) {
+    auto* box = const_cast<ResultBox*>(static_cast<const ResultBox*>(r));
+    std::string& s = box->why_info_json;
+    s = "{";
+    bool first = true;
+    for (auto& [anchor, fields] : box->r.why_found_info) {
+        if (!first) s += ',';
+        first = false;
+        s += '"' + std::to_string(anchor) + "\":{";
+        bool f1 = true;
+        for (auto& [field, texts] : fields) {
+            if (!f1) s += ',';
+            f1 = false;
+            vqjson::escape_to(s, field);
+            s += ":[";
+            for (size_t i = 0; i < texts.size(); ++i) {
+                if (i) s += ',';
+                vqjson::escape_to(s, texts[i]);
+            }
+            s += ']';
+        }
+        s += '}';
     }
     s += '}';
     return s.c_str();

@@ -1250,6 +1250,41 @@ struct PlanCtx {
     }
 };
 
+std::optional<std::string> highlight_document(const Index& index, const std::string& path, uint64_t value_id, const std::vector<uint32_t>& token_ids, const SnippetInfo& opt);
+
+// get_why_found (src/search/why_found.rs:11-50): for every returned anchor and every searched field, the field's texts of that anchor
+// (join_anchor_to_leaf, facet.rs:75-93) highlighted with ALL term ids the search matched in the field (highlight_document with the default snippet
+// options); texts without a hit leave no entry
+std::map<uint32_t, std::map<std::string, std::vector<std::string>>> get_why_found(const Index& index, const std::vector<uint32_t>& anchor_ids,
+                                                                                  const TermIdHits& term_id_hits_in_field) {
+    static const SnippetInfo kDefaultSnippetInfo;
+    std::map<uint32_t, std::map<std::string, std::vector<std::string>>> anchor_highlights;
+    for (auto& [path, term_with_ids] : term_id_hits_in_field) {
+        const std::string field_name = extract_field_name(path);
+        const std::vector<std::string> paths = get_steps_to_anchor(field_name);
+        std::vector<uint32_t> all_term_ids_hits_in_path;
+        for (auto& [term, hits] : term_with_ids) all_term_ids_hits_in_path.insert(all_term_ids_hits_in_path.end(), hits.begin(), hits.end());
+        if (all_term_ids_hits_in_path.empty()) continue;
+        for (uint32_t anchor_id : anchor_ids) {
+            std::vector<uint32_t> ids(1, anchor_id);
+            for (auto& step : paths) {
+                const KeyValueStore& kv = index.get_valueid_to_parent(step + PARENT_TO_VALUE_ID);
+                std::vector<uint32_t> next;
+                for (uint32_t id : ids) {
+                    const uint32_t *b, *e;
+                    if (kv.get_values(id, &b, &e)) next.insert(next.end(), b, e);
+                }
+                ids.swap(next);
+            }
+            for (uint32_t value_id : ids) {
+                auto highlighted_document = highlight_document(index, paths.back(), value_id, all_term_ids_hits_in_path, kDefaultSnippetInfo);
+                if (highlighted_document) anchor_highlights[anchor_id][field_name].push_back(*highlighted_document);
+            }
+        }
+    }
+    return anchor_highlights;
+}
+
 }  // namespace
 
 SearchResult search(Request request, const Index& index) {
@@ -1366,6 +1401,11 @@ SearchResult search(Request request, const Index& index) {
     search_result.num_hits = res.hits_scores.size();  // :207
     search_result.data = top_n_sort(std::move(res.hits_scores), uint32_t(*request.top) + uint32_t(request.skip.value_or(0)));  // :210-211
     apply_top_skip(search_result.data, request.skip, request.top);  // :218
+    if (request.why_found && request.has_select) {  // :220-224
+        std::vector<uint32_t> anchor_ids;
+        for (auto& h : search_result.data) anchor_ids.push_back(h.id);
+        search_result.why_found_info = get_why_found(index, anchor_ids, res.term_id_hits_in_field);
+    }
     search_result.execution_time_ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - start).count());
     return search_result;
 }

@@ -156,6 +156,8 @@ struct SearchResult {  // src/search/result/search_result.rs:9-26
     std::vector<std::pair<std::string, std::vector<std::pair<std::string, uint64_t>>>> facets;  // request order
     std::map<std::string, std::vector<std::string>> why_found_terms;  // search.rs:186 (the reference's map and list orders are unspecified)
     ExplainMap explain;                                               // search.rs:174; per hit: explain.get(&hit.id) (search.rs:86,96)
+    // search.rs:220-224 (request.why_found && request.select): anchor -> field -> highlighted texts of the field that hold a matched token
+    std::map<uint32_t, std::map<std::string, std::vector<std::string>>> why_found_info;
 };
 struct SuggestEntry {  // search_field.rs:158 SuggestFieldResult = Vec<(String, Score, TermId)>
     std::string text;

@@ -198,7 +198,7 @@ def test_errors(corpus):
         veloci_amd.search({"top": 3}, idx)
     assert e2.value.code == 1
     with pytest.raises(veloci_amd.VelociError) as e3:
-        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"]}}, "why_found": True, "select": ["body"]}, idx)  # why_found_info: highlighting
+        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"], "snippet": True}}}, idx)  # snippets inside a search: vq_highlight_json's work
     assert e3.value.code == 4
 
 
@@ -903,9 +903,71 @@ def test_suggest_regex_and_why_found_terms_match_the_reference_and_the_oracle():
         assert {k: sorted(v) for k, v in got.why_found_terms.items()} == {k: sorted(v) for k, v in want.why_found_terms.items()}, json.dumps(req)
     for req, got in zip(reqs, veloci_amd.search_batch(reqs, idx)):
         assert_same(req, got, ora.search_json(json.dumps(req)))
-    with pytest.raises(veloci_amd.VelociError) as e:
-        veloci_amd.search(dict(reqs[0], select=["title"]), idx)
-    assert e.value.kind == "Unsupported"
+    # `select` alone changes nothing in search::search (reading the fields is to_documents' work, search.rs:63-103)
+    assert_same(reqs[0], veloci_amd.search(dict(reqs[0], select=["title"]), idx), ora.search_json(json.dumps(reqs[0])))
+
+
+def test_why_found_with_select_matches_the_reference_and_the_oracle():
+    """`why_found` together with `select` (search.rs:220-224 -> SearchResult::why_found_info, search/why_found.rs:11-50) through the C ABI: the
+    reference's own assertions (tests/golden/reference_why_found.json), then product == oracle on a wider set — singly and as one batch — and the
+    entry points without a place for the map decline."""
+    import veloci_amd
+    from oracle import binding as O
+    from parity import assert_same
+    from veloci_amd import mini_indexer
+    import refcases
+    import test_reference_integration as T
+    fx = T._load_why_found()
+    built = {}
+    for case in fx["cases"]:
+        if case["corpus"] not in built:
+            c = fx["corpora"][case["corpus"]]
+            docs = refcases.corpus_docs(c)
+            data, info = mini_indexer.build_index(docs, c["indices"])
+            ora = O.OracleIndex(data.num_anchors)
+            data.load_into(ora)
+            built[case["corpus"]] = (veloci_amd.Index(data, device=0), ora, docs)
+        idx, ora, docs = built[case["corpus"]]
+        got = veloci_amd.search(case["request"], idx)
+        assert len(got.ids) >= 1, case["name"]
+        for k, v in case.get("expect_doc", {}).items():
+            assert docs[int(got.ids[0])][k] == v, case["name"]
+        assert got.why_found_info.get(int(got.ids[0]), {}) == case["expect_why_found"], (case["name"], got.why_found_info)
+        want = ora.search_json(json.dumps(case["request"]))
+        assert_same(case["request"], got, want)
+        assert got.why_found_info == want.why_found_info, case["name"]
+
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    idx = veloci_amd.Index(data, device=0)
+    reqs = T.why_found_select_requests()
+    answered, with_entries = [], 0
+    for req in reqs:
+        try:
+            want = ora.search_json(json.dumps(req))
+        except O.OracleError as eo:
+            with pytest.raises(veloci_amd.VelociError) as ev:
+                veloci_amd.search(req, idx)
+            assert str(ev.value) == str(eo), req
+            continue
+        got = veloci_amd.search(req, idx)
+        assert_same(req, got, want)
+        if req.get("why_found") and "select" in req:
+            assert got.why_found_info == want.why_found_info, (json.dumps(req), got.why_found_info, want.why_found_info)
+            with_entries += sum(len(t) for f in got.why_found_info.values() for t in f.values())
+        else:
+            assert got.why_found_info is None and want.why_found_info == {}, req
+        answered.append((req, want))
+    assert len(answered) > 40 and with_entries > 40, (len(answered), with_entries)
+    for (req, want), got in zip(answered, veloci_amd.search_batch([r for r, _ in answered], idx)):
+        assert_same(req, got, want)
+        assert (got.why_found_info or {}) == want.why_found_info, json.dumps(req)
+    # the flat entry point has no place for the map: such a request is declined there, its neighbours are answered
+    asked = [r for r, _ in answered if r.get("why_found") and "select" in r][:3]
+    plain = [r for r, _ in answered if not r.get("why_found")][:1]
+    status = veloci_amd.search_batch_flat(asked + plain, idx, stride=20)[4]
+    assert len(asked) == 3 and list(status) == [4, 4, 4, 0], status
 
 
 def test_random_requests_in_batches_match_the_oracle():
@@ -1647,8 +1709,10 @@ def test_sharded_step_error_paths_leave_the_index_usable(corpus):
     empty = veloci_amd.RequestBatch([])
     out = shard_step_end(shard_step_begin(idx, empty), 10)
     assert len(out[0]) == 0
-    # a request the path declines (select) and one that fails to compile (unknown field) ride along: statuses, not a failed step
-    mixed = reqs[:6] + [dict(synth.req_single(meta.extra_probes[0]), select=["body"]), {"search_req": {"search": {"terms": ["x"], "path": "nosuchfield"}}}]
+    # a request the path declines (a snippet inside a search) and one that fails to compile (unknown field) ride along: statuses, not a failed step
+    declined = json.loads(json.dumps(synth.req_single(meta.extra_probes[0])))
+    declined["search_req"]["search"]["snippet"] = True
+    mixed = reqs[:6] + [declined, {"search_req": {"search": {"terms": ["x"], "path": "nosuchfield"}}}]
     mb = veloci_amd.RequestBatch(mixed)
     res = shard_step_end(shard_step_begin(idx, mb), 32)
     assert list(res[4][:6]) == [0] * 6 and res[4][6] != 0 and res[4][7] != 0

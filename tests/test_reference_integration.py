@@ -382,3 +382,85 @@ def test_highlight_text_matches_the_reference_vectors_the_oracle_and_a_python_re
         veloci_amd.highlight_text("a b", ["a"], {"num_words_around_snippet": -1})
     with pytest.raises(veloci_amd.VelociError):
         veloci_amd.highlight_text("a b", ["a"], {"max_snippets": "x"})
+
+
+# ---------------------------------------------------------------- why_found with select (search.rs:220-224, search/why_found.rs)
+def _load_why_found():
+    import os
+    with open(os.path.join(refcases.HERE, "golden", "reference_why_found.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def why_found_select_requests():
+    """Requests with `why_found` and `select` on the reference's `test_all` corpus: one and several fields, 1:n and nested paths, fuzzy / prefix terms
+    (several matched tokens per text), trees, top / skip windows, a field searched twice.  Shared by the oracle's own checks and the GPU parity test."""
+    def leaf(**kw):
+        return {"search": kw}
+    reqs = []
+    for path in ("mylongtext", "tags[]", "sub_level[].text", "meanings.ger[]", "meanings.eng[]", "ent_seq", "field1[].text"):
+        for term, kw in (("story", {}), ("the", {}), ("a", {}), ("nice", {}), ("majestät", {}), ("will", {"starts_with": True}), ("test", {"levenshtein_distance": 1}),
+                         ("der", {}), ("1587690", {}), ("awesome", {})):
+            reqs.append({"search_req": leaf(terms=[term], path=path, **kw), "why_found": True, "select": ["ent_seq"]})
+    reqs += [
+        {"search_req": {"or": {"queries": [leaf(terms=["story"], path="mylongtext"), leaf(terms=["nice"], path="tags[]"), leaf(terms=["will"], path="meanings.eng[]")]}},
+         "why_found": True, "select": ["tags[]"], "top": 20},
+        {"search_req": {"and": {"queries": [leaf(terms=["the"], path="mylongtext"), leaf(terms=["a"], path="mylongtext")]}}, "why_found": True, "select": []},
+        {"search_req": {"or": {"queries": [leaf(terms=["the"], path="mylongtext"), leaf(terms=["the"], path="mylongtext", levenshtein_distance=1)]}},
+         "why_found": True, "select": ["x"]},
+        {"search_req": {"or": {"queries": [leaf(terms=["majestät"], path="meanings.ger[]"), leaf(terms=["majestätischer"], path="meanings.ger[]"),
+                                           leaf(terms=["anblick"], path="meanings.ger[]", levenshtein_distance=1)]}}, "why_found": True, "select": ["meanings"], "top": 3, "skip": 1},
+        {"search_req": leaf(terms=["will"], path="meanings.eng[]", starts_with=True), "why_found": True, "select": ["a"], "top": 2, "skip": 2},
+        {"search_req": leaf(terms=["nope"], path="mylongtext"), "why_found": True, "select": ["a"]},
+        {"search_req": leaf(terms=["story"], path="mylongtext"), "why_found": True, "select": ["a"], "top": 0},
+        {"search_req": leaf(terms=["story"], path="mylongtext"), "why_found": True, "select": ["a"], "text_locality": True},
+        {"search_req": leaf(terms=["nice"], path="tags[]"), "why_found": True, "select": ["a"], "filter": leaf(terms=["cool"], path="tags[]"),
+         "facets": [{"field": "tags[]"}]},
+        {"search_req": leaf(terms=["story"], path="mylongtext"), "select": ["mylongtext"]},   # select without why_found: nothing more than the search
+        {"search_req": leaf(terms=["story"], path="mylongtext"), "why_found": True},           # why_found without select: the terms only
+    ]
+    return reqs
+
+
+def test_oracle_reproduces_reference_why_found_with_select_assertions():
+    from oracle import binding as O
+    from veloci_amd import mini_indexer
+    fx = _load_why_found()
+    oracles = {}
+    for case in fx["cases"]:
+        if case["corpus"] not in oracles:
+            c = fx["corpora"][case["corpus"]]
+            data, info = mini_indexer.build_index(refcases.corpus_docs(c), c["indices"])
+            ora = O.OracleIndex(data.num_anchors)
+            data.load_into(ora)
+            oracles[case["corpus"]] = (ora, refcases.corpus_docs(c))
+        ora, docs = oracles[case["corpus"]]
+        res = ora.search_json(json.dumps(case["request"]))
+        assert len(res.ids) >= 1, case["name"]
+        for k, v in case.get("expect_doc", {}).items():
+            assert docs[int(res.ids[0])][k] == v, case["name"]
+        assert res.why_found_info.get(int(res.ids[0]), {}) == case["expect_why_found"], (case["name"], res.why_found_info)
+    # wider, on the reference's main test corpus: only returned anchors carry entries, every entry is one of the anchor's texts of the field with
+    # its matched tokens tagged, nothing is produced unless both flags are set
+    data, docs, info = refcases.build("test_all")
+    ora = O.OracleIndex(data.num_anchors)
+    data.load_into(ora)
+    with_entries = 0
+    for req in why_found_select_requests():
+        try:
+            res = ora.search_json(json.dumps(req))
+        except O.OracleError:
+            continue
+        if not (req.get("why_found") and "select" in req):
+            assert res.why_found_info == {}, req
+            continue
+        assert set(res.why_found_info) <= set(int(i) for i in res.ids), req
+        for anchor, fields in res.why_found_info.items():
+            for field, texts in fields.items():
+                assert field + ".textindex" in res.why_found_terms, (req, field)
+                terms = set(res.why_found_terms[field + ".textindex"])
+                for t in texts:
+                    with_entries += 1
+                    assert "<b>" in t and "</b>" in t, (req, t)
+                    tagged = [piece.split("</b>")[0] for piece in t.split("<b>")[1:]]
+                    assert all(x in terms for x in tagged), (req, t, terms)
+    assert with_entries > 40, with_entries

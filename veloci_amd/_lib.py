@@ -16,7 +16,7 @@ SYMBOLS = [
     "vq_index_add_key_value_store", "vq_index_add_phrase_pair_to_anchor", "vq_index_add_boost", "vq_index_set_column_meta", "vq_index_build",
     "vq_index_free", "vq_index_set_stream", "vq_index_set_streams", "vq_index_set_allreduce", "vq_index_device_bytes", "vq_request_parse", "vq_request_free", "vq_request_to_json", "vq_request_has_facets", "vq_request_page_after", "vq_result_is_page", "vq_debug_to_lowercase", "vq_debug_normalize_text", "vq_debug_sort_unique_u32", "vq_debug_compile", "vq_result_num_hits",
     "vq_result_execution_time_ns", "vq_result_len", "vq_result_ids", "vq_result_scores", "vq_result_num_facets", "vq_result_facet_field",
-    "vq_result_facet_len", "vq_result_facet_value", "vq_result_facet_count", "vq_result_to_json", "vq_result_why_found_terms_json", "vq_result_explain_json", "vq_result_free", "vq_search", "vq_search_json",
+    "vq_result_facet_len", "vq_result_facet_value", "vq_result_facet_count", "vq_result_to_json", "vq_result_why_found_terms_json", "vq_result_why_found_info_json", "vq_result_explain_json", "vq_result_free", "vq_search", "vq_search_json",
     "vq_highlight_json", "vq_highlight_text", "vq_suggest_json", "vq_suggest_len", "vq_suggest_text", "vq_suggest_score", "vq_suggest_term_id", "vq_suggest_free",
     "vq_search_batch", "vq_search_batch_flat", "vq_search_batch_partial", "vq_partial_bytes", "vq_partial_device_ptr", "vq_partial_hist_bytes",
     "vq_partial_hist_device_ptr", "vq_merge_partials", "vq_merge_partials_flat", "vq_partial_free",
@@ -98,6 +98,7 @@ def lib():
         "vq_result_facet_count": (u64, [vp, sz, sz]),
         "vq_result_to_json": (cp, [vp]),
         "vq_result_why_found_terms_json": (cp, [vp]),
+        "vq_result_why_found_info_json": (cp, [vp]),
         "vq_result_explain_json": (cp, [vp]),
         "vq_suggest_json": (i, [vp, cp, sz, C.POINTER(vp)]),
         "vq_highlight_json": (i, [vp, cp, sz, C.POINTER(vp)]),

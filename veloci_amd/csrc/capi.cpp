@@ -93,6 +93,18 @@ static void why_found_terms_json(std::string& s, const std::map<std::string, std
     s += '}';
 }
 
+static void why_found_info_json(std::string& s, const Result& R) {  // {"<anchor id>": {"<field>": ["highlighted text", ...]}}
+    s += '{';
+    bool first = true;
+    for (auto& [anchor, fields] : R.why_found_info) {
+        if (!first) s += ',';
+        first = false;
+        s += '"' + std::to_string(anchor) + "\":";
+        why_found_terms_json(s, fields);
+    }
+    s += '}';
+}
+
 // ---- canonical dump of a parsed request: every field of search::Request in declaration order, absent options as null, f32 values as their bit
 // patterns — what the parser understood, for the golden request-parse fixtures (tests/golden/request_parse.json)
 namespace {
@@ -532,6 +544,10 @@ const char* vq_result_to_json(const vq_result* r) {
         s += ",\"why_found_terms\":";
         why_found_terms_json(s, r->r.why_found_terms);
     }
+    if (r->r.why_found_plan) {
+        s += ",\"why_found_info\":";
+        why_found_info_json(s, r->r);
+    }
     s += '}';
     return s.c_str();
 }
@@ -546,6 +562,13 @@ const char* vq_result_why_found_terms_json(const vq_result* r) {
     thread_local std::string s;
     s.clear();
     why_found_terms_json(s, r->r.why_found_terms);
+    return s.c_str();
+}
+const char* vq_result_why_found_info_json(const vq_result* r) {
+    thread_local std::string s;
+    s.clear();
+    if (!r->r.why_found_plan) return "null";
+    why_found_info_json(s, r->r);
     return s.c_str();
 }
 void vq_result_free(vq_result* r) { delete r; }
@@ -661,6 +684,7 @@ static int run_batch(const vq_index* index, const vq_request* const* requests, s
         }  // (the batch's workspace is free again: deep requests scan on)
         complete_deep_requests(*index->idx, reqs.data() + b, e - b, r, s2, e2);
         complete_explain_requests(*index->idx, r, s2, e2);
+        complete_why_found_requests(*index->idx, r, s2, e2);
         for (size_t i = b; i < e; ++i) {
             results[i] = std::move(r[i - b]);
             st[i] = s2[i - b];
@@ -724,13 +748,13 @@ int vq_search_batch(const vq_index* index, const vq_request* const* requests, si
     });
 }
 
-// Explain records are produced by vq_search / vq_search_json / vq_search_batch: the flat outputs have no place for them, and on the sharded path a
-// rank only holds the postings of its own docs.
+// Explain records and why_found_info (why_found with select) are produced by vq_search / vq_search_json / vq_search_batch: the flat outputs have no
+// place for them, and on the sharded path a rank only holds the postings and the texts of its own docs.
 static void decline_explain(std::vector<std::unique_ptr<Result>>& results, std::vector<int>& st, std::vector<std::string>& errs, const char* where) {
     for (size_t i = 0; i < results.size(); ++i)
-        if (st[i] == 0 && results[i] && results[i]->explain_plan) {
+        if (st[i] == 0 && results[i] && (results[i]->explain_plan || results[i]->why_found_plan)) {
             st[i] = VQ_ERR_UNSUPPORTED;
-            errs[i] = std::string("unsupported on the MI355X query path: explain on ") + where;
+            errs[i] = std::string("unsupported on the MI355X query path: ") + (results[i]->explain_plan ? "explain on " : "why_found with select on ") + where;
             results[i].reset();
         }
 }

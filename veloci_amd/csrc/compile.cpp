@@ -1884,8 +1884,8 @@ struct Compiler {
         cq.pres.reserve(8);
         cq.pres_in.reserve(16);
         by_address.reserve(8);
-        if (req.has_select) unsupported("select");
-        if (req.why_found && req.has_select) unsupported("why_found with select (why_found_info: highlighting of the returned documents)");
+        // (`select` itself is not looked at: search::search leaves the reading of the selected fields to to_documents, search.rs:63-103; together with
+        //  why_found it asks for why_found_info, :220-224 — complete_why_found_requests)
         if (req.has_suggest) unsupported("suggest");
         if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
         const uint64_t top64 = req.top.value_or(10), skip64 = req.skip.value_or(0);  // :146
@@ -2044,6 +2044,17 @@ struct Compiler {
                 }
             }
 
+        if (req.why_found && req.has_select) {  // search.rs:220-224, why_found.rs:20-31
+            if (idx.sharded()) unsupported("why_found with select on a shard (why_found_info joins the returned anchors to their texts: the caller's merged page may hold other shards' anchors)");
+            auto plan = std::make_shared<WhyFoundPlan>();
+            for (auto& [path, terms] : term_id_hits) {
+                std::vector<uint32_t>& all = (*plan)[path];
+                for (auto& [term, ids] : terms) all.insert(all.end(), ids.begin(), ids.end());
+                std::sort(all.begin(), all.end());
+                all.erase(std::unique(all.begin(), all.end()), all.end());
+            }
+            cq.why_found_plan = std::move(plan);
+        }
         // text locality (search.rs:180-184, boost.rs:11-87)
         if (req.text_locality)
             for (auto& [path, terms] : term_id_hits) {
@@ -2654,6 +2665,60 @@ std::vector<SuggestEntry> highlight_part(const Index& idx, const RequestSearchPa
     return out;
 }
 
+// get_why_found (src/search/why_found.rs:11-50) for the finished requests that asked for why_found together with select: for every searched field
+// and every returned anchor, the anchor's texts of the field (join_anchor_to_leaf, facet.rs:75-93) highlighted with all term ids the search matched
+// there (highlight_document with DEFAULT_SNIPPETINFO, highlight_field.rs:187-272); a text without a hit leaves no entry.
+void complete_why_found_requests(const Index& idx, std::vector<std::unique_ptr<Result>>& results, std::vector<int>& status, std::vector<std::string>& errors) {
+    static const vqreq::SnippetInfo kDefault;
+    for (size_t i = 0; i < results.size(); ++i) {
+        if (status[i] != 0 || !results[i] || !results[i]->why_found_plan) continue;
+        Result& R = *results[i];
+        try {
+            for (auto& [path, wanted] : *R.why_found_plan) {  // (wanted: sorted, unique)
+                if (wanted.empty() || R.ids.empty()) continue;  // why_found.rs:29-31
+                const std::string field_name = path.substr(0, path.size() - std::strlen(TEXTINDEX));
+                const std::vector<std::string> steps = get_steps_to_anchor(field_name);
+                auto store = [&](const std::string& name) -> const KVStore& {
+                    auto it = idx.kv.find(name);
+                    if (it == idx.kv.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + name);
+                    return it->second;
+                };
+                std::vector<const KVStore*> chain;
+                for (auto& st : steps) chain.push_back(&store(st + PARENT_TO_VALUE_ID));
+                const KVStore& t2t = store(steps.back() + ".text_id_to_token_ids");
+                auto dit = idx.dict.find(steps.back());
+                if (dit == idx.dict.end()) throw VelociError(ERR_INDEX_NOT_FOUND, "Did not found path in indices " + steps.back() + ".fst");
+                const Dictionary& dict = dit->second;
+                std::vector<uint32_t> level, next;
+                for (uint32_t anchor : R.ids) {
+                    level.assign(1, anchor);
+                    for (const KVStore* st : chain) {
+                        next.clear();
+                        for (uint32_t id : level) {
+                            const uint32_t *rb, *re;
+                            if (st->host_row(id, &rb, &re)) next.insert(next.end(), rb, re);
+                        }
+                        level.swap(next);
+                    }
+                    for (uint32_t value_id : level) {
+                        const uint32_t *b, *e;
+                        if (t2t.host_row(value_id, &b, &e)) {
+                            bool any = false;
+                            std::string sn = snippet_of_text(dict, b, size_t(e - b), wanted, kDefault, &any);
+                            if (any) R.why_found_info[anchor][field_name].push_back(std::move(sn));
+                        } else if (std::binary_search(wanted.begin(), wanted.end(), value_id))  // the text is its own only token: all of it (highlight_field.rs:198-203)
+                            R.why_found_info[anchor][field_name].push_back(kDefault.snippet_start_tag + (value_id < dict.terms.size() ? dict.terms[value_id] : std::string()) +
+                                                                           kDefault.snippet_end_tag);
+                    }
+                }
+            }
+        } catch (const VelociError& e) {
+            status[i] = e.code;
+            errors[i] = e.what();
+            results[i].reset();
+        }
+    }
+}
 
 // ---- dictionary scans requested by a batch (collected before compilation, answered by k_dict_scan)
 std::string fuzzy_key(const RequestSearchPart& p) {

@@ -552,6 +552,7 @@ struct ExplainNode {  // one node of the request's score tree, as the reference 
     std::map<uint32_t, ExplainRecs> term_records;  // the dictionary result's explain map, keyed by TERM id (search_field.rs:336-343; field_result.rs:44 copies it
                                                    // into the anchor-keyed result: an anchor whose id is one of these keys starts with that term's records)
 };
+using WhyFoundPlan = std::map<std::string, std::vector<uint32_t>>;
 struct ExplainPlan {
     std::vector<ExplainNode> nodes;
     int root = -1;
@@ -565,6 +566,9 @@ struct CompiledQuery {
     size_t blob_bytes = 0, desc_bytes = 0;  // size of the packed blob / of its descriptor part, taken right after compilation on the compiling thread (0: not taken)
     int status = 0;
     std::shared_ptr<const ExplainPlan> explain_plan;  // request.explain: what complete_explain_requests needs for the returned hits
+    // request.why_found with request.select (search.rs:220-224): textindex path -> all term ids the search matched there (what get_why_found flattens out of
+    // term_id_hits_in_field, why_found.rs:24-27); complete_why_found_requests highlights the returned anchors' texts with them
+    std::shared_ptr<const WhyFoundPlan> why_found_plan;
     std::string error;
     std::vector<RangeJob> range_requests;  // status == kStatusNeedsRanges
     std::vector<UnionJob> union_requests;  // status == kStatusNeedsUnion: jobs to run before compiling again
@@ -624,6 +628,9 @@ struct Result;
 // ranks only keys below the previous page's last) and cut the requested window.
 // explain records of the returned hits (k_explain + host formatting); requests without `explain` are left alone
 void complete_explain_requests(const Index& idx, std::vector<std::unique_ptr<Result>>& results, std::vector<int>& status, std::vector<std::string>& errors);
+// why_found_info of the returned hits (get_why_found, search/why_found.rs:11-50): host work over the host copies of the key-value stores and the
+// dictionary, on the final window of ids; requests without `why_found` + `select` are left alone
+void complete_why_found_requests(const Index& idx, std::vector<std::unique_ptr<Result>>& results, std::vector<int>& status, std::vector<std::string>& errors);
 bool request_wants_explain(const vqreq::Request& req);
 std::string explain_records_json(const ExplainRecs& records);
 void complete_deep_requests(const Index& idx, const vqreq::Request* const* reqs, size_t n, std::vector<std::unique_ptr<Result>>& results,
@@ -643,6 +650,8 @@ struct Result {
     bool has_facets = false;
     std::map<std::string, std::vector<std::string>> why_found_terms;
     std::shared_ptr<const ExplainPlan> explain_plan;
+    std::shared_ptr<const WhyFoundPlan> why_found_plan;
+    std::map<uint32_t, std::map<std::string, std::vector<std::string>>> why_found_info;  // search.rs:220-224: anchor -> field -> highlighted texts
     bool has_explain = false;
     std::vector<std::pair<bool, ExplainRecs>> explain;  // per returned hit: (the reference's map has an entry for the hit, its records) — search.rs:86,96
     bool deep = false;  // holds the first page of a deep request (see CompiledQuery::deep)

@@ -1988,6 +1988,7 @@ void finish_batch(const Index& idx, PartialBatch& pb, const void* gathered_devic
         if (!cq.facet_out.empty()) r->has_facets = true;
         r->why_found_terms = cq.why_found_terms;
         r->explain_plan = cq.explain_plan;
+        r->why_found_plan = cq.why_found_plan;
         for (size_t f = 0; f < cq.facet_out.size(); ++f, ++job) {
             const FacetOut& fo = cq.facet_out[f];
             ResultFacet rf;

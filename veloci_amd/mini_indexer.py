@@ -351,8 +351,10 @@ def build_index(docs, indices="", token_values=None):
         tp = path + TEXTINDEX
         if d["tokens_to_text_id"] is not None:
             data.add_key_value_store(tp + ".tokens_to_text_id", *csr_from_lists(_multi_store(d["tokens_to_text_id"], True)))
-        if d["text_id_to_token_ids"]:  # create.rs:633-635: insertion order kept, separators included, nothing deduplicated
-            rows = [[] for _ in range(max(d["text_id_to_token_ids"]) + 1)]
+        if d["text_id_to_token_ids"] is not None:  # create.rs:633-635: insertion order kept, separators included, nothing deduplicated
+            # (an untokenised field's store is written too, empty — persistence.rs:258-262 loads it as a store without keys: highlight_document finds
+            #  the index and no row, highlight_field.rs:196-207)
+            rows = [[] for _ in range(max(d["text_id_to_token_ids"], default=-1) + 1)]
             for k, v in d["text_id_to_token_ids"].items():
                 rows[k] = v
             data.add_key_value_store(tp + ".text_id_to_token_ids", *csr_from_lists(rows))

@@ -139,6 +139,8 @@ def _take_result(L, h):
         res.is_page = bool(L.vq_result_is_page(h))  # page 0 of a request that reaches beyond one scan's ranking (sharded merge only)
         wf = L.vq_result_why_found_terms_json(h)  # (requests without why_found / explain: two short strings, no JSON parsing per result)
         res.why_found_terms = {} if wf == b"{}" else json.loads(wf.decode())
+        wi = L.vq_result_why_found_info_json(h)  # why_found with select (search.rs:220-224): {anchor id: {field: [highlighted texts]}}; None when not asked
+        res.why_found_info = None if wi == b"null" else {int(k): v for k, v in json.loads(wi.decode()).items()}
         ex = L.vq_result_explain_json(h)  # per hit: null or its Explain records (src/search.rs:86,96); "null" without `explain`
         res.explain_json = ex.decode()
         res.explain = None if ex == b"null" else json.loads(res.explain_json)
