@@ -37,7 +37,7 @@ enum {
     VQ_ERR_FST_NOT_FOUND = 2,
     /* VelociError::StringError("Did not found path in indices ...") (src/persistence.rs:454-458) */
     VQ_ERR_INDEX_NOT_FOUND = 3,
-    /* request uses a feature outside the GPU hot path (snippets inside a search, the declined explain combinations, why_found_info on the flat / sharded entry points ...): never silently ignored */
+    /* request uses a feature outside the GPU hot path (the declined explain combinations, why_found_info on the flat / sharded entry points, the bounds of DESIGN.md §7 ...): never silently ignored */
     VQ_ERR_UNSUPPORTED = 4,
     /* HIP runtime failure / no device / extension missing */
     VQ_ERR_DEVICE = 5,

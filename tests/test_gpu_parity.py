@@ -198,7 +198,8 @@ def test_errors(corpus):
         veloci_amd.search({"top": 3}, idx)
     assert e2.value.code == 1
     with pytest.raises(veloci_amd.VelociError) as e3:
-        veloci_amd.search({"search_req": {"search": {"path": "body", "terms": ["x"], "snippet": True}}}, idx)  # snippets inside a search: vq_highlight_json's work
+        veloci_amd.search({"search_req": {"or": {"queries": [{"search": {"path": "body", "terms": ["x"], "options": {"explain": True}}},
+                                                             {"search": {"path": "body", "terms": ["y"]}}]}}}, idx)  # explain on a part of the tree: declined
     assert e3.value.code == 4
 
 
@@ -1709,9 +1710,9 @@ def test_sharded_step_error_paths_leave_the_index_usable(corpus):
     empty = veloci_amd.RequestBatch([])
     out = shard_step_end(shard_step_begin(idx, empty), 10)
     assert len(out[0]) == 0
-    # a request the path declines (a snippet inside a search) and one that fails to compile (unknown field) ride along: statuses, not a failed step
-    declined = json.loads(json.dumps(synth.req_single(meta.extra_probes[0])))
-    declined["search_req"]["search"]["snippet"] = True
+    # a request the path declines (explain on a part of its tree) and one that fails to compile (unknown field) ride along: statuses, not a failed step
+    part = synth.req_single(meta.extra_probes[0])["search_req"]["search"]
+    declined = {"search_req": {"or": {"queries": [{"search": dict(part, options={"explain": True})}, {"search": dict(part)}]}}}
     mixed = reqs[:6] + [declined, {"search_req": {"search": {"terms": ["x"], "path": "nosuchfield"}}}]
     mb = veloci_amd.RequestBatch(mixed)
     res = shard_step_end(shard_step_begin(idx, mb), 32)

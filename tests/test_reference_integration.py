@@ -415,6 +415,11 @@ def why_found_select_requests():
         {"search_req": leaf(terms=["story"], path="mylongtext"), "why_found": True, "select": ["a"], "text_locality": True},
         {"search_req": leaf(terms=["nice"], path="tags[]"), "why_found": True, "select": ["a"], "filter": leaf(terms=["cool"], path="tags[]"),
          "facets": [{"field": "tags[]"}]},
+        # what search::search does not look at changes nothing: snippet options on a leaf (plan_steps.rs:184 resolves ids only), a suggest beside the search
+        {"search_req": leaf(terms=["story"], path="mylongtext", snippet=True, snippet_info={"max_snippets": 1}), "why_found": True, "select": ["a"]},
+        {"search_req": {"or": {"queries": [leaf(terms=["story"], path="mylongtext", snippet=True), leaf(terms=["story"], path="mylongtext")]}}},
+        {"search_req": leaf(terms=["will"], path="meanings.eng[]", starts_with=True, snippet_info={"num_words_around_snippet": 1}), "top": 3},
+        {"search_req": leaf(terms=["nice"], path="tags[]"), "suggest": [{"terms": ["ni"], "path": "tags[]", "starts_with": True}]},
         {"search_req": leaf(terms=["story"], path="mylongtext"), "select": ["mylongtext"]},   # select without why_found: nothing more than the search
         {"search_req": leaf(terms=["story"], path="mylongtext"), "why_found": True},           # why_found without select: the terms only
     ]

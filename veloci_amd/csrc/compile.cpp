@@ -375,7 +375,8 @@ struct Compiler {
     void lookup_terms(const Index& idx, Leaf& l, bool get_scores, bool get_ids) {
         PhaseTimer pt(0);
         const RequestSearchPart& p = *l.part;
-        if (p.snippet.value_or(false) || p.has_snippet_info) unsupported("snippet");
+        // (`snippet` / `snippet_info` are not looked at here: a search resolves token hits with resolve_token_hits_to_text_id_ids_only, plan_steps.rs:184 —
+        //  snippets are made by search_field::highlight alone, search_field.rs:243 = vq_highlight_json)
         if (p.terms.empty()) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"terms is empty\" ");
         l.path = p.path;
         if (!ends_with(l.path, TEXTINDEX)) l.path += TEXTINDEX;
@@ -1886,7 +1887,7 @@ struct Compiler {
         by_address.reserve(8);
         // (`select` itself is not looked at: search::search leaves the reading of the selected fields to to_documents, search.rs:63-103; together with
         //  why_found it asks for why_found_info, :220-224 — complete_why_found_requests)
-        if (req.has_suggest) unsupported("suggest");
+        // (`suggest` is not looked at either: search::search reads search_req, search.rs:151-155; suggest_multi is vq_suggest_json)
         if (!req.search_req) throw VelociError(ERR_INVALID_REQUEST, "InvalidRequest: \"search_req is None, but is required in search\" ");
         const uint64_t top64 = req.top.value_or(10), skip64 = req.skip.value_or(0);  // :146
         const uint64_t want = top64 + skip64 < top64 ? ~0ull : top64 + skip64;
