@@ -242,6 +242,17 @@ def test_two_shards_merge_equals_unsharded(corpus):
     p1.merge(None, 1)  # releases the shard's workspace
     for r, got in zip(reqs, res):
         assert_same(r, got, ora.search_json(json.dumps(r)))
+    # why_found_info (why_found with select) joins the returned anchors to their texts: a shard declines it — its neighbours in the batch are answered
+    with pytest.raises(veloci_amd.VelociError) as e:
+        veloci_amd.search(dict(reqs[3], why_found=True, select=["body"]), s1)
+    assert e.value.code == 4 and "on a shard" in str(e.value)
+    # (the unsharded index goes on — to the reference's own error here: the synthetic corpus holds no parent_to_value_id store for the join)
+    from oracle.binding import OracleError
+    with pytest.raises(veloci_amd.VelociError) as e2:
+        veloci_amd.search(dict(reqs[3], why_found=True, select=["body"]), idx)
+    with pytest.raises(OracleError) as eo:
+        ora.search_json(json.dumps(dict(reqs[3], why_found=True, select=["body"])))
+    assert str(e2.value) == str(eo.value) == "Did not found path in indices body.textindex.parent_to_value_id"
 
 
 def test_two_shards_chunked_step_with_one_exchange_equals_unsharded(corpus):
